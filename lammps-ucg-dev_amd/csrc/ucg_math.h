@@ -1,0 +1,236 @@
+/* ucg_math.h -- exactly specified fp64 elementary functions (exp, expm1, log, tanh).
+ *
+ * Why this exists: the reference calls libm's std::exp / std::expm1 / std::log /
+ * std::tanh (UCG/fix_ucgstate.cpp:102, UCG/pair_table_ucg_bethe.cpp:550-551,
+ * UCG/pair_table_ucg_bethe_density.cpp:110,120,306,609,652).  glibc's and the
+ * GPU's (ocml) versions are both "< 1 ulp" but not bit-identical to each other,
+ * and the posteriors feed back into the dynamics (ucgl = ucgp), so a bitwise
+ * reproducible trajectory needs ONE definition evaluated with the same IEEE
+ * operations on the host and on gfx950.  These are straight-line restatements
+ * of the classic fdlibm algorithms (argument reduction + minimax polynomial),
+ * written only with + - * / and integer bit moves, so that with FMA contraction
+ * off they produce the same bits under gcc and under hipcc.
+ *
+ * Every translation unit that includes this header must be compiled with
+ * -ffp-contract=off.  tests/test_math.py checks each function against libm
+ * (<= 1 ulp) so a wrong constant cannot hide behind the shared definition.
+ */
+#ifndef UCG_MATH_H
+#define UCG_MATH_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define UCG_HD __host__ __device__ __forceinline__
+#else
+#define UCG_HD static inline
+#endif
+
+#if defined(__cplusplus) && defined(__HIPCC__)
+#define UCG_BITS_D2U(d) ((uint64_t)__builtin_bit_cast(unsigned long long, (d)))
+#define UCG_BITS_U2D(u) (__builtin_bit_cast(double, (unsigned long long)(u)))
+#else
+static inline uint64_t ucg_d2u_(double d) { union { double d; uint64_t u; } c; c.d = d; return c.u; }
+static inline double ucg_u2d_(uint64_t u) { union { double d; uint64_t u; } c; c.u = u; return c.d; }
+#define UCG_BITS_D2U(d) ucg_d2u_(d)
+#define UCG_BITS_U2D(u) ucg_u2d_(u)
+#endif
+
+/* y * 2^k for finite y in [0.25, 4) and integer k, by exponent arithmetic; two
+ * steps near the subnormal range so the final rounding is a single multiply. */
+UCG_HD double ucg_scalbn_(double y, int k)
+{
+  if (k >= -1021) {
+    if (k > 1023) { /* only reached for results about to overflow */
+      y = UCG_BITS_U2D(UCG_BITS_D2U(y) + ((uint64_t)1023 << 52));
+      k -= 1023;
+      if (k > 1023) k = 1023;
+      return y * UCG_BITS_U2D((uint64_t)(k + 1023) << 52);
+    }
+    return UCG_BITS_U2D(UCG_BITS_D2U(y) + ((uint64_t)(int64_t)k << 52));
+  }
+  /* twom1000 = 2^-1000 */
+  y = UCG_BITS_U2D(UCG_BITS_D2U(y) + ((uint64_t)(int64_t)(k + 1000) << 52));
+  return y * 9.33263618503218878990e-302;
+}
+
+UCG_HD double ucg_exp(double x)
+{
+  const double o_threshold = 7.09782712893383973096e+02;
+  const double u_threshold = -7.45133219101941108420e+02;
+  const double ln2HI = 6.93147180369123816490e-01;
+  const double ln2LO = 1.90821492927058770002e-10;
+  const double invln2 = 1.44269504088896338700e+00;
+  const double P1 = 1.66666666666666019037e-01;
+  const double P2 = -2.77777777770155933842e-03;
+  const double P3 = 6.61375632143793436117e-05;
+  const double P4 = -1.65339022054652515390e-06;
+  const double P5 = 4.13813679705723846039e-08;
+
+  if (x != x) return x;
+  if (x > o_threshold) return UCG_BITS_U2D((uint64_t)0x7ff0000000000000ULL);
+  if (x < u_threshold) return 0.0;
+
+  double hi = x, lo = 0.0;
+  int k = 0;
+  const double ax = x < 0.0 ? -x : x;
+  if (ax > 0.34657359027997264) { /* |x| > 0.5 ln2 */
+    k = (int)(invln2 * x + (x < 0.0 ? -0.5 : 0.5));
+    const double t = (double)k;
+    hi = x - t * ln2HI;
+    lo = t * ln2LO;
+    x = hi - lo;
+  }
+  const double t = x * x;
+  const double c = x - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+  if (k == 0) return 1.0 - ((x * c) / (c - 2.0) - x);
+  const double y = 1.0 - ((lo - (x * c) / (2.0 - c)) - hi);
+  return ucg_scalbn_(y, k);
+}
+
+UCG_HD double ucg_expm1(double x)
+{
+  const double o_threshold = 7.09782712893383973096e+02;
+  const double ln2_hi = 6.93147180369123816490e-01;
+  const double ln2_lo = 1.90821492927058770002e-10;
+  const double invln2 = 1.44269504088896338700e+00;
+  const double Q1 = -3.33333333333331316428e-02;
+  const double Q2 = 1.58730158725481460165e-03;
+  const double Q3 = -7.93650757867487942473e-05;
+  const double Q4 = 4.00821782732936239552e-06;
+  const double Q5 = -2.01099218183624371326e-07;
+
+  if (x != x) return x;
+  if (x > o_threshold) return UCG_BITS_U2D((uint64_t)0x7ff0000000000000ULL);
+  if (x < -38.816242111356935) return -1.0; /* x < -56 ln2: exp(x)-1 rounds to -1 */
+
+  const double ax = x < 0.0 ? -x : x;
+  double hi, lo, c = 0.0;
+  int k = 0;
+  if (ax > 0.34657359027997264) {
+    k = (int)(invln2 * x + (x < 0.0 ? -0.5 : 0.5));
+    const double t = (double)k;
+    hi = x - t * ln2_hi;
+    lo = t * ln2_lo;
+    x = hi - lo;
+    c = (hi - x) - lo;
+  } else if (ax < 5.551115123125783e-17) { /* |x| < 2^-54 */
+    return x;
+  }
+
+  const double hfx = 0.5 * x;
+  const double hxs = x * hfx;
+  const double r1 = 1.0 + hxs * (Q1 + hxs * (Q2 + hxs * (Q3 + hxs * (Q4 + hxs * Q5))));
+  double t = 3.0 - r1 * hfx;
+  double e = hxs * ((r1 - t) / (6.0 - x * t));
+  if (k == 0) return x - (x * e - hxs);
+  e = (x * (e - c) - c);
+  e -= hxs;
+  if (k == -1) return 0.5 * (x - e) - 0.5;
+  if (k == 1) {
+    if (x < -0.25) return -2.0 * (e - (x + 0.5));
+    return 1.0 + 2.0 * (x - e);
+  }
+  double y;
+  if (k <= -2 || k > 56) {
+    y = 1.0 - (e - x);
+    y = ucg_scalbn_(y, k);
+    return y - 1.0;
+  }
+  if (k < 20) {
+    /* t = 1 - 2^-k */
+    t = UCG_BITS_U2D(((uint64_t)(0x3ff00000u - (0x200000u >> k))) << 32);
+    y = t - (e - x);
+    y = ucg_scalbn_(y, k);
+  } else {
+    /* t = 2^-k */
+    t = UCG_BITS_U2D(((uint64_t)(0x3ff - k)) << 52);
+    y = x - (e + t);
+    y += 1.0;
+    y = ucg_scalbn_(y, k);
+  }
+  return y;
+}
+
+UCG_HD double ucg_log(double x)
+{
+  const double ln2_hi = 6.93147180369123816490e-01;
+  const double ln2_lo = 1.90821492927058770002e-10;
+  const double two54 = 1.80143985094819840000e+16;
+  const double Lg1 = 6.666666666666735130e-01;
+  const double Lg2 = 3.999999999940941908e-01;
+  const double Lg3 = 2.857142874366239149e-01;
+  const double Lg4 = 2.222219843214978396e-01;
+  const double Lg5 = 1.818357216161805012e-01;
+  const double Lg6 = 1.531383769920937332e-01;
+  const double Lg7 = 1.479819860511658591e-01;
+
+  uint64_t u = UCG_BITS_D2U(x);
+  int32_t hx = (int32_t)(u >> 32);
+  uint32_t lx = (uint32_t)u;
+  int k = 0;
+  if (hx < 0x00100000) {
+    if (((hx & 0x7fffffff) | lx) == 0) return UCG_BITS_U2D((uint64_t)0xfff0000000000000ULL); /* -inf */
+    if (hx < 0) return UCG_BITS_U2D((uint64_t)0x7ff8000000000000ULL);                        /* nan  */
+    k -= 54;
+    x *= two54;
+    u = UCG_BITS_D2U(x);
+    hx = (int32_t)(u >> 32);
+  }
+  if (hx >= 0x7ff00000) return x + x;
+  k += (hx >> 20) - 1023;
+  hx &= 0x000fffff;
+  int32_t i = (hx + 0x95f64) & 0x100000;
+  u = (u & 0xffffffffULL) | ((uint64_t)(uint32_t)(hx | (i ^ 0x3ff00000)) << 32);
+  x = UCG_BITS_U2D(u);
+  k += (i >> 20);
+  const double f = x - 1.0;
+  const double dk = (double)k;
+  if ((0x000fffff & (2 + hx)) < 3) { /* |f| < 2^-20 */
+    if (f == 0.0) {
+      if (k == 0) return 0.0;
+      return dk * ln2_hi + dk * ln2_lo;
+    }
+    const double R = f * f * (0.5 - 0.33333333333333333 * f);
+    if (k == 0) return f - R;
+    return dk * ln2_hi - ((R - dk * ln2_lo) - f);
+  }
+  const double s = f / (2.0 + f);
+  const double z = s * s;
+  i = hx - 0x6147a;
+  const double w = z * z;
+  const int32_t j = 0x6b851 - hx;
+  const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+  const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+  i |= j;
+  const double R = t2 + t1;
+  if (i > 0) {
+    const double hfsq = 0.5 * f * f;
+    if (k == 0) return f - (hfsq - s * (hfsq + R));
+    return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+  }
+  if (k == 0) return f - s * (f - R);
+  return dk * ln2_hi - ((s * (f - R) - dk * ln2_lo) - f);
+}
+
+UCG_HD double ucg_tanh(double x)
+{
+  if (x != x) return x;
+  const double ax = x < 0.0 ? -x : x;
+  double z;
+  if (ax < 22.0) {
+    if (ax < 2.7755575615628914e-17) return x * (1.0 + x); /* |x| < 2^-55 */
+    if (ax >= 1.0) {
+      const double t = ucg_expm1(2.0 * ax);
+      z = 1.0 - 2.0 / (t + 2.0);
+    } else {
+      const double t = ucg_expm1(-2.0 * ax);
+      z = -t / (t + 2.0);
+    }
+  } else {
+    z = 1.0;
+  }
+  return x < 0.0 ? -z : z;
+}
+
+#endif /* UCG_MATH_H */

@@ -1,0 +1,399 @@
+"""ctypes binding of the CPU oracle (liborc.so).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module.  The product (lammps-ucg-dev_amd/) never does.  See oracle/orc.h for the
+"parity unpinned" statement and the reference citations.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+c_double_p = C.POINTER(C.c_double)
+c_int_p = C.POINTER(C.c_int)
+c_ll_p = C.POINTER(C.c_longlong)
+
+STYLE_UCGLD, STYLE_BETHE, STYLE_BETHE_DENSITY = 0, 1, 2
+LOOKUP, LINEAR, SPLINE, BITMAP = 0, 1, 2, 3
+ORIENT_BIT = 29
+NEIGHMASK = 0x1FFFFFFF
+
+
+class Atoms(C.Structure):
+    _fields_ = [
+        ("nlocal", C.c_int), ("nghost", C.c_int),
+        ("x", c_double_p), ("v", c_double_p), ("f", c_double_p),
+        ("type", c_int_p), ("tag", c_int_p), ("mask", c_int_p),
+        ("ucgstate", c_int_p), ("num_ucgstates", c_int_p),
+        ("ucgl", c_double_p), ("ucgvl", c_double_p), ("ucgml", c_double_p),
+        ("ucgp", c_double_p), ("ucgforce", c_double_p),
+        ("scores", c_double_p), ("mass", c_double_p),
+    ]
+
+
+class NList(C.Structure):
+    _fields_ = [
+        ("inum", C.c_int), ("ilist", c_int_p), ("numneigh", c_int_p),
+        ("first", c_ll_p), ("neigh", c_int_p),
+    ]
+
+
+class Ev(C.Structure):
+    _fields_ = [("eng_vdwl", C.c_double), ("virial", C.c_double * 6), ("err", C.c_int),
+                ("err_i", C.c_int), ("err_j", C.c_int)]
+
+
+class RanMars(C.Structure):
+    _fields_ = [("u", C.c_double * 98), ("i97", C.c_int), ("j97", C.c_int),
+                ("c", C.c_double), ("cd", C.c_double), ("cm", C.c_double)]
+
+
+def build(force: bool = False) -> str:
+    """Compile liborc.so with the committed Makefile (gcc, -O2 -ffp-contract=off)."""
+    so = os.path.join(_HERE, "liborc.so")
+    srcs = [f for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+    newest = max(os.path.getmtime(os.path.join(_HERE, f)) for f in srcs)
+    mh = os.path.join(_HERE, "..", "lammps-ucg-dev_amd", "csrc", "ucg_math.h")
+    if os.path.exists(mh):
+        newest = max(newest, os.path.getmtime(mh))
+    if force or not os.path.exists(so) or os.path.getmtime(so) < newest:
+        subprocess.check_call(["make", "-s", "-C", _HERE, "liborc.so"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    L = C.CDLL(build())
+    L.orc_ranmars_init.argtypes = [C.POINTER(RanMars), C.c_int]
+    L.orc_ranmars_uniform.argtypes = [C.POINTER(RanMars)]
+    L.orc_ranmars_uniform.restype = C.c_double
+    L.orc_ranmars_fill.argtypes = [C.POINTER(RanMars), C.c_int, c_double_p]
+    L.orc_set_math.argtypes = [C.c_int]
+    for fn in ("orc_exp", "orc_expm1", "orc_log", "orc_tanh"):
+        getattr(L, fn).argtypes = [C.c_double]
+        getattr(L, fn).restype = C.c_double
+    L.orc_pair_create.argtypes = [C.c_int]
+    L.orc_pair_create.restype = C.c_void_p
+    L.orc_pair_destroy.argtypes = [C.c_void_p]
+    L.orc_pair_error.argtypes = [C.c_void_p]
+    L.orc_pair_error.restype = C.c_char_p
+    L.orc_pair_settings.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_char_p)]
+    L.orc_pair_coeff.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_char_p)]
+    L.orc_pair_init.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
+    L.orc_pair_compute_half.argtypes = [C.c_void_p, C.POINTER(Atoms), C.POINTER(NList), C.c_int,
+                                        C.c_int, C.c_int, C.POINTER(Ev)]
+    L.orc_pair_compute_gather.argtypes = [C.c_void_p, C.POINTER(Atoms), C.POINTER(NList), C.c_int,
+                                          C.c_int, C.POINTER(Ev)]
+    L.orc_pair_table_info.argtypes = [C.c_void_p, C.c_int, c_double_p]
+    L.orc_pair_table_array.argtypes = [C.c_void_p, C.c_int, C.c_char_p, c_int_p]
+    L.orc_pair_table_array.restype = c_double_p
+    L.orc_pair_int_array.argtypes = [C.c_void_p, C.c_char_p, c_int_p]
+    L.orc_pair_int_array.restype = c_int_p
+    L.orc_pair_dbl_array.argtypes = [C.c_void_p, C.c_char_p, c_int_p]
+    L.orc_pair_dbl_array.restype = c_double_p
+    L.orc_pair_set_compat.argtypes = [C.c_void_p, C.c_int]
+    L.orc_pair_density_compute.argtypes = [C.c_void_p, C.POINTER(Atoms), C.POINTER(NList), C.c_int,
+                                           C.c_int, C.POINTER(Ev)]
+    L.orc_force_clear.argtypes = [C.POINTER(Atoms), C.c_int]
+    L.orc_fix_nve_initial.argtypes = [C.POINTER(Atoms), C.c_double, C.c_double, C.c_int]
+    L.orc_fix_nve_final.argtypes = [C.POINTER(Atoms), C.c_double, C.c_double, C.c_int]
+    L.orc_fix_langevin_create.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int]
+    L.orc_fix_langevin_create.restype = C.c_void_p
+    L.orc_fix_langevin_destroy.argtypes = [C.c_void_p]
+    L.orc_fix_langevin_init.argtypes = [C.c_void_p, C.POINTER(Atoms), C.c_double, C.c_double, C.c_double, C.c_double]
+    L.orc_fix_langevin_post_force.argtypes = [C.c_void_p, C.POINTER(Atoms), C.c_int, C.c_longlong,
+                                              C.c_longlong, C.c_longlong]
+    L.orc_fix_langevin_end_of_step.argtypes = [C.c_void_p, C.POINTER(Atoms), C.c_int, C.c_double, C.c_double]
+    L.orc_fix_langevin_get.argtypes = [C.c_void_p, c_double_p]
+    L.orc_fix_ucgstate_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_int]
+    L.orc_fix_ucgstate_create.restype = C.c_void_p
+    L.orc_fix_ucgstate_destroy.argtypes = [C.c_void_p]
+    L.orc_fix_ucgstate_post_force.argtypes = [C.c_void_p, C.POINTER(Atoms)]
+    # sim
+    L.orc_sim_create.argtypes = [C.c_int, c_double_p, c_double_p, C.c_double, C.c_double, C.c_int]
+    L.orc_sim_create.restype = C.c_void_p
+    L.orc_sim_destroy.argtypes = [C.c_void_p]
+    L.orc_sim_atoms.argtypes = [C.c_void_p]
+    L.orc_sim_atoms.restype = C.POINTER(Atoms)
+    L.orc_sim_full_list.argtypes = [C.c_void_p]
+    L.orc_sim_full_list.restype = C.POINTER(NList)
+    L.orc_sim_half_list.argtypes = [C.c_void_p]
+    L.orc_sim_half_list.restype = C.POINTER(NList)
+    L.orc_sim_rebuild.argtypes = [C.c_void_p]
+    L.orc_sim_forward_comm.argtypes = [C.c_void_p]
+    L.orc_sim_reverse_comm.argtypes = [C.c_void_p]
+    L.orc_sim_setup.argtypes = [C.c_void_p, C.c_longlong]
+    L.orc_sim_run.argtypes = [C.c_void_p, C.c_longlong, C.c_int]
+    L.orc_sim_set_run_params.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.orc_sim_set_units.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double]
+    L.orc_sim_attach.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_int, C.c_double]
+    L.orc_sim_get_info.argtypes = [C.c_void_p, c_ll_p]
+    L.orc_sim_get_ev.argtypes = [C.c_void_p, c_double_p]
+    for fn in ("orc_sim_ghost_src", "orc_sim_ghost_shift", "orc_sim_bin_of"):
+        getattr(L, fn).argtypes = [C.c_void_p]
+        getattr(L, fn).restype = c_int_p
+    L.orc_sim_mass.argtypes = [C.c_void_p]
+    L.orc_sim_mass.restype = c_double_p
+    L.orc_sim_compute_forces.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    _LIB = L
+    return L
+
+
+def _dp(a):
+    return a.ctypes.data_as(c_double_p)
+
+
+def _ip(a):
+    return a.ctypes.data_as(c_int_p)
+
+
+def _argv(args):
+    arr = (C.c_char_p * len(args))(*[a.encode() for a in args])
+    return arr
+
+
+class OracleError(RuntimeError):
+    pass
+
+
+class Pair:
+    """Oracle pair style: same command arguments as the LAMMPS style."""
+
+    STYLES = {"table_ucgld": STYLE_UCGLD, "table_ucg_bethe": STYLE_BETHE,
+              "table_ucg_bethe_density": STYLE_BETHE_DENSITY}
+
+    def __init__(self, style: str):
+        self.L = lib()
+        self.style = style
+        self.h = self.L.orc_pair_create(self.STYLES[style])
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.orc_pair_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc:
+            raise OracleError(self.L.orc_pair_error(self.h).decode())
+
+    def settings(self, args):
+        self._chk(self.L.orc_pair_settings(self.h, len(args), _argv(args)))
+
+    def coeff(self, args, ntypes=2):
+        self._chk(self.L.orc_pair_coeff(self.h, ntypes, len(args), _argv(args)))
+
+    def init(self, ntypes=2, T=1.0, boltz=1.0):
+        self._chk(self.L.orc_pair_init(self.h, ntypes, T, boltz))
+
+    def set_compat(self, flags: int):
+        self.L.orc_pair_set_compat(self.h, flags)
+
+    def table_info(self, m):
+        out = np.zeros(8)
+        self.L.orc_pair_table_info(self.h, m, _dp(out))
+        return dict(innersq=out[0], delta=out[1], invdelta=out[2], deltasq6=out[3], cut=out[4],
+                    ninput=int(out[5]), match=int(out[6]))
+
+    def table_array(self, m, name):
+        n = C.c_int(0)
+        p = self.L.orc_pair_table_array(self.h, m, name.encode(), C.byref(n))
+        if not p:
+            return None
+        return np.ctypeslib.as_array(p, shape=(n.value,)).copy()
+
+    def int_array(self, name):
+        n = C.c_int(0)
+        p = self.L.orc_pair_int_array(self.h, name.encode(), C.byref(n))
+        return np.ctypeslib.as_array(p, shape=(n.value,)).copy()
+
+    def dbl_array(self, name):
+        n = C.c_int(0)
+        p = self.L.orc_pair_dbl_array(self.h, name.encode(), C.byref(n))
+        return np.ctypeslib.as_array(p, shape=(n.value,)).copy()
+
+
+class AtomArrays:
+    """numpy-owned per-atom arrays + the ctypes view the oracle functions take."""
+
+    def __init__(self, nlocal, nghost, ntypes=2):
+        nall = nlocal + nghost
+        self.nlocal, self.nghost = nlocal, nghost
+        self.x = np.zeros((nall, 3))
+        self.v = np.zeros((max(nlocal, 1), 3))
+        self.f = np.zeros((nall, 3))
+        self.type = np.ones(nall, dtype=np.int32)
+        self.tag = np.zeros(nall, dtype=np.int32)
+        self.mask = np.ones(nall, dtype=np.int32)
+        self.ucgstate = np.zeros(nall, dtype=np.int32)
+        self.num_ucgstates = np.zeros(nall, dtype=np.int32)
+        self.ucgl = np.zeros(nall)
+        self.ucgvl = np.zeros(nall)
+        self.ucgml = np.ones(nall)
+        self.ucgp = np.full(nall, -1.0)
+        self.ucgforce = np.zeros(nall)
+        self.scores = np.zeros((nall, 2))
+        self.mass = np.ones(ntypes + 1)
+
+    def cstruct(self):
+        a = Atoms()
+        a.nlocal, a.nghost = self.nlocal, self.nghost
+        for name in ("x", "v", "f", "ucgl", "ucgvl", "ucgml", "ucgp", "ucgforce", "scores", "mass"):
+            setattr(a, name, _dp(getattr(self, name)))
+        for name in ("type", "tag", "mask", "ucgstate", "num_ucgstates"):
+            setattr(a, name, _ip(getattr(self, name)))
+        return a
+
+
+def make_list(rows):
+    """rows: list of int arrays -> (NList, keepalive)"""
+    inum = len(rows)
+    numneigh = np.array([len(r) for r in rows], dtype=np.int32)
+    first = np.zeros(inum, dtype=np.int64)
+    if inum:
+        first[1:] = np.cumsum(numneigh[:-1])
+    neigh = np.concatenate([np.asarray(r, dtype=np.int32) for r in rows]) if inum and numneigh.sum() else np.zeros(1, dtype=np.int32)
+    ilist = np.arange(inum, dtype=np.int32)
+    return list_from_csr(ilist, numneigh, first, neigh)
+
+
+def list_from_csr(ilist, numneigh, first, neigh):
+    ilist = np.ascontiguousarray(ilist, dtype=np.int32)
+    numneigh = np.ascontiguousarray(numneigh, dtype=np.int32)
+    first = np.ascontiguousarray(first, dtype=np.int64)
+    neigh = np.ascontiguousarray(neigh, dtype=np.int32)
+    l = NList()
+    l.inum = len(ilist)
+    l.ilist = _ip(ilist)
+    l.numneigh = _ip(numneigh)
+    l.first = first.ctypes.data_as(c_ll_p)
+    l.neigh = _ip(neigh)
+    return l, (ilist, numneigh, first, neigh)
+
+
+def list_to_csr(lptr):
+    """copy an oracle-owned list out to numpy (ilist, numneigh, first, neigh)"""
+    l = lptr.contents if hasattr(lptr, "contents") else lptr
+    inum = l.inum
+    ilist = np.ctypeslib.as_array(l.ilist, shape=(inum,)).copy()
+    numneigh = np.ctypeslib.as_array(l.numneigh, shape=(inum,)).copy()
+    first = np.ctypeslib.as_array(l.first, shape=(inum,)).copy()
+    total = int(first[-1] + numneigh[-1]) if inum else 0
+    neigh = np.ctypeslib.as_array(l.neigh, shape=(max(total, 1),)).copy()[:total]
+    return ilist, numneigh, first, neigh
+
+
+class Sim:
+    """Oracle MD driver (orc_md.c)."""
+
+    def __init__(self, beads, cutforce=2.5, skin=0.3):
+        self.L = lib()
+        L = self.L
+        n = beads.n
+        lo = np.ascontiguousarray(beads.boxlo, dtype=np.float64)
+        hi = np.ascontiguousarray(beads.boxhi, dtype=np.float64)
+        self.h = L.orc_sim_create(n, _dp(lo), _dp(hi), cutforce, skin, beads.ntypes)
+        self._keep = []
+        a = L.orc_sim_atoms(self.h).contents
+        np.ctypeslib.as_array(a.x, shape=(n, 3))[:] = beads.x
+        np.ctypeslib.as_array(a.v, shape=(n, 3))[:] = beads.v
+        for name in ("type", "tag", "mask", "ucgstate"):
+            np.ctypeslib.as_array(getattr(a, name), shape=(n,))[:] = getattr(beads, name)
+        for name in ("ucgl", "ucgvl", "ucgml", "ucgp"):
+            np.ctypeslib.as_array(getattr(a, name), shape=(n,))[:] = getattr(beads, name)
+        np.ctypeslib.as_array(L.orc_sim_mass(self.h), shape=(beads.ntypes + 1,))[:] = beads.mass
+        self.pair = None
+        self.lang = None
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.orc_sim_destroy(self.h)
+                self.h = None
+            if self.lang:
+                self.L.orc_fix_langevin_destroy(self.lang)
+                self.lang = None
+        except Exception:
+            pass
+
+    def set_run_params(self, dt=0.002, every=1, delay=0, check=1, mode=1):
+        self.L.orc_sim_set_run_params(self.h, dt, every, delay, check, mode)
+
+    def attach(self, pair: Pair, langevin=None, nve=True, ucgstate=None, ntypes=2):
+        """langevin = (t_start, t_stop, damp, seed) or None; ucgstate = None | "ld" | "plain" | ("mc", seed, rate)"""
+        self.pair = pair
+        if langevin is not None:
+            self.lang = self.L.orc_fix_langevin_create(ntypes, langevin[0], langevin[1], langevin[2], int(langevin[3]), 0)
+        have_ucg, ld, mc, seed, rate = 0, 0, 0, 0, 0.01
+        if ucgstate is not None:
+            have_ucg = 1
+            if ucgstate == "ld":
+                ld = 1
+            elif ucgstate == "plain":
+                pass
+            else:
+                mc, seed, rate = 1, int(ucgstate[1]), float(ucgstate[2])
+        self.L.orc_sim_attach(self.h, pair.h, self.lang, 1 if nve else 0, have_ucg, ld, mc, seed, rate)
+
+    def setup(self, nsteps):
+        return self.L.orc_sim_setup(self.h, nsteps)
+
+    def run(self, nsteps, thermo_every=0):
+        return self.L.orc_sim_run(self.h, nsteps, thermo_every)
+
+    def rebuild(self):
+        self.L.orc_sim_rebuild(self.h)
+
+    def compute_forces(self, eflag=1, vflag=1):
+        return self.L.orc_sim_compute_forces(self.h, eflag, vflag)
+
+    def info(self):
+        out = np.zeros(16, dtype=np.int64)
+        self.L.orc_sim_get_info(self.h, out.ctypes.data_as(c_ll_p))
+        keys = ["nlocal", "nghost", "nrebuild", "pair_errors", "ntimestep", "nbx", "nby", "nbz",
+                "sx", "sy", "sz", "nfull", "nhalf"]
+        return dict(zip(keys, [int(v) for v in out[:13]]))
+
+    def ev(self):
+        out = np.zeros(8)
+        self.L.orc_sim_get_ev(self.h, _dp(out))
+        return dict(eng_vdwl=out[0], virial=out[1:7].copy(), lambda_temp=out[7])
+
+    def arrays(self, ghosts=False):
+        """copies of the per-atom arrays (owned, optionally + ghosts)"""
+        a = self.L.orc_sim_atoms(self.h).contents
+        n = a.nlocal + (a.nghost if ghosts else 0)
+        out = {}
+        for name, w in (("x", 3), ("f", 3), ("scores", 2)):
+            out[name] = np.ctypeslib.as_array(getattr(a, name), shape=(n, w)).copy()
+        out["v"] = np.ctypeslib.as_array(a.v, shape=(a.nlocal, 3)).copy()
+        for name in ("type", "tag", "mask", "ucgstate", "num_ucgstates", "ucgl", "ucgp", "ucgforce"):
+            out[name] = np.ctypeslib.as_array(getattr(a, name), shape=(n,)).copy()
+        for name in ("ucgvl", "ucgml"):
+            out[name] = np.ctypeslib.as_array(getattr(a, name), shape=(a.nlocal,)).copy()
+        out["nlocal"], out["nghost"] = a.nlocal, a.nghost
+        return out
+
+    def ghost_map(self):
+        i = self.info()
+        ng = i["nghost"]
+        src = np.ctypeslib.as_array(self.L.orc_sim_ghost_src(self.h), shape=(max(ng, 1),)).copy()[:ng]
+        sh = np.ctypeslib.as_array(self.L.orc_sim_ghost_shift(self.h), shape=(max(ng, 1), 3)).copy()[:ng]
+        return src, sh
+
+    def full_list(self):
+        return list_to_csr(self.L.orc_sim_full_list(self.h))
+
+    def half_list(self):
+        return list_to_csr(self.L.orc_sim_half_list(self.h))

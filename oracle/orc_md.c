@@ -1,0 +1,560 @@
+/* orc_md.c -- oracle MD driver: periodic box, ghosts, bins, neighbour lists and
+ * the Verlet step order.  TEST INFRASTRUCTURE (see orc.h).
+ *
+ * None of this is in /root/reference: ghosts, binning, neighbour lists, atom
+ * sorting and the integrator loop are upstream LAMMPS (Comm, Neighbor, AtomSort,
+ * Verlet), absent here.  The STEP ORDER restates upstream Verlet::setup()/run()
+ * as summarised in SURVEY.md section 3.1; the data-management steps follow the
+ * "ucg-rebuild-v1" specification in DESIGN.md, which the HIP path implements
+ * with the same IEEE operations so that whole trajectories can be compared bit
+ * for bit:
+ *
+ *   rebuild: (1) wrap owned atoms into the box (Domain::pbc form);
+ *            (2) bins of ~cutneigh/2 over the box extended by cutneigh;
+ *            (3) sort owned atoms by (bin, tag);
+ *            (4) ghosts = every periodic image x + s*prd (s in {-1,0,1}^3 \ 0) that
+ *                falls in the extended box, sorted by (bin, tag, shift code);
+ *            (5) full list rows: stencil bins in (dz,dy,dx) ascending order, owned
+ *                atoms of the bin then ghost atoms of the bin, entry kept when
+ *                rsq < cutneigh^2; bit 29 = (tag_k < tag_m) or equal tags.
+ *   decide : every `every` steps, rebuild when any owned atom moved more than
+ *            skin/2 since the last build (Neighbor::check_distance form).
+ */
+#include "orc_md.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+static void *xrealloc(void *p, size_t n)
+{
+  void *q = realloc(p, n ? n : 1);
+  if (!q) { fprintf(stderr, "orc_md: out of memory\n"); abort(); }
+  return q;
+}
+
+orc_sim *orc_sim_create(int natoms, const double *boxlo, const double *boxhi, double cutforce,
+                        double skin, int ntypes)
+{
+  orc_sim *s = (orc_sim *) calloc(1, sizeof(orc_sim));
+  for (int d = 0; d < 3; d++) {
+    s->boxlo[d] = boxlo[d];
+    s->boxhi[d] = boxhi[d];
+    s->prd[d] = boxhi[d] - boxlo[d];
+  }
+  s->cutforce = cutforce;
+  s->skin = skin;
+  s->cutneigh = cutforce + skin;
+  s->every = 1;
+  s->delay = 0;
+  s->check = 1;
+  s->ntypes = ntypes;
+  s->boltz = s->ftm2v = s->mvv2e = 1.0;
+  s->dt = 0.005;
+  s->groupbit = 1;
+  s->mode = 1;
+  s->a.nlocal = natoms;
+  s->a.nghost = 0;
+  s->a.mass = (double *) calloc((size_t) ntypes + 1, sizeof(double));
+  s->nmax = 0;
+  orc_sim_grow(s, natoms + natoms / 2 + 1024);
+  return s;
+}
+
+void orc_sim_grow(orc_sim *s, int nmax)
+{
+  if (nmax <= s->nmax) return;
+  orc_atoms *a = &s->a;
+  const size_t n = (size_t) nmax;
+  a->x = (double *) xrealloc(a->x, 3 * n * sizeof(double));
+  a->v = (double *) xrealloc(a->v, 3 * n * sizeof(double));
+  a->f = (double *) xrealloc(a->f, 3 * n * sizeof(double));
+  a->type = (int *) xrealloc(a->type, n * sizeof(int));
+  a->tag = (int *) xrealloc(a->tag, n * sizeof(int));
+  a->mask = (int *) xrealloc(a->mask, n * sizeof(int));
+  a->ucgstate = (int *) xrealloc(a->ucgstate, n * sizeof(int));
+  a->num_ucgstates = (int *) xrealloc(a->num_ucgstates, n * sizeof(int));
+  a->ucgl = (double *) xrealloc(a->ucgl, n * sizeof(double));
+  a->ucgvl = (double *) xrealloc(a->ucgvl, n * sizeof(double));
+  a->ucgml = (double *) xrealloc(a->ucgml, n * sizeof(double));
+  a->ucgp = (double *) xrealloc(a->ucgp, n * sizeof(double));
+  a->ucgforce = (double *) xrealloc(a->ucgforce, n * sizeof(double));
+  a->scores = (double *) xrealloc(a->scores, 2 * n * sizeof(double));
+  s->xhold = (double *) xrealloc(s->xhold, 3 * n * sizeof(double));
+  s->ghost_src = (int *) xrealloc(s->ghost_src, n * sizeof(int));
+  s->ghost_shift = (int *) xrealloc(s->ghost_shift, 3 * n * sizeof(int));
+  s->bin_of = (int *) xrealloc(s->bin_of, n * sizeof(int));
+  for (int i = s->nmax; i < nmax; i++) {
+    a->num_ucgstates[i] = 0;
+    a->ucgforce[i] = 0.0;
+    a->scores[2 * i] = a->scores[2 * i + 1] = 0.0;
+    a->f[3 * i] = a->f[3 * i + 1] = a->f[3 * i + 2] = 0.0;
+  }
+  s->nmax = nmax;
+}
+
+void orc_sim_destroy(orc_sim *s)
+{
+  if (!s) return;
+  orc_atoms *a = &s->a;
+  free(a->x); free(a->v); free(a->f); free(a->type); free(a->tag); free(a->mask);
+  free(a->ucgstate); free(a->num_ucgstates); free(a->ucgl); free(a->ucgvl); free(a->ucgml);
+  free(a->ucgp); free(a->ucgforce); free(a->scores); free(a->mass);
+  free(s->xhold); free(s->ghost_src); free(s->ghost_shift); free(s->bin_of);
+  free(s->binstart_owned); free(s->binstart_ghost);
+  free(s->full.ilist); free(s->full.numneigh); free(s->full.first); free(s->full.neigh);
+  free(s->half.ilist); free(s->half.numneigh); free(s->half.first); free(s->half.neigh);
+  free(s);
+}
+
+orc_atoms *orc_sim_atoms(orc_sim *s) { return &s->a; }
+orc_list *orc_sim_full_list(orc_sim *s) { return &s->full; }
+orc_list *orc_sim_half_list(orc_sim *s) { return &s->half; }
+
+/* ---------------------------------------------------------------- rebuild */
+
+static void pbc_wrap(orc_sim *s)
+{
+  /* upstream Domain::pbc(), orthogonal periodic box */
+  double *x = s->a.x;
+  for (int i = 0; i < s->a.nlocal; i++) {
+    for (int d = 0; d < 3; d++) {
+      if (x[3 * i + d] < s->boxlo[d]) x[3 * i + d] += s->prd[d];
+      if (x[3 * i + d] >= s->boxhi[d]) {
+        x[3 * i + d] -= s->prd[d];
+        x[3 * i + d] = (x[3 * i + d] > s->boxlo[d]) ? x[3 * i + d] : s->boxlo[d];
+      }
+    }
+  }
+}
+
+void orc_sim_setup_bins(orc_sim *s)
+{
+  const double target = 0.5 * s->cutneigh;
+  s->nbins = 1;
+  for (int d = 0; d < 3; d++) {
+    s->bboxlo[d] = s->boxlo[d] - s->cutneigh;
+    const double ext = (s->boxhi[d] + s->cutneigh) - s->bboxlo[d];
+    int nb = (int) (ext / target);
+    if (nb < 1) nb = 1;
+    s->nbin[d] = nb;
+    s->binsize[d] = ext / nb;
+    s->bininv[d] = 1.0 / s->binsize[d];
+    int sx = (int) (s->cutneigh * s->bininv[d]);
+    if (sx * s->binsize[d] < s->cutneigh) sx++;
+    s->sten[d] = sx;
+    s->nbins *= nb;
+  }
+}
+
+static int coord2bin(const orc_sim *s, const double *x)
+{
+  int ib[3];
+  for (int d = 0; d < 3; d++) {
+    int b = (int) ((x[d] - s->bboxlo[d]) * s->bininv[d]);
+    if (b < 0) b = 0;
+    if (b > s->nbin[d] - 1) b = s->nbin[d] - 1;
+    ib[d] = b;
+  }
+  return (ib[2] * s->nbin[1] + ib[1]) * s->nbin[0] + ib[0];
+}
+
+typedef struct { long long key; int idx; int code; } sortrec;
+
+static int cmp_sortrec(const void *pa, const void *pb)
+{
+  const sortrec *a = (const sortrec *) pa, *b = (const sortrec *) pb;
+  if (a->key != b->key) return a->key < b->key ? -1 : 1;
+  if (a->code != b->code) return a->code < b->code ? -1 : 1;
+  return 0;
+}
+
+static void permute_d(double *arr, const sortrec *r, int n, int w, double *tmp)
+{
+  for (int i = 0; i < n; i++)
+    for (int c = 0; c < w; c++) tmp[(size_t) w * i + c] = arr[(size_t) w * r[i].idx + c];
+  memcpy(arr, tmp, sizeof(double) * (size_t) w * n);
+}
+
+static void permute_i(int *arr, const sortrec *r, int n, int *tmp)
+{
+  for (int i = 0; i < n; i++) tmp[i] = arr[r[i].idx];
+  memcpy(arr, tmp, sizeof(int) * (size_t) n);
+}
+
+static void sort_owned(orc_sim *s)
+{
+  orc_atoms *a = &s->a;
+  const int n = a->nlocal;
+  sortrec *r = (sortrec *) malloc(sizeof(sortrec) * (size_t) n);
+  for (int i = 0; i < n; i++) {
+    r[i].key = ((long long) coord2bin(s, &a->x[3 * i]) << 32) | (unsigned int) a->tag[i];
+    r[i].idx = i;
+    r[i].code = 0;
+  }
+  qsort(r, (size_t) n, sizeof(sortrec), cmp_sortrec);
+  double *td = (double *) malloc(sizeof(double) * 3 * (size_t) n);
+  int *ti = (int *) malloc(sizeof(int) * (size_t) n);
+  permute_d(a->x, r, n, 3, td);
+  permute_d(a->v, r, n, 3, td);
+  permute_d(a->ucgl, r, n, 1, td);
+  permute_d(a->ucgvl, r, n, 1, td);
+  permute_d(a->ucgml, r, n, 1, td);
+  permute_d(a->ucgp, r, n, 1, td);
+  permute_i(a->type, r, n, ti);
+  permute_i(a->tag, r, n, ti);
+  permute_i(a->mask, r, n, ti);
+  permute_i(a->ucgstate, r, n, ti);
+  permute_i(a->num_ucgstates, r, n, ti);
+  for (int i = 0; i < n; i++) s->bin_of[i] = (int) (r[i].key >> 32);
+  free(td);
+  free(ti);
+  free(r);
+}
+
+static void build_ghosts(orc_sim *s)
+{
+  orc_atoms *a = &s->a;
+  const int n = a->nlocal;
+  double lo[3], hi[3];
+  for (int d = 0; d < 3; d++) {
+    lo[d] = s->boxlo[d] - s->cutneigh;
+    hi[d] = s->boxhi[d] + s->cutneigh;
+  }
+  int cap = 1024, ng = 0;
+  sortrec *r = (sortrec *) malloc(sizeof(sortrec) * (size_t) cap);
+  for (int sz = -1; sz <= 1; sz++)
+    for (int sy = -1; sy <= 1; sy++)
+      for (int sx = -1; sx <= 1; sx++) {
+        if (sx == 0 && sy == 0 && sz == 0) continue;
+        const int code = (sz + 1) * 9 + (sy + 1) * 3 + (sx + 1);
+        for (int i = 0; i < n; i++) {
+          double xs[3];
+          xs[0] = a->x[3 * i + 0] + sx * s->prd[0];
+          xs[1] = a->x[3 * i + 1] + sy * s->prd[1];
+          xs[2] = a->x[3 * i + 2] + sz * s->prd[2];
+          if (xs[0] < lo[0] || xs[0] >= hi[0] || xs[1] < lo[1] || xs[1] >= hi[1] ||
+              xs[2] < lo[2] || xs[2] >= hi[2])
+            continue;
+          if (ng == cap) {
+            cap *= 2;
+            r = (sortrec *) xrealloc(r, sizeof(sortrec) * (size_t) cap);
+          }
+          r[ng].key = ((long long) coord2bin(s, xs) << 32) | (unsigned int) a->tag[i];
+          r[ng].idx = i;
+          r[ng].code = code;
+          ng++;
+        }
+      }
+  qsort(r, (size_t) ng, sizeof(sortrec), cmp_sortrec);
+  orc_sim_grow(s, n + ng);
+  a = &s->a;
+  a->nghost = ng;
+  for (int g = 0; g < ng; g++) {
+    const int src = r[g].idx, code = r[g].code;
+    const int sx = code % 3 - 1, sy = (code / 3) % 3 - 1, sz = code / 9 - 1;
+    s->ghost_src[g] = src;
+    s->ghost_shift[3 * g + 0] = sx;
+    s->ghost_shift[3 * g + 1] = sy;
+    s->ghost_shift[3 * g + 2] = sz;
+    s->bin_of[n + g] = (int) (r[g].key >> 32);
+    a->tag[n + g] = a->tag[src];
+    a->type[n + g] = a->type[src];
+    a->mask[n + g] = a->mask[src];
+  }
+  free(r);
+  orc_sim_forward_comm(s);
+}
+
+/* forward communication: owner -> its periodic images (fields_comm of
+ * UCG/atom_vec_ucg.cpp:71: x + shift, ucgstate, ucgl, ucgp) */
+void orc_sim_forward_comm(orc_sim *s)
+{
+  orc_atoms *a = &s->a;
+  const int n = a->nlocal;
+  for (int g = 0; g < a->nghost; g++) {
+    const int src = s->ghost_src[g];
+    for (int d = 0; d < 3; d++)
+      a->x[3 * (n + g) + d] = a->x[3 * src + d] + s->ghost_shift[3 * g + d] * s->prd[d];
+    a->ucgstate[n + g] = a->ucgstate[src];
+    a->ucgl[n + g] = a->ucgl[src];
+    a->ucgp[n + g] = a->ucgp[src];
+  }
+}
+
+/* reverse communication (reference-order mode only): ghost sums -> owners
+ * (fields_reverse of UCG/atom_vec_ucg.cpp:73: f, ucgforce, ucgsoftmaxscores) */
+void orc_sim_reverse_comm(orc_sim *s)
+{
+  orc_atoms *a = &s->a;
+  const int n = a->nlocal;
+  for (int g = 0; g < a->nghost; g++) {
+    const int src = s->ghost_src[g];
+    for (int d = 0; d < 3; d++) a->f[3 * src + d] += a->f[3 * (n + g) + d];
+    a->ucgforce[src] += a->ucgforce[n + g];
+    a->scores[2 * src + 0] += a->scores[2 * (n + g) + 0];
+    a->scores[2 * src + 1] += a->scores[2 * (n + g) + 1];
+  }
+}
+
+static void build_bins(orc_sim *s)
+{
+  const orc_atoms *a = &s->a;
+  const int n = a->nlocal, ng = a->nghost;
+  s->binstart_owned = (int *) xrealloc(s->binstart_owned, sizeof(int) * ((size_t) s->nbins + 1));
+  s->binstart_ghost = (int *) xrealloc(s->binstart_ghost, sizeof(int) * ((size_t) s->nbins + 1));
+  /* both classes are already sorted by bin */
+  int p = 0;
+  for (int b = 0; b <= s->nbins; b++) {
+    while (p < n && s->bin_of[p] < b) p++;
+    s->binstart_owned[b] = p;
+  }
+  p = 0;
+  for (int b = 0; b <= s->nbins; b++) {
+    while (p < ng && s->bin_of[n + p] < b) p++;
+    s->binstart_ghost[b] = n + p;
+  }
+}
+
+static void list_reserve(orc_list *l, int inum, long long nent)
+{
+  l->ilist = (int *) xrealloc(l->ilist, sizeof(int) * (size_t) (inum + 1));
+  l->numneigh = (int *) xrealloc(l->numneigh, sizeof(int) * (size_t) (inum + 1));
+  l->first = (long long *) xrealloc(l->first, sizeof(long long) * (size_t) (inum + 1));
+  l->neigh = (int *) xrealloc(l->neigh, sizeof(int) * (size_t) (nent + 1));
+}
+
+static void build_lists(orc_sim *s)
+{
+  const orc_atoms *a = &s->a;
+  const int n = a->nlocal;
+  const double cutsq = s->cutneigh * s->cutneigh;
+  const double *x = a->x;
+  /* pass 0 counts, pass 1 fills */
+  long long total = 0;
+  for (int pass = 0; pass < 2; pass++) {
+    if (pass == 1) list_reserve(&s->full, n, total);
+    long long pos = 0;
+    for (int k = 0; k < n; k++) {
+      const int b = s->bin_of[k];
+      const int bx = b % s->nbin[0], by = (b / s->nbin[0]) % s->nbin[1], bz = b / (s->nbin[0] * s->nbin[1]);
+      const long long start = pos;
+      for (int dz = -s->sten[2]; dz <= s->sten[2]; dz++) {
+        const int cz = bz + dz;
+        if (cz < 0 || cz >= s->nbin[2]) continue;
+        for (int dy = -s->sten[1]; dy <= s->sten[1]; dy++) {
+          const int cy = by + dy;
+          if (cy < 0 || cy >= s->nbin[1]) continue;
+          for (int dx = -s->sten[0]; dx <= s->sten[0]; dx++) {
+            const int cx = bx + dx;
+            if (cx < 0 || cx >= s->nbin[0]) continue;
+            const int c = (cz * s->nbin[1] + cy) * s->nbin[0] + cx;
+            for (int cls = 0; cls < 2; cls++) {
+              const int *bs = cls ? s->binstart_ghost : s->binstart_owned;
+              for (int m = bs[c]; m < bs[c + 1]; m++) {
+                if (m == k) continue;
+                const double delx = x[3 * k + 0] - x[3 * m + 0];
+                const double dely = x[3 * k + 1] - x[3 * m + 1];
+                const double delz = x[3 * k + 2] - x[3 * m + 2];
+                const double rsq = delx * delx + dely * dely + delz * delz;
+                if (rsq < cutsq) {
+                  if (pass == 1) {
+                    const int orient = (a->tag[k] <= a->tag[m]) ? 1 : 0;
+                    s->full.neigh[pos] = m | (orient << ORC_ORIENT_BIT);
+                  }
+                  pos++;
+                }
+              }
+            }
+          }
+        }
+      }
+      if (pass == 1) {
+        s->full.ilist[k] = k;
+        s->full.first[k] = start;
+        s->full.numneigh[k] = (int) (pos - start);
+      }
+    }
+    total = pos;
+  }
+  s->full.inum = n;
+
+  /* half list for the reference-order mode: each pair once.  owned-owned: the
+     lower tag is "i".  owned-ghost: lower tag owns the pair; equal tags (self
+     image) by the z/y/x coordinate rule of LAMMPS' newton half lists. */
+  list_reserve(&s->half, n, total);
+  long long pos = 0;
+  for (int k = 0; k < n; k++) {
+    const long long start = pos;
+    const int *row = s->full.neigh + s->full.first[k];
+    for (int e = 0; e < s->full.numneigh[k]; e++) {
+      const int m = row[e] & ORC_NEIGHMASK;
+      int keep;
+      if (a->tag[k] != a->tag[m]) keep = a->tag[k] < a->tag[m];
+      else {
+        if (x[3 * m + 2] != x[3 * k + 2]) keep = x[3 * m + 2] > x[3 * k + 2];
+        else if (x[3 * m + 1] != x[3 * k + 1]) keep = x[3 * m + 1] > x[3 * k + 1];
+        else keep = x[3 * m + 0] > x[3 * k + 0];
+      }
+      if (keep) s->half.neigh[pos++] = m;
+    }
+    s->half.ilist[k] = k;
+    s->half.first[k] = start;
+    s->half.numneigh[k] = (int) (pos - start);
+  }
+  s->half.inum = n;
+}
+
+void orc_sim_rebuild(orc_sim *s)
+{
+  pbc_wrap(s);
+  orc_sim_setup_bins(s);
+  sort_owned(s);
+  build_ghosts(s);
+  build_bins(s);
+  build_lists(s);
+  memcpy(s->xhold, s->a.x, sizeof(double) * 3 * (size_t) s->a.nlocal);
+  s->ago = 0;
+  s->nrebuild++;
+}
+
+static int check_distance(const orc_sim *s)
+{
+  const double deltasq = 0.25 * s->skin * s->skin;
+  const double *x = s->a.x, *xh = s->xhold;
+  for (int i = 0; i < s->a.nlocal; i++) {
+    const double delx = x[3 * i + 0] - xh[3 * i + 0];
+    const double dely = x[3 * i + 1] - xh[3 * i + 1];
+    const double delz = x[3 * i + 2] - xh[3 * i + 2];
+    const double rsq = delx * delx + dely * dely + delz * delz;
+    if (rsq > deltasq) return 1;
+  }
+  return 0;
+}
+
+static int decide(orc_sim *s)
+{
+  /* upstream Neighbor::decide() */
+  s->ago++;
+  if (s->ago >= s->delay && s->ago % s->every == 0) {
+    if (s->check == 0) return 1;
+    return check_distance(s);
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------ force + fixes */
+
+static int compute_forces(orc_sim *s, int eflag, int vflag)
+{
+  int rc;
+  if (s->mode == 0) {
+    orc_force_clear(&s->a, 1);
+    rc = orc_pair_compute_half(s->pair, &s->a, &s->half, 1, eflag, vflag, &s->ev);
+    orc_sim_reverse_comm(s);
+  } else {
+    orc_force_clear(&s->a, 0);
+    rc = orc_pair_compute_gather(s->pair, &s->a, &s->full, eflag, vflag, &s->ev);
+  }
+  if (rc) s->pair_errors++;
+  return rc;
+}
+
+static void post_force(orc_sim *s)
+{
+  /* fix order = definition order: thermostat first, then fix ucgstate
+     (UCG/fix_ucgstate.cpp:143-154 requires that order) */
+  if (s->lang) orc_fix_langevin_post_force(s->lang, &s->a, s->groupbit, s->ntimestep, s->beginstep, s->endstep);
+  if (s->have_ucgstate) orc_fix_ucgstate_post_force(&s->ucgst, &s->a);
+}
+
+int orc_sim_setup(orc_sim *s, long long nsteps_planned)
+{
+  /* upstream Verlet::setup(): build lists, compute forces, then Modify::setup ->
+     each fix's setup(); Fix_UCGLD_Langevin::setup and FixUCGState::setup both call
+     post_force (UCG/fix_ucgld_langevin.cpp:187-197, UCG/fix_ucgstate.cpp:142-171) */
+  s->beginstep = s->ntimestep;
+  s->endstep = s->ntimestep + nsteps_planned;
+  if (s->lang) orc_fix_langevin_init(s->lang, &s->a, s->dt, s->boltz, s->ftm2v, s->mvv2e);
+  orc_sim_rebuild(s);
+  int rc = compute_forces(s, 1, 1);
+  post_force(s);
+  return rc;
+}
+
+int orc_sim_run(orc_sim *s, long long nsteps, int thermo_every)
+{
+  int rc_any = 0;
+  for (long long n = 0; n < nsteps; n++) {
+    s->ntimestep++;
+    const int ev = (thermo_every > 0 && (s->ntimestep % thermo_every == 0)) ? 1 : 0;
+    if (s->have_nve) orc_fix_nve_initial(&s->a, s->dt, s->ftm2v, s->groupbit);
+    if (decide(s)) orc_sim_rebuild(s);
+    else orc_sim_forward_comm(s);
+    int rc = compute_forces(s, ev, ev);
+    if (rc) rc_any = rc;
+    post_force(s);
+    if (s->have_nve) orc_fix_nve_final(&s->a, s->dt, s->ftm2v, s->groupbit);
+    if (s->lang) orc_fix_langevin_end_of_step(s->lang, &s->a, s->groupbit, s->boltz, s->mvv2e);
+  }
+  return rc_any;
+}
+
+/* ------------------------------------------------- accessors for the tests */
+
+void orc_sim_set_run_params(orc_sim *s, double dt, int every, int delay, int check, int mode)
+{
+  s->dt = dt;
+  s->every = every;
+  s->delay = delay;
+  s->check = check;
+  s->mode = mode;
+}
+
+void orc_sim_set_units(orc_sim *s, double boltz, double ftm2v, double mvv2e)
+{
+  s->boltz = boltz;
+  s->ftm2v = ftm2v;
+  s->mvv2e = mvv2e;
+}
+
+void orc_sim_attach(orc_sim *s, orc_pair *pair, orc_fix_langevin *lang, int have_nve,
+                    int have_ucgstate, int ld_flag, int mc_flag, int mc_seed, double mc_rate)
+{
+  s->pair = pair;
+  s->lang = lang;
+  s->have_nve = have_nve;
+  s->have_ucgstate = have_ucgstate;
+  if (have_ucgstate) orc_fix_ucgstate_init(&s->ucgst, ld_flag, mc_flag, mc_seed, mc_rate, 0);
+}
+
+void orc_sim_get_info(const orc_sim *s, long long *out)
+{
+  out[0] = s->a.nlocal;
+  out[1] = s->a.nghost;
+  out[2] = s->nrebuild;
+  out[3] = s->pair_errors;
+  out[4] = s->ntimestep;
+  out[5] = s->nbin[0];
+  out[6] = s->nbin[1];
+  out[7] = s->nbin[2];
+  out[8] = s->sten[0];
+  out[9] = s->sten[1];
+  out[10] = s->sten[2];
+  out[11] = s->full.inum ? (s->full.first[s->full.inum - 1] + s->full.numneigh[s->full.inum - 1]) : 0;
+  out[12] = s->half.inum ? (s->half.first[s->half.inum - 1] + s->half.numneigh[s->half.inum - 1]) : 0;
+}
+
+void orc_sim_get_ev(const orc_sim *s, double *out)
+{
+  out[0] = s->ev.eng_vdwl;
+  for (int c = 0; c < 6; c++) out[1 + c] = s->ev.virial[c];
+  out[7] = s->lang ? s->lang->lambda_temp : 0.0;
+}
+
+const int *orc_sim_ghost_src(const orc_sim *s) { return s->ghost_src; }
+const int *orc_sim_ghost_shift(const orc_sim *s) { return s->ghost_shift; }
+const int *orc_sim_bin_of(const orc_sim *s) { return s->bin_of; }
+double *orc_sim_mass(orc_sim *s) { return s->a.mass; }
+int orc_sim_compute_forces(orc_sim *s, int eflag, int vflag) { return compute_forces(s, eflag, vflag); }

@@ -1,0 +1,71 @@
+/* orc_md.h -- oracle MD driver state.  TEST INFRASTRUCTURE (see orc.h). */
+#ifndef ORC_MD_H
+#define ORC_MD_H
+
+#include "orc.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+  double boxlo[3], boxhi[3], prd[3];
+  double cutforce, skin, cutneigh;
+  int every, delay, check; /* neigh_modify */
+  int ntypes;
+  double dt, boltz, ftm2v, mvv2e;
+  int groupbit;
+  int mode; /* 0 = reference order (half list + reverse sum), 1 = canonical gather */
+
+  orc_atoms a;
+  int nmax;
+  double *xhold;
+  int *ghost_src;   /* [nghost] owned index this ghost is an image of */
+  int *ghost_shift; /* [nghost*3] periodic shift in box lengths       */
+  int *bin_of;      /* [nall] bin id at the last rebuild               */
+
+  int nbin[3], sten[3], nbins;
+  double bboxlo[3], binsize[3], bininv[3];
+  int *binstart_owned, *binstart_ghost; /* [nbins+1] */
+
+  orc_list full, half;
+
+  orc_pair *pair;              /* borrowed */
+  orc_fix_langevin *lang;      /* borrowed, may be NULL */
+  orc_fix_ucgstate ucgst;
+  int have_ucgstate, have_nve;
+
+  long long ntimestep, beginstep, endstep;
+  int ago, nrebuild, pair_errors;
+  orc_ev ev;
+} orc_sim;
+
+orc_sim *orc_sim_create(int natoms, const double *boxlo, const double *boxhi, double cutforce,
+                        double skin, int ntypes);
+void orc_sim_destroy(orc_sim *s);
+void orc_sim_grow(orc_sim *s, int nmax);
+orc_atoms *orc_sim_atoms(orc_sim *s);
+orc_list *orc_sim_full_list(orc_sim *s);
+orc_list *orc_sim_half_list(orc_sim *s);
+void orc_sim_setup_bins(orc_sim *s);
+void orc_sim_rebuild(orc_sim *s);
+void orc_sim_forward_comm(orc_sim *s);
+void orc_sim_reverse_comm(orc_sim *s);
+int orc_sim_setup(orc_sim *s, long long nsteps_planned);
+int orc_sim_run(orc_sim *s, long long nsteps, int thermo_every);
+void orc_sim_set_run_params(orc_sim *s, double dt, int every, int delay, int check, int mode);
+void orc_sim_set_units(orc_sim *s, double boltz, double ftm2v, double mvv2e);
+void orc_sim_attach(orc_sim *s, orc_pair *pair, orc_fix_langevin *lang, int have_nve,
+                    int have_ucgstate, int ld_flag, int mc_flag, int mc_seed, double mc_rate);
+void orc_sim_get_info(const orc_sim *s, long long *out);
+void orc_sim_get_ev(const orc_sim *s, double *out);
+const int *orc_sim_ghost_src(const orc_sim *s);
+const int *orc_sim_ghost_shift(const orc_sim *s);
+const int *orc_sim_bin_of(const orc_sim *s);
+double *orc_sim_mass(orc_sim *s);
+int orc_sim_compute_forces(orc_sim *s, int eflag, int vflag);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
