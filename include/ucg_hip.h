@@ -1,0 +1,207 @@
+/* ucg_hip.h -- C ABI of libucg_hip.so, the MI355X (gfx950) implementation of the
+ * UCG hot path of LAMMPS-UCG (KJAdams2000/LAMMPS-UCG-dev).
+ *
+ * Plain C, plain pointers and sizes; no C++ types, no exceptions, no torch.
+ * Every entry point returns 0 on success and a nonzero UCG_ERR_* code on
+ * failure; ucg_last_error() then gives the message the LAMMPS glue hands to
+ * error->one()/error->all().  One context per rank/GPU, called from one host
+ * thread (the reference is single-threaded per rank).
+ *
+ * Each group below names the reference interface it replaces (paths relative
+ * to the reference root).  INTEGRATION.md shows the LAMMPS-side classes that
+ * bind these calls under the reference's style names.
+ *
+ * Host arrays use the layouts LAMMPS hands to a pair style / fix:
+ *   x, v, f            double[n][3]  (AoS)
+ *   ucgsoftmaxscores   double[n][2]
+ *   type, tag, mask, ucgstate, num_ucgstates   int[n]
+ *   ucgl, ucgvl, ucgml, ucgp, ucgforce         double[n]
+ * with n = nlocal (+ nghost where stated); ghosts follow owned atoms.
+ */
+#ifndef UCG_HIP_H
+#define UCG_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UCG_ABI_VERSION 1
+
+enum {
+  UCG_OK = 0,
+  UCG_ERR_INVALID = 1,      /* bad argument / call order                         */
+  UCG_ERR_INPUT = 2,        /* input-deck error (the reference's error->all)      */
+  UCG_ERR_HIP = 3,          /* HIP runtime failure                                */
+  UCG_ERR_TABLE_INNER = 4,  /* "Pair distance < table inner cutoff"  (ucgld.cpp:437-439) */
+  UCG_ERR_TABLE_OUTER = 5,  /* "Pair distance > table outer cutoff"  (ucgld.cpp:442-444) */
+  UCG_ERR_UNSUPPORTED = 6,  /* feature the GPU path does not cover (e.g. BITMAP)  */
+  UCG_ERR_NEIGH_OVERFLOW = 7
+};
+
+enum { UCG_STYLE_UCGLD = 0, UCG_STYLE_BETHE = 1, UCG_STYLE_BETHE_DENSITY = 2 };
+enum { UCG_LOOKUP = 0, UCG_LINEAR = 1, UCG_SPLINE = 2, UCG_BITMAP = 3 };
+
+/* neighbour-entry bits (device lists and ucg_neigh_upload_full): [28:0] index,
+ * [29] orientation (1: the row owner is the reference's "i" of the pair, i.e.
+ * tag_row <= tag_neighbour), [31:30] LAMMPS special-bond code (sbmask). */
+#define UCG_NEIGHMASK 0x1FFFFFFF
+#define UCG_ORIENT_BIT 29
+#define UCG_SBBITS 30
+
+typedef struct ucg_ctx ucg_ctx;
+typedef struct ucg_pair ucg_pair;
+
+/* ------------------------------------------------------------------ context */
+
+int ucg_abi_version(void);
+/* device < 0: use the current HIP device */
+int ucg_ctx_create(int device, ucg_ctx **out);
+void ucg_ctx_destroy(ucg_ctx *ctx);
+const char *ucg_last_error(const ucg_ctx *ctx);
+/* run on a caller-owned hipStream_t (passed as void*); NULL = the context's own stream */
+int ucg_ctx_set_stream(ucg_ctx *ctx, void *hip_stream);
+int ucg_ctx_synchronize(ucg_ctx *ctx);
+/* force->boltz, force->ftm2v, force->mvv2e, update->dt, force->special_lj[0..3] */
+int ucg_ctx_set_units(ucg_ctx *ctx, double boltz, double ftm2v, double mvv2e, double dt,
+                      const double *special_lj);
+
+/* --------------------------------------------------------------- pair styles
+ * replaces PairTable_UCGLD / PairTable_UCG_Bethe / PairTable_UCG_Bethe_Density
+ *   settings()   UCG/pair_table_ucgld.cpp:654-716, UCG/pair_table_ucg_bethe.cpp:746-886,
+ *                UCG/pair_table_ucg_bethe_density.cpp:896-958  (+ read_state_settings)
+ *   coeff()      UCG/pair_table_ucgld.cpp:719-865 (read_table/spline_table/compute_table)
+ *   init_style() + init_one()  UCG/pair_table_ucgld.cpp:867-895
+ *   compute()    UCG/pair_table_ucgld.cpp:111-541, UCG/pair_table_ucg_bethe.cpp:88-630,
+ *                UCG/pair_table_ucg_bethe_density.cpp:133-758
+ * argv arrays are the words after the style name, exactly as LAMMPS passes them. */
+
+int ucg_pair_create(ucg_ctx *ctx, int style, ucg_pair **out);
+/* host-only pair: the setup half of the style (settings, coeff, init, single, table
+ * inspection) without a device; compute() is refused.  This is input parsing and
+ * table construction, which the reference also does on the host -- not a fallback. */
+int ucg_pair_create_host(int style, double boltz, ucg_pair **out);
+const char *ucg_pair_last_error(const ucg_pair *p);
+void ucg_pair_destroy(ucg_pair *p);
+int ucg_pair_settings(ucg_pair *p, int narg, const char *const *arg);
+int ucg_pair_coeff(ucg_pair *p, int ntypes, int narg, const char *const *arg);
+/* Pair::init(): T = thermostat t_target found through Fix::extract("t_target")
+ * (UCG/pair_table_ucgld.cpp:873-881; must be given);
+ * uploads the packed tables and type maps to the device */
+int ucg_pair_init(ucg_pair *p, int ntypes, double T);
+/* what init_one(i,j) returns for formal types (i,j): the table cutoff */
+double ucg_pair_cut(const ucg_pair *p, int i, int j);
+/* largest table cutoff (Pair::cutforce) */
+double ucg_pair_cutforce(const ucg_pair *p);
+/* Pair::single(): UCG/pair_table_ucgld.cpp:1474-1520, evaluated on the host */
+int ucg_pair_single(const ucg_pair *p, int itype, int jtype, double rsq, double factor_lj,
+                    double *fforce, double *energy);
+/* host copies of the built tables, for inspection: which in
+ * {"rsq","e","f","de","df","e2","f2"}; returns the length or <0 */
+int ucg_pair_table_count(const ucg_pair *p);
+int ucg_pair_table_params(const ucg_pair *p, int m, double *out5 /* innersq,delta,invdelta,deltasq6,cut */);
+int ucg_pair_table_array(const ucg_pair *p, int m, const char *which, double *out, int cap);
+/* tabindex[(n_formal+1)^2] after init */
+int ucg_pair_tabindex(const ucg_pair *p, int *out, int cap);
+
+/* One force evaluation on the atoms/list resident in the context.  Writes
+ * f, ucgforce, ucgsoftmaxscores, num_ucgstates (and ucgp for the density
+ * style) of the owned atoms.  eng_vdwl / virial[6] (xx,yy,zz,xy,xz,yz) may be
+ * NULL when eflag / vflag are 0. */
+int ucg_pair_compute(ucg_pair *p, int eflag, int vflag, double *eng_vdwl, double *virial);
+/* device-side table-range violations of the last compute (0 = none); the glue
+ * turns a nonzero return into error->one() like UCG/pair_table_ucgld.cpp:437-444 */
+int ucg_pair_check_errors(ucg_pair *p);
+
+/* ------------------------------------------------------------- atoms (AtomVecUCG)
+ * replaces the per-atom fields of atom style "ucg": UCG/atom_vec_ucg.cpp:48-90,
+ * atom.h:180-192.  Device mirrors only; LAMMPS keeps ownership of host arrays. */
+
+int ucg_atoms_upload(ucg_ctx *ctx, int nlocal, int nghost, int ntypes, const double *x,
+                     const double *v, const int *type, const int *tag, const int *mask,
+                     const int *ucgstate, const double *ucgl, const double *ucgvl,
+                     const double *ucgml, const double *ucgp, const double *mass);
+/* fields_comm of UCG/atom_vec_ucg.cpp:71: refresh x, ucgstate, ucgl, ucgp of all nall atoms */
+int ucg_atoms_upload_comm(ucg_ctx *ctx, const double *x, const int *ucgstate, const double *ucgl,
+                          const double *ucgp);
+/* any pointer may be NULL; arrays are nlocal long (x: nlocal+nghost if with_ghosts) */
+int ucg_atoms_download(ucg_ctx *ctx, int with_ghosts, double *x, double *v, double *f, int *type,
+                       int *tag, int *ucgstate, int *num_ucgstates, double *ucgl, double *ucgvl,
+                       double *ucgml, double *ucgp, double *ucgforce, double *ucgsoftmaxscores);
+int ucg_atoms_counts(const ucg_ctx *ctx, int *nlocal, int *nghost);
+/* AtomVecUCG::force_clear (UCG/atom_vec_ucg.cpp:131-135) + Verlet::force_clear */
+int ucg_force_clear(ucg_ctx *ctx);
+
+/* ------------------------------------------------------------ neighbour lists
+ * (upstream Neighbor; the styles only request lists: ucgld.cpp:868, density.cpp:1135) */
+
+/* host-built FULL list over owned rows; entries as described above */
+int ucg_neigh_upload_full(ucg_ctx *ctx, int inum, const int *numneigh, const long long *first,
+                          const int *neigh);
+/* periodic orthogonal box + neighbour settings for the device builder */
+int ucg_domain_set(ucg_ctx *ctx, const double *boxlo, const double *boxhi, double cutforce,
+                   double skin, int every, int delay, int check);
+/* wrap, sort by (bin, tag), rebuild periodic-image ghosts, bin, build the full list */
+int ucg_neigh_rebuild(ucg_ctx *ctx);
+/* owner -> periodic images (fields_comm) on the device */
+int ucg_halo_forward(ucg_ctx *ctx);
+/* device list back to the host (CSR); call with neigh==NULL to get the sizes */
+int ucg_neigh_download(ucg_ctx *ctx, int *inum, int *numneigh, long long *first, int *neigh,
+                       long long cap, long long *total);
+/* ghost map of the device builder: source owned index + periodic shift of each ghost */
+int ucg_ghosts_download(ucg_ctx *ctx, int *src, int *shift3, int cap);
+
+/* ---------------------------------------------------------------- fix nve/ucgld
+ * replaces FixNVE_UCGLD::initial_integrate / final_integrate
+ * (UCG/fix_nve_ucgld.cpp:44-101, 104-153), per-type mass branch */
+int ucg_fix_nve_initial(ucg_ctx *ctx, int groupbit);
+int ucg_fix_nve_final(ucg_ctx *ctx, int groupbit);
+
+/* ----------------------------------------------------------- fix ucgld/langevin
+ * replaces Fix_UCGLD_Langevin (UCG/fix_ucgld_langevin.cpp): constructor :54-119,
+ * init :149-183, post_force_templated<0> :226-297, end_of_step :303-312,
+ * compute_scalar :403-406, extract("t_target") :412-417 */
+int ucg_fix_langevin_create(ucg_ctx *ctx, double t_start, double t_stop, double t_period, int seed,
+                            int me);
+/* per-type prefactors computed by the glue exactly as init() does (it reads
+ * atom->ucgml[type index]); arrays are ntypes+1 long */
+int ucg_fix_langevin_init(ucg_ctx *ctx, int ntypes, const double *gfactor1, const double *gfactor2);
+/* convenience: the reference's init() arithmetic from mλ values indexed by type */
+int ucg_fix_langevin_init_from_ucgml(ucg_ctx *ctx, int ntypes, const double *ucgml_by_type_index);
+int ucg_fix_langevin_post_force(ucg_ctx *ctx, int groupbit, long long ntimestep,
+                                long long beginstep, long long endstep);
+int ucg_fix_langevin_end_of_step(ucg_ctx *ctx, int groupbit, double *lambda_temp);
+double ucg_fix_langevin_t_target(const ucg_ctx *ctx);
+
+/* ---------------------------------------------------------------- fix ucgstate
+ * replaces FixUCGState::post_force (UCG/fix_ucgstate.cpp:88-132);
+ * mode: ld_flag / mc_flag / seed / rate as parsed at :37-67 */
+int ucg_fix_ucgstate_create(ucg_ctx *ctx, int ld_flag, int mc_flag, int mc_seed, double mc_rate,
+                            int me);
+int ucg_fix_ucgstate_post_force(ucg_ctx *ctx);
+
+/* ------------------------------------------------------- RanMars on the device
+ * the upstream generator behind both fixes, exposed for known-answer tests:
+ * n draws of RanMars(seed).uniform() (after its constructor warm-up draw) */
+int ucg_ranmars_fill(ucg_ctx *ctx, int seed, long long skip, int n, double *out);
+
+/* ------------------------------------------------------ resident Verlet driver
+ * step order of upstream Verlet::setup()/run() with the
+ * whole state resident in HBM; used by bench.py and the trajectory-parity tests */
+int ucg_md_attach(ucg_ctx *ctx, ucg_pair *pair, int use_nve, int use_langevin, int use_ucgstate);
+int ucg_md_setup(ucg_ctx *ctx, long long nsteps_planned);
+int ucg_md_run(ucg_ctx *ctx, long long nsteps, int thermo_every);
+/* out[0..15]: ntimestep, nrebuild, nlocal, nghost, list entries, pair errors, ... */
+int ucg_md_info(ucg_ctx *ctx, long long *out16);
+/* last thermo: eng_vdwl, virial[6], lambda_temp, state-1 population */
+int ucg_md_thermo(ucg_ctx *ctx, double *out9);
+
+/* --------------------------------------------------------------- measurement
+ * HIP-event timing of the pair kernel on the stream it runs on: enable, run,
+ * then read launches and summed milliseconds since the last reset */
+int ucg_profile_enable(ucg_ctx *ctx, int on);
+int ucg_profile_read(ucg_ctx *ctx, long long *pair_launches, double *pair_ms, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UCG_HIP_H */

@@ -5,3 +5,4 @@ tests/conftest.py, bench.py and __graft_entry__.py) under the module name
 ``lammps_ucg_dev_amd``.
 """
 from . import synth  # noqa: F401
+from . import capi  # noqa: F401

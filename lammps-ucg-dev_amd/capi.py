@@ -1,0 +1,434 @@
+"""ctypes binding of libucg_hip.so (the C ABI in include/ucg_hip.h).
+
+This is plumbing for tests, bench.py and smoke(): it adds nothing to the path.  There is
+no CPU fallback -- if the HIP library is missing or no GPU is visible, calls fail loudly.
+The classes mirror the reference's plugin interface for this path (same style names,
+same command arguments, same hooks):
+
+    Pair("table_ucgld" | "table_ucg_bethe" | "table_ucg_bethe_density")
+        .settings(args) .coeff(args) .init(T) .compute(eflag, vflag)      -- LAMMPS Pair
+    Context.fix_nve_ucgld_* / fix_ucgld_langevin_* / fix_ucgstate_*      -- LAMMPS Fix hooks
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libucg_hip.so")
+_LIB = None
+
+c_double_p = C.POINTER(C.c_double)
+c_int_p = C.POINTER(C.c_int)
+c_ll_p = C.POINTER(C.c_longlong)
+
+STYLE_IDS = {"table_ucgld": 0, "table_ucg_bethe": 1, "table_ucg_bethe_density": 2}
+ORIENT_BIT = 29
+NEIGHMASK = 0x1FFFFFFF
+
+# every symbol include/ucg_hip.h declares (checked by the CPU test-suite against the .so)
+SYMBOLS = [
+    "ucg_abi_version", "ucg_ctx_create", "ucg_ctx_destroy", "ucg_last_error", "ucg_ctx_set_stream",
+    "ucg_ctx_synchronize", "ucg_ctx_set_units",
+    "ucg_pair_create", "ucg_pair_create_host", "ucg_pair_last_error", "ucg_pair_destroy", "ucg_pair_settings", "ucg_pair_coeff", "ucg_pair_init",
+    "ucg_pair_cut", "ucg_pair_cutforce", "ucg_pair_single", "ucg_pair_table_count",
+    "ucg_pair_table_params", "ucg_pair_table_array", "ucg_pair_tabindex", "ucg_pair_compute",
+    "ucg_pair_check_errors",
+    "ucg_atoms_upload", "ucg_atoms_upload_comm", "ucg_atoms_download", "ucg_atoms_counts", "ucg_force_clear",
+    "ucg_neigh_upload_full", "ucg_domain_set", "ucg_neigh_rebuild", "ucg_halo_forward", "ucg_neigh_download",
+    "ucg_ghosts_download",
+    "ucg_fix_nve_initial", "ucg_fix_nve_final",
+    "ucg_fix_langevin_create", "ucg_fix_langevin_init", "ucg_fix_langevin_init_from_ucgml",
+    "ucg_fix_langevin_post_force", "ucg_fix_langevin_end_of_step", "ucg_fix_langevin_t_target",
+    "ucg_fix_ucgstate_create", "ucg_fix_ucgstate_post_force",
+    "ucg_ranmars_fill",
+    "ucg_md_attach", "ucg_md_setup", "ucg_md_run", "ucg_md_info", "ucg_md_thermo",
+    "ucg_profile_enable", "ucg_profile_read",
+]
+
+
+class UcgError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"[ucg_hip error {code}] {msg}")
+        self.code = code
+        self.msg = msg
+
+
+def lib():
+    """Load libucg_hip.so (built in-tree by __graft_entry__.build()).  No fallback."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the UCG hot path.")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.ucg_abi_version.restype = C.c_int
+    L.ucg_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.ucg_ctx_destroy.argtypes = [vp]
+    L.ucg_ctx_destroy.restype = None
+    L.ucg_last_error.argtypes = [vp]
+    L.ucg_last_error.restype = C.c_char_p
+    L.ucg_ctx_set_stream.argtypes = [vp, vp]
+    L.ucg_ctx_synchronize.argtypes = [vp]
+    L.ucg_ctx_set_units.argtypes = [vp, C.c_double, C.c_double, C.c_double, C.c_double, c_double_p]
+    L.ucg_pair_create.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.ucg_pair_create_host.argtypes = [C.c_int, C.c_double, C.POINTER(vp)]
+    L.ucg_pair_last_error.argtypes = [vp]
+    L.ucg_pair_last_error.restype = C.c_char_p
+    L.ucg_pair_destroy.argtypes = [vp]
+    L.ucg_pair_destroy.restype = None
+    L.ucg_pair_settings.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p)]
+    L.ucg_pair_coeff.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_char_p)]
+    L.ucg_pair_init.argtypes = [vp, C.c_int, C.c_double]
+    L.ucg_pair_cut.argtypes = [vp, C.c_int, C.c_int]
+    L.ucg_pair_cut.restype = C.c_double
+    L.ucg_pair_cutforce.argtypes = [vp]
+    L.ucg_pair_cutforce.restype = C.c_double
+    L.ucg_pair_single.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_double, c_double_p, c_double_p]
+    L.ucg_pair_table_count.argtypes = [vp]
+    L.ucg_pair_table_params.argtypes = [vp, C.c_int, c_double_p]
+    L.ucg_pair_table_array.argtypes = [vp, C.c_int, C.c_char_p, c_double_p, C.c_int]
+    L.ucg_pair_tabindex.argtypes = [vp, c_int_p, C.c_int]
+    L.ucg_pair_compute.argtypes = [vp, C.c_int, C.c_int, c_double_p, c_double_p]
+    L.ucg_pair_check_errors.argtypes = [vp]
+    L.ucg_atoms_upload.argtypes = [vp, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p, c_int_p, c_int_p, c_int_p,
+                                   c_int_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]
+    L.ucg_atoms_upload_comm.argtypes = [vp, c_double_p, c_int_p, c_double_p, c_double_p]
+    L.ucg_atoms_download.argtypes = [vp, C.c_int, c_double_p, c_double_p, c_double_p, c_int_p, c_int_p, c_int_p,
+                                     c_int_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]
+    L.ucg_atoms_counts.argtypes = [vp, c_int_p, c_int_p]
+    L.ucg_force_clear.argtypes = [vp]
+    L.ucg_neigh_upload_full.argtypes = [vp, C.c_int, c_int_p, c_ll_p, c_int_p]
+    L.ucg_domain_set.argtypes = [vp, c_double_p, c_double_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int]
+    L.ucg_neigh_rebuild.argtypes = [vp]
+    L.ucg_halo_forward.argtypes = [vp]
+    L.ucg_neigh_download.argtypes = [vp, c_int_p, c_int_p, c_ll_p, c_int_p, C.c_longlong, c_ll_p]
+    L.ucg_ghosts_download.argtypes = [vp, c_int_p, c_int_p, C.c_int]
+    L.ucg_fix_nve_initial.argtypes = [vp, C.c_int]
+    L.ucg_fix_nve_final.argtypes = [vp, C.c_int]
+    L.ucg_fix_langevin_create.argtypes = [vp, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int]
+    L.ucg_fix_langevin_init.argtypes = [vp, C.c_int, c_double_p, c_double_p]
+    L.ucg_fix_langevin_init_from_ucgml.argtypes = [vp, C.c_int, c_double_p]
+    L.ucg_fix_langevin_post_force.argtypes = [vp, C.c_int, C.c_longlong, C.c_longlong, C.c_longlong]
+    L.ucg_fix_langevin_end_of_step.argtypes = [vp, C.c_int, c_double_p]
+    L.ucg_fix_langevin_t_target.argtypes = [vp]
+    L.ucg_fix_langevin_t_target.restype = C.c_double
+    L.ucg_fix_ucgstate_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int]
+    L.ucg_fix_ucgstate_post_force.argtypes = [vp]
+    L.ucg_ranmars_fill.argtypes = [vp, C.c_int, C.c_longlong, C.c_int, c_double_p]
+    L.ucg_md_attach.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int]
+    L.ucg_md_setup.argtypes = [vp, C.c_longlong]
+    L.ucg_md_run.argtypes = [vp, C.c_longlong, C.c_int]
+    L.ucg_md_info.argtypes = [vp, c_ll_p]
+    L.ucg_md_thermo.argtypes = [vp, c_double_p]
+    L.ucg_profile_enable.argtypes = [vp, C.c_int]
+    L.ucg_profile_read.argtypes = [vp, c_ll_p, c_double_p, C.c_int]
+    _LIB = L
+    return L
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(c_double_p)
+
+
+def _ip(a):
+    return None if a is None else a.ctypes.data_as(c_int_p)
+
+
+def _argv(args):
+    return (C.c_char_p * len(args))(*[str(a).encode() for a in args])
+
+
+def _f64(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.int32)
+
+
+class Context:
+    """One GPU context (one per rank), plus the fix hooks that act on its resident beads."""
+
+    def __init__(self, device: int = -1, boltz=1.0, ftm2v=1.0, mvv2e=1.0, dt=0.002, special_lj=(1.0, 1.0, 1.0, 1.0)):
+        self.L = lib()
+        h = C.c_void_p()
+        rc = self.L.ucg_ctx_create(device, C.byref(h))
+        if rc:
+            raise UcgError(rc, "ucg_ctx_create failed: no usable HIP device (the UCG hot path has no CPU fallback)")
+        self.h = h
+        self.set_units(boltz, ftm2v, mvv2e, dt, special_lj)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.ucg_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def chk(self, rc):
+        if rc:
+            raise UcgError(rc, self.L.ucg_last_error(self.h).decode())
+
+    def set_units(self, boltz, ftm2v, mvv2e, dt, special_lj=(1.0, 1.0, 1.0, 1.0)):
+        s = _f64(special_lj)
+        self.chk(self.L.ucg_ctx_set_units(self.h, boltz, ftm2v, mvv2e, dt, _dp(s)))
+
+    def set_stream(self, stream_ptr):
+        self.chk(self.L.ucg_ctx_set_stream(self.h, C.c_void_p(stream_ptr) if stream_ptr else None))
+
+    def synchronize(self):
+        self.chk(self.L.ucg_ctx_synchronize(self.h))
+
+    # ---- atoms
+    def atoms_upload(self, nlocal, nghost, ntypes, x, v, type, tag, mask, ucgstate, ucgl, ucgvl, ucgml, ucgp, mass):
+        keep = [_f64(x), _f64(v), _i32(type), _i32(tag), _i32(mask), _i32(ucgstate), _f64(ucgl), _f64(ucgvl),
+                _f64(ucgml), _f64(ucgp), _f64(mass)]
+        self.chk(self.L.ucg_atoms_upload(self.h, nlocal, nghost, ntypes, _dp(keep[0]), _dp(keep[1]), _ip(keep[2]),
+                                         _ip(keep[3]), _ip(keep[4]), _ip(keep[5]), _dp(keep[6]), _dp(keep[7]),
+                                         _dp(keep[8]), _dp(keep[9]), _dp(keep[10])))
+
+    def upload_beads(self, beads):
+        """all beads owned, no ghosts (the device builder makes the periodic images)"""
+        self.atoms_upload(beads.n, 0, beads.ntypes, beads.x, beads.v, beads.type, beads.tag, beads.mask,
+                          beads.ucgstate, beads.ucgl, beads.ucgvl, beads.ucgml, beads.ucgp, beads.mass)
+
+    def atoms_upload_comm(self, x, ucgstate, ucgl, ucgp):
+        k = [_f64(x), _i32(ucgstate), _f64(ucgl), _f64(ucgp)]
+        self.chk(self.L.ucg_atoms_upload_comm(self.h, _dp(k[0]), _ip(k[1]), _dp(k[2]), _dp(k[3])))
+
+    def counts(self):
+        a, b = C.c_int(0), C.c_int(0)
+        self.chk(self.L.ucg_atoms_counts(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def atoms_download(self, with_ghosts=False):
+        nl, ng = self.counts()
+        nall = nl + (ng if with_ghosts else 0)
+        out = dict(
+            x=np.zeros((nall, 3)), v=np.zeros((nl, 3)), f=np.zeros((nl, 3)), type=np.zeros(nall, np.int32),
+            tag=np.zeros(nall, np.int32), ucgstate=np.zeros(nall, np.int32), num_ucgstates=np.zeros(nl, np.int32),
+            ucgl=np.zeros(nall), ucgvl=np.zeros(nl), ucgml=np.zeros(nl), ucgp=np.zeros(nall), ucgforce=np.zeros(nl),
+            scores=np.zeros((nl, 2)))
+        self.chk(self.L.ucg_atoms_download(
+            self.h, 1 if with_ghosts else 0, _dp(out["x"]), _dp(out["v"]), _dp(out["f"]), _ip(out["type"]),
+            _ip(out["tag"]), _ip(out["ucgstate"]), _ip(out["num_ucgstates"]), _dp(out["ucgl"]), _dp(out["ucgvl"]),
+            _dp(out["ucgml"]), _dp(out["ucgp"]), _dp(out["ucgforce"]), _dp(out["scores"])))
+        out["nlocal"], out["nghost"] = nl, ng
+        return out
+
+    def force_clear(self):
+        self.chk(self.L.ucg_force_clear(self.h))
+
+    # ---- neighbour lists / domain
+    def neigh_upload_full(self, numneigh, first, neigh):
+        nn, fi, ne = _i32(numneigh), np.ascontiguousarray(first, dtype=np.int64), _i32(neigh)
+        if ne.size == 0:
+            ne = np.zeros(1, np.int32)
+        self.chk(self.L.ucg_neigh_upload_full(self.h, len(nn), _ip(nn), fi.ctypes.data_as(c_ll_p), _ip(ne)))
+
+    def domain_set(self, boxlo, boxhi, cutforce, skin, every=1, delay=0, check=1):
+        lo, hi = _f64(boxlo), _f64(boxhi)
+        self.chk(self.L.ucg_domain_set(self.h, _dp(lo), _dp(hi), cutforce, skin, every, delay, check))
+
+    def neigh_rebuild(self):
+        self.chk(self.L.ucg_neigh_rebuild(self.h))
+
+    def halo_forward(self):
+        self.chk(self.L.ucg_halo_forward(self.h))
+
+    def neigh_download(self):
+        inum, total = C.c_int(0), C.c_longlong(0)
+        self.chk(self.L.ucg_neigh_download(self.h, C.byref(inum), None, None, None, 0, C.byref(total)))
+        n, tot = inum.value, total.value
+        nn = np.zeros(max(n, 1), np.int32)
+        fi = np.zeros(max(n, 1), np.int64)
+        ne = np.zeros(max(tot, 1), np.int32)
+        self.chk(self.L.ucg_neigh_download(self.h, C.byref(inum), _ip(nn), fi.ctypes.data_as(c_ll_p), _ip(ne), tot,
+                                           C.byref(total)))
+        return np.arange(n, dtype=np.int32), nn[:n], fi[:n], ne[:tot]
+
+    def ghosts_download(self):
+        nl, ng = self.counts()
+        src = np.zeros(max(ng, 1), np.int32)
+        sh = np.zeros((max(ng, 1), 3), np.int32)
+        self.chk(self.L.ucg_ghosts_download(self.h, _ip(src), _ip(sh), ng))
+        return src[:ng], sh[:ng]
+
+    # ---- fix nve/ucgld
+    def fix_nve_ucgld_initial_integrate(self, groupbit=1):
+        self.chk(self.L.ucg_fix_nve_initial(self.h, groupbit))
+
+    def fix_nve_ucgld_final_integrate(self, groupbit=1):
+        self.chk(self.L.ucg_fix_nve_final(self.h, groupbit))
+
+    # ---- fix ucgld/langevin
+    def fix_ucgld_langevin(self, t_start, t_stop, damp, seed, me=0):
+        self.chk(self.L.ucg_fix_langevin_create(self.h, t_start, t_stop, damp, int(seed), me))
+
+    def fix_ucgld_langevin_init(self, ntypes, ucgml_by_type_index):
+        ml = _f64(ucgml_by_type_index)
+        self.chk(self.L.ucg_fix_langevin_init_from_ucgml(self.h, ntypes, _dp(ml)))
+
+    def fix_ucgld_langevin_post_force(self, ntimestep, beginstep, endstep, groupbit=1):
+        self.chk(self.L.ucg_fix_langevin_post_force(self.h, groupbit, ntimestep, beginstep, endstep))
+
+    def fix_ucgld_langevin_end_of_step(self, groupbit=1):
+        t = C.c_double(0)
+        self.chk(self.L.ucg_fix_langevin_end_of_step(self.h, groupbit, C.byref(t)))
+        return t.value
+
+    def fix_ucgld_langevin_t_target(self):
+        return self.L.ucg_fix_langevin_t_target(self.h)
+
+    # ---- fix ucgstate
+    def fix_ucgstate(self, mode=None, seed=0, rate=0.01, me=0):
+        """mode: None (plain) | "ld" | "mc" -- `fix ID grp ucgstate [ld | mc seed rate]`"""
+        self.chk(self.L.ucg_fix_ucgstate_create(self.h, 1 if mode == "ld" else 0, 1 if mode == "mc" else 0, int(seed),
+                                                float(rate), me))
+
+    def fix_ucgstate_post_force(self):
+        self.chk(self.L.ucg_fix_ucgstate_post_force(self.h))
+
+    # ---- RanMars
+    def ranmars_fill(self, seed, skip, n):
+        out = np.zeros(max(n, 1))
+        self.chk(self.L.ucg_ranmars_fill(self.h, int(seed), int(skip), int(n), _dp(out)))
+        return out[:n]
+
+    # ---- resident driver
+    def md_attach(self, pair, nve=True, langevin=False, ucgstate=False):
+        self.chk(self.L.ucg_md_attach(self.h, pair.h, int(nve), int(langevin), int(ucgstate)))
+
+    def md_setup(self, nsteps):
+        self.chk(self.L.ucg_md_setup(self.h, nsteps))
+
+    def md_run(self, nsteps, thermo_every=0):
+        self.chk(self.L.ucg_md_run(self.h, nsteps, thermo_every))
+
+    def md_info(self):
+        out = np.zeros(16, np.int64)
+        self.chk(self.L.ucg_md_info(self.h, out.ctypes.data_as(c_ll_p)))
+        keys = ["ntimestep", "nrebuild", "nlocal", "nghost", "list_entries", "pair_error_steps", "maxrow", "pitch",
+                "nbx", "nby", "nbz"]
+        return dict(zip(keys, [int(v) for v in out[:len(keys)]]))
+
+    def md_thermo(self):
+        out = np.zeros(9)
+        self.chk(self.L.ucg_md_thermo(self.h, _dp(out)))
+        return dict(eng_vdwl=out[0], virial=out[1:7].copy(), lambda_temp=out[7], state1=out[8])
+
+    # ---- measurement
+    def profile_enable(self, on=True):
+        self.chk(self.L.ucg_profile_enable(self.h, int(on)))
+
+    def profile_read(self, reset=True):
+        n, ms = C.c_longlong(0), C.c_double(0)
+        self.chk(self.L.ucg_profile_read(self.h, C.byref(n), C.byref(ms), int(reset)))
+        return n.value, ms.value
+
+
+class _HostOnly:
+    """stands in for a Context when a pair is created without a device (setup half only)"""
+
+    def __init__(self):
+        self.L = lib()
+        self.h = None
+        self.pair_h = None
+
+    def chk(self, rc):
+        if rc:
+            raise UcgError(rc, self.L.ucg_pair_last_error(self.pair_h).decode())
+
+
+class Pair:
+    """pair_style table_ucgld | table_ucg_bethe | table_ucg_bethe_density on the GPU.
+
+    ``Pair(None, style)`` builds a host-only pair: settings / coeff / init / single and table
+    inspection work (that half runs on the host in the reference too); compute() is refused.
+    """
+
+    def __init__(self, ctx, style: str, boltz: float = 1.0):
+        self.style = style
+        h = C.c_void_p()
+        if ctx is None:
+            self.ctx = _HostOnly()
+            rc = self.ctx.L.ucg_pair_create_host(STYLE_IDS[style], boltz, C.byref(h))
+            if rc:
+                raise UcgError(rc, "ucg_pair_create_host failed")
+            self.ctx.pair_h = h
+        else:
+            self.ctx = ctx
+            ctx.chk(ctx.L.ucg_pair_create(ctx.h, STYLE_IDS[style], C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None) and (isinstance(self.ctx, _HostOnly) or getattr(self.ctx, "h", None)):
+            self.ctx.L.ucg_pair_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def settings(self, args):
+        self.ctx.chk(self.ctx.L.ucg_pair_settings(self.h, len(args), _argv(args)))
+
+    def coeff(self, args, ntypes=2):
+        self.ctx.chk(self.ctx.L.ucg_pair_coeff(self.h, ntypes, len(args), _argv(args)))
+
+    def init(self, ntypes=2, T=1.0):
+        self.ctx.chk(self.ctx.L.ucg_pair_init(self.h, ntypes, T))
+
+    def init_one(self, i, j):
+        return self.ctx.L.ucg_pair_cut(self.h, i, j)
+
+    @property
+    def cutforce(self):
+        return self.ctx.L.ucg_pair_cutforce(self.h)
+
+    def single(self, itype, jtype, rsq, factor_lj=1.0):
+        f, e = C.c_double(0), C.c_double(0)
+        self.ctx.chk(self.ctx.L.ucg_pair_single(self.h, itype, jtype, rsq, factor_lj, C.byref(f), C.byref(e)))
+        return e.value, f.value
+
+    def table_count(self):
+        return self.ctx.L.ucg_pair_table_count(self.h)
+
+    def table_params(self, m):
+        out = np.zeros(5)
+        self.ctx.chk(self.ctx.L.ucg_pair_table_params(self.h, m, _dp(out)))
+        return dict(innersq=out[0], delta=out[1], invdelta=out[2], deltasq6=out[3], cut=out[4])
+
+    def table_array(self, m, which):
+        n = self.ctx.L.ucg_pair_table_array(self.h, m, which.encode(), None, 0)
+        if n <= 0:
+            return None
+        out = np.zeros(n)
+        self.ctx.L.ucg_pair_table_array(self.h, m, which.encode(), _dp(out), n)
+        return out
+
+    def tabindex(self):
+        n = self.ctx.L.ucg_pair_tabindex(self.h, None, 0)
+        out = np.zeros(n, np.int32)
+        self.ctx.L.ucg_pair_tabindex(self.h, _ip(out), n)
+        return out
+
+    def compute(self, eflag=0, vflag=0):
+        e = C.c_double(0)
+        v = np.zeros(6)
+        self.ctx.chk(self.ctx.L.ucg_pair_compute(self.h, eflag, vflag, C.byref(e), _dp(v)))
+        return e.value, v
+
+    def check_errors(self):
+        self.ctx.chk(self.ctx.L.ucg_pair_check_errors(self.h))

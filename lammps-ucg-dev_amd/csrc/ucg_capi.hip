@@ -1,0 +1,936 @@
+// ucg_capi.hip -- the extern "C" surface declared in include/ucg_hip.h.
+// No exception crosses the ABI: every entry point converts failures into an
+// error code + message (the LAMMPS glue forwards it to error->one / error->all).
+#include <cmath>
+#include <cstring>
+
+#include "../../include/ucg_hip.h"
+#include "ucg_ctx.h"
+
+using namespace ucg;
+
+namespace {
+
+template <typename F>
+int guarded(ucg_ctx *ctx, F &&fn)
+{
+  try {
+    return fn();
+  } catch (const InputError &e) {
+    if (ctx) ctx->err = e.msg;
+    return UCG_ERR_INPUT;
+  } catch (const HipFailure &e) {
+    if (ctx) ctx->err = std::string("HIP error: ") + hipGetErrorString(e.code) + " in " + e.what;
+    return UCG_ERR_HIP;
+  } catch (const std::exception &e) {
+    if (ctx) ctx->err = e.what();
+    return UCG_ERR_INVALID;
+  }
+}
+
+int fail(ucg_ctx *ctx, int code, const std::string &msg)
+{
+  if (ctx) ctx->err = msg;
+  return code;
+}
+
+// pair entry points: input-error messages are kept on the pair as well, so that a
+// host-only pair (no context, see ucg_pair_create_host) can report them
+template <typename F>
+int guarded_pair(ucg_pair *p, F &&fn)
+{
+  try {
+    return fn();
+  } catch (const InputError &e) {
+    p->err = e.msg;
+    if (p->ctx) p->ctx->err = e.msg;
+    return UCG_ERR_INPUT;
+  } catch (const HipFailure &e) {
+    p->err = std::string("HIP error: ") + hipGetErrorString(e.code) + " in " + e.what;
+    if (p->ctx) p->ctx->err = p->err;
+    return UCG_ERR_HIP;
+  } catch (const std::exception &e) {
+    p->err = e.what();
+    if (p->ctx) p->ctx->err = p->err;
+    return UCG_ERR_INVALID;
+  }
+}
+
+template <typename T>
+void h2d(ucg_ctx *ctx, T *dst, const T *src, size_t n)
+{
+  if (n) UCG_HIP(hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+}
+template <typename T>
+void d2h(ucg_ctx *ctx, T *dst, const T *src, size_t n)
+{
+  if (n) UCG_HIP(hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+}
+void sync(ucg_ctx *ctx) { UCG_HIP(hipStreamSynchronize(ctx->stream)); }
+
+}  // namespace
+
+AtomsDev ucg_ctx::atoms_dev() const
+{
+  AtomsDev A;
+  A.nlocal = nlocal;
+  A.nghost = nghost;
+  A.pos4 = pos4.get();
+  A.vel4 = vel4.get();
+  A.frc4 = frc4.get();
+  A.scores = scores.get();
+  A.meta = meta.get();
+  A.ucgp = ucgp.get();
+  A.tag = tag.get();
+  A.mask = mask.get();
+  A.num_ucgstates = num_ucgstates.get();
+  A.ucgml = ucgml.get();
+  A.mass = mass.get();
+  return A;
+}
+
+ListDev ucg_ctx::list_dev() const
+{
+  ListDev L;
+  L.inum = list_inum;
+  L.pitch = list_pitch;
+  L.maxrow = list_maxrow;
+  L.neigh = neigh.get();
+  L.numneigh = numneigh.get();
+  return L;
+}
+
+void ucg_ctx::ensure_rm_jump(int n)
+{
+  const int need = (n + RANMARS_CHUNK - 1) / RANMARS_CHUNK + 1;
+  if (need <= rm_chunks) return;
+  const int want = need + need / 4 + 8;
+  std::vector<unsigned int> host((size_t) want * 97);
+  ranmars_jump_host(want, host.data());
+  rm_jump.reserve(host.size());
+  UCG_HIP(hipMemcpyAsync(rm_jump.get(), host.data(), host.size() * sizeof(unsigned int), hipMemcpyHostToDevice, stream));
+  UCG_HIP(hipStreamSynchronize(stream));
+  rm_chunks = want;
+}
+
+extern "C" {
+
+int ucg_abi_version(void) { return UCG_ABI_VERSION; }
+
+int ucg_ctx_create(int device, ucg_ctx **out)
+{
+  if (!out) return UCG_ERR_INVALID;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return UCG_ERR_HIP;
+  ucg_ctx *ctx = new ucg_ctx();
+  int rc = guarded(ctx, [&]() -> int {
+    if (device >= 0) UCG_HIP(hipSetDevice(device));
+    UCG_HIP(hipGetDevice(&ctx->device));
+    UCG_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    ctx->own_stream = true;
+    ctx->redout.reserve(64);
+    return UCG_OK;
+  });
+  if (rc) {
+    delete ctx;
+    return rc;
+  }
+  *out = ctx;
+  return UCG_OK;
+}
+
+void ucg_ctx_destroy(ucg_ctx *ctx)
+{
+  if (!ctx) return;
+  (void) hipStreamSynchronize(ctx->stream);
+  for (auto ev : ctx->prof_ev) (void) hipEventDestroy(ev);
+  domain_destroy(ctx);
+  if (ctx->own_stream && ctx->stream) (void) hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char *ucg_last_error(const ucg_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int ucg_ctx_set_stream(ucg_ctx *ctx, void *hip_stream)
+{
+  if (!ctx) return UCG_ERR_INVALID;
+  return guarded(ctx, [&]() -> int {
+    UCG_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream && ctx->stream) UCG_HIP(hipStreamDestroy(ctx->stream));
+    if (hip_stream) {
+      ctx->stream = (hipStream_t) hip_stream;
+      ctx->own_stream = false;
+    } else {
+      UCG_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+      ctx->own_stream = true;
+    }
+    return UCG_OK;
+  });
+}
+
+int ucg_ctx_synchronize(ucg_ctx *ctx)
+{
+  if (!ctx) return UCG_ERR_INVALID;
+  return guarded(ctx, [&]() -> int {
+    sync(ctx);
+    return UCG_OK;
+  });
+}
+
+int ucg_ctx_set_units(ucg_ctx *ctx, double boltz, double ftm2v, double mvv2e, double dt, const double *special_lj)
+{
+  if (!ctx) return UCG_ERR_INVALID;
+  ctx->boltz = boltz;
+  ctx->ftm2v = ftm2v;
+  ctx->mvv2e = mvv2e;
+  ctx->dt = dt;
+  if (special_lj)
+    for (int i = 0; i < 4; i++) ctx->special_lj[i] = special_lj[i];
+  return UCG_OK;
+}
+
+/* ------------------------------------------------------------------ pair */
+
+int ucg_pair_create(ucg_ctx *ctx, int style, ucg_pair **out)
+{
+  if (!ctx || !out) return UCG_ERR_INVALID;
+  if (style < 0 || style > 2) return fail(ctx, UCG_ERR_INVALID, "unknown pair style id");
+  ucg_pair *p = new ucg_pair(style);
+  p->ctx = ctx;
+  *out = p;
+  return UCG_OK;
+}
+
+int ucg_pair_create_host(int style, double boltz, ucg_pair **out)
+{
+  if (!out || style < 0 || style > 2) return UCG_ERR_INVALID;
+  ucg_pair *p = new ucg_pair(style);
+  p->ctx = nullptr;
+  p->host_boltz = boltz;
+  *out = p;
+  return UCG_OK;
+}
+
+const char *ucg_pair_last_error(const ucg_pair *p)
+{
+  if (!p) return "null pair";
+  if (p->ctx && p->err.empty()) return p->ctx->err.c_str();
+  return p->err.c_str();
+}
+
+void ucg_pair_destroy(ucg_pair *p)
+{
+  if (!p) return;
+  if (p->ctx) {
+    (void) hipStreamSynchronize(p->ctx->stream);
+    if (p->ctx->md_pair == p) p->ctx->md_pair = nullptr;
+  }
+  delete p;
+}
+
+int ucg_pair_settings(ucg_pair *p, int narg, const char *const *arg)
+{
+  if (!p) return UCG_ERR_INVALID;
+  return guarded_pair(const_cast<ucg_pair *>(p), [&]() -> int {
+    p->uploaded = false;
+    p->model.settings(narg, arg);
+    return UCG_OK;
+  });
+}
+
+int ucg_pair_coeff(ucg_pair *p, int ntypes, int narg, const char *const *arg)
+{
+  if (!p) return UCG_ERR_INVALID;
+  return guarded_pair(const_cast<ucg_pair *>(p), [&]() -> int {
+    p->uploaded = false;
+    p->model.coeff(ntypes, narg, arg);
+    return UCG_OK;
+  });
+}
+
+int ucg_pair_init(ucg_pair *p, int ntypes, double T)
+{
+  if (!p) return UCG_ERR_INVALID;
+  ucg_ctx *ctx = p->ctx;
+  return guarded_pair(p, [&]() -> int {
+    PairModel &M = p->model;
+    if (!(T > 0.0) || !std::isfinite(T))
+      throw InputError{"pair style needs the thermostat target temperature (Fix::extract(\"t_target\")); none given"};
+    M.init(ntypes, T, ctx ? ctx->boltz : p->host_boltz);
+    if (!ctx) return UCG_OK;  // host-only pair: tables and maps stay on the host
+    if (M.n_actual > UCG_MAX_ACTUAL) return fail(ctx, UCG_ERR_UNSUPPORTED, "more actual types than the GPU kernels stage (UCG_MAX_ACTUAL)");
+    const int na1 = M.n_actual + 1, nt = M.n_formal + 1, ms = M.max_states;
+    for (int t = 1; t <= M.n_actual; t++)
+      if (M.n_states_per_type[(size_t) t] != 2)
+        return fail(ctx, UCG_ERR_UNSUPPORTED,
+                    "GPU UCG styles cover 2-state types only (the reference cannot configure 1-state types either: "
+                    "formal type 0 is rejected by coeff())");
+    // device tables: only those reachable through tabindex after init_one
+    p->tabmap.assign(M.tables.size(), -1);
+    std::vector<int> order;
+    std::vector<int> pairtab((size_t) na1 * na1 * 4, 0);
+    for (int ti = 1; ti <= M.n_actual; ti++)
+      for (int tj = 1; tj <= M.n_actual; tj++)
+        for (int a = 0; a < 2; a++)
+          for (int b = 0; b < 2; b++) {
+            const int fi = M.formal_from_actual[(size_t) ti * ms + a], fj = M.formal_from_actual[(size_t) tj * ms + b];
+            if (fi > ntypes || fj > ntypes) throw InputError{"formal type exceeds atom->ntypes"};
+            const int id = M.tabindex[(size_t) fi * nt + fj];
+            if (p->tabmap[(size_t) id] < 0) {
+              p->tabmap[(size_t) id] = (int) order.size();
+              order.push_back(id);
+            }
+            pairtab[((size_t) ti * na1 + tj) * 4 + a * 2 + b] = p->tabmap[(size_t) id];
+          }
+    const int ntab = (int) order.size();
+    if (ntab > UCG_MAX_TABLES) return fail(ctx, UCG_ERR_UNSUPPORTED, "more tables than the GPU kernels stage (UCG_MAX_TABLES)");
+    const int tl = M.tablength, tlm1 = tl - 1;
+    std::vector<double4> tab((size_t) ntab * tl), par((size_t) ntab);
+    for (int d = 0; d < ntab; d++) {
+      const Table &tb = M.tables[(size_t) order[(size_t) d]];
+      par[(size_t) d] = make_double4(tb.innersq, tb.delta, tb.invdelta, tb.deltasq6);
+      for (int k = 0; k < tl; k++) {
+        double4 v = make_double4(0, 0, 0, 0);
+        if (M.tabstyle == LOOKUP) {
+          if (k < tlm1) v = make_double4(tb.e[(size_t) k], tb.f[(size_t) k], 0, 0);
+        } else if (M.tabstyle == LINEAR) {
+          v.x = tb.e[(size_t) k];
+          v.z = tb.f[(size_t) k];
+          if (k < tlm1) {
+            v.y = tb.de[(size_t) k];
+            v.w = tb.df[(size_t) k];
+          }
+        } else {
+          v = make_double4(tb.e[(size_t) k], tb.f[(size_t) k], tb.e2[(size_t) k], tb.f2[(size_t) k]);
+        }
+        tab[(size_t) d * tl + k] = v;
+      }
+    }
+    std::vector<double> cutsq((size_t) na1 * na1, 0.0), mu((size_t) na1 * 2, 0.0), prior((size_t) na1 * 2, 0.0);
+    for (int ti = 1; ti <= M.n_actual; ti++) {
+      for (int tj = 1; tj <= M.n_actual; tj++)
+        cutsq[(size_t) ti * na1 + tj] = M.cutsq[(size_t) ti * nt + tj];  // indexed by ACTUAL types, as the reference does (:213)
+      for (int s = 0; s < 2; s++) {
+        mu[(size_t) ti * 2 + s] = M.chem_pot[(size_t) M.formal_from_actual[(size_t) ti * ms + s]];
+        prior[(size_t) ti * 2 + s] = M.prior_prob_from_type[(size_t) ti * ms + s];
+      }
+    }
+    p->d_tab.reserve(tab.size());
+    p->d_tabpar.reserve(par.size());
+    p->d_pairtab.reserve(pairtab.size());
+    p->d_cutsq.reserve(cutsq.size());
+    p->d_mu.reserve(mu.size());
+    p->d_prior.reserve(prior.size());
+    p->d_err.reserve(4);
+    p->d_evout.reserve(8);
+    h2d(ctx, p->d_tab.get(), tab.data(), tab.size());
+    h2d(ctx, p->d_tabpar.get(), par.data(), par.size());
+    h2d(ctx, p->d_pairtab.get(), pairtab.data(), pairtab.size());
+    h2d(ctx, p->d_cutsq.get(), cutsq.data(), cutsq.size());
+    h2d(ctx, p->d_mu.get(), mu.data(), mu.size());
+    h2d(ctx, p->d_prior.get(), prior.data(), prior.size());
+    UCG_HIP(hipMemsetAsync(p->d_err.get(), 0, 4 * sizeof(int), ctx->stream));
+    sync(ctx);
+
+    PairDev &D = p->dev;
+    D.style = M.style;
+    D.tabstyle = M.tabstyle;
+    D.tablength = tl;
+    D.tlm1 = tlm1;
+    D.n_actual = M.n_actual;
+    D.ntab = ntab;
+    // one 1024-lane workgroup per CU owns the LDS: 160 KB minus the small static arrays
+    D.tab_in_lds = ((size_t) ntab * tl * sizeof(double4) <= 152 * 1024) ? 1 : 0;
+    D.pseudo_flag = M.pseudo_flag;
+    D.prior_flag = M.prior_flag;
+    D.method_flag = M.method_flag;
+    D.tab = p->d_tab.get();
+    D.tabpar = p->d_tabpar.get();
+    D.pairtab = p->d_pairtab.get();
+    D.cutsq = p->d_cutsq.get();
+    D.mu = p->d_mu.get();
+    D.prior_type = p->d_prior.get();
+    D.kT = M.kT;
+    for (int i = 0; i < 4; i++) D.special_lj[i] = ctx->special_lj[i];
+    if (M.style == STYLE_BETHE && M.prior_flag == PRIOR_CHEMPOT_NOISE)
+      return fail(ctx, UCG_ERR_UNSUPPORTED,
+                  "prior chemical_potential noise draws RanMars inside the neighbour loop in list order "
+                  "(UCG/pair_table_ucg_bethe.cpp:187,235); not reproducible on a parallel device");
+    p->uploaded = true;
+    return UCG_OK;
+  });
+}
+
+double ucg_pair_cut(const ucg_pair *p, int i, int j)
+{
+  if (!p || !p->model.initialized) return -1.0;
+  const int nt = p->model.n_formal + 1;
+  if (i < 1 || j < 1 || i >= nt || j >= nt) return -1.0;
+  return p->model.tables[(size_t) p->model.tabindex[(size_t) i * nt + j]].cut;
+}
+
+double ucg_pair_cutforce(const ucg_pair *p) { return (p && p->model.initialized) ? p->model.cutforce : -1.0; }
+
+int ucg_pair_single(const ucg_pair *p, int itype, int jtype, double rsq, double factor_lj, double *fforce, double *energy)
+{
+  if (!p || !fforce || !energy) return UCG_ERR_INVALID;
+  return guarded_pair(const_cast<ucg_pair *>(p), [&]() -> int {
+    if (!p->model.initialized) throw InputError{"pair style not initialised"};
+    const int nt = p->model.n_formal + 1;
+    if (itype < 1 || jtype < 1 || itype >= nt || jtype >= nt) throw InputError{"type out of range in single()"};
+    *energy = p->model.single(itype, jtype, rsq, factor_lj, *fforce);
+    return UCG_OK;
+  });
+}
+
+int ucg_pair_table_count(const ucg_pair *p) { return p ? (int) p->model.tables.size() : -1; }
+
+int ucg_pair_table_params(const ucg_pair *p, int m, double *out5)
+{
+  if (!p || !out5 || m < 0 || m >= (int) p->model.tables.size()) return UCG_ERR_INVALID;
+  const Table &tb = p->model.tables[(size_t) m];
+  out5[0] = tb.innersq;
+  out5[1] = tb.delta;
+  out5[2] = tb.invdelta;
+  out5[3] = tb.deltasq6;
+  out5[4] = tb.cut;
+  return UCG_OK;
+}
+
+int ucg_pair_table_array(const ucg_pair *p, int m, const char *which, double *out, int cap)
+{
+  if (!p || !which || m < 0 || m >= (int) p->model.tables.size()) return -1;
+  const Table &tb = p->model.tables[(size_t) m];
+  const std::vector<double> *v = nullptr;
+  const std::string w = which;
+  if (w == "rsq") v = &tb.rsq;
+  else if (w == "e") v = &tb.e;
+  else if (w == "f") v = &tb.f;
+  else if (w == "de") v = &tb.de;
+  else if (w == "df") v = &tb.df;
+  else if (w == "e2") v = &tb.e2;
+  else if (w == "f2") v = &tb.f2;
+  else if (w == "rfile") v = &tb.rfile;
+  else if (w == "efile") v = &tb.efile;
+  else if (w == "ffile") v = &tb.ffile;
+  else if (w == "e2file") v = &tb.e2file;
+  else if (w == "f2file") v = &tb.f2file;
+  else return -1;
+  const int n = (int) v->size();
+  if (out && cap >= n) std::memcpy(out, v->data(), sizeof(double) * (size_t) n);
+  return n;
+}
+
+int ucg_pair_tabindex(const ucg_pair *p, int *out, int cap)
+{
+  if (!p) return -1;
+  const int n = (int) p->model.tabindex.size();
+  if (out && cap >= n) std::memcpy(out, p->model.tabindex.data(), sizeof(int) * (size_t) n);
+  return n;
+}
+
+int ucg_pair_compute(ucg_pair *p, int eflag, int vflag, double *eng_vdwl, double *virial)
+{
+  if (!p || !p->ctx) return UCG_ERR_INVALID;
+  ucg_ctx *ctx = p->ctx;
+  return guarded(ctx, [&]() -> int {
+    if (!p->uploaded) return fail(ctx, UCG_ERR_INVALID, "ucg_pair_compute before ucg_pair_init");
+    if (p->model.style == STYLE_BETHE_DENSITY) return fail(ctx, UCG_ERR_UNSUPPORTED, "table_ucg_bethe_density kernels are not built yet");
+    if (ctx->list_inum != ctx->nlocal) return fail(ctx, UCG_ERR_INVALID, "neighbour list does not match the resident atoms");
+    const bool ev = (eflag || vflag);
+    const int nb = pair_gather_blocks(ctx->nlocal);
+    if (ev) p->d_evpart.reserve((size_t) nb * 8 + 8);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ctx->prof_on) {
+      UCG_HIP(hipEventCreate(&e0));
+      UCG_HIP(hipEventCreate(&e1));
+      UCG_HIP(hipEventRecord(e0, ctx->stream));
+    }
+    UCG_HIP(launch_pair_gather(p->dev, ctx->atoms_dev(), ctx->list_dev(), ev, p->d_evpart.get(), p->d_evout.get(),
+                               p->d_err.get(), ctx->stream));
+    if (ctx->prof_on) {
+      UCG_HIP(hipEventRecord(e1, ctx->stream));
+      ctx->prof_ev.push_back(e0);
+      ctx->prof_ev.push_back(e1);
+    }
+    if (ev) {
+      double out[8];
+      d2h(ctx, out, p->d_evout.get(), 8);
+      sync(ctx);
+      if (eng_vdwl) *eng_vdwl = out[0];
+      if (virial)
+        for (int c = 0; c < 6; c++) virial[c] = out[1 + c];
+      ctx->thermo[0] = out[0];
+      for (int c = 0; c < 6; c++) ctx->thermo[1 + c] = out[1 + c];
+    }
+    return UCG_OK;
+  });
+}
+
+int ucg_pair_check_errors(ucg_pair *p)
+{
+  if (!p || !p->ctx) return UCG_ERR_INVALID;
+  ucg_ctx *ctx = p->ctx;
+  return guarded(ctx, [&]() -> int {
+    if (!p->uploaded) return UCG_OK;
+    int flag = 0;
+    d2h(ctx, &flag, p->d_err.get(), 1);
+    sync(ctx);
+    if (!flag) return UCG_OK;
+    UCG_HIP(hipMemsetAsync(p->d_err.get(), 0, sizeof(int), ctx->stream));
+    if (flag & 1) return fail(ctx, UCG_ERR_TABLE_INNER, "Pair distance < table inner cutoff");
+    return fail(ctx, UCG_ERR_TABLE_OUTER, "Pair distance > table outer cutoff");
+  });
+}
+
+/* ----------------------------------------------------------------- atoms */
+
+int ucg_atoms_upload(ucg_ctx *ctx, int nlocal, int nghost, int ntypes, const double *x, const double *v,
+                     const int *type, const int *tag, const int *mask, const int *ucgstate, const double *ucgl,
+                     const double *ucgvl, const double *ucgml, const double *ucgp, const double *mass)
+{
+  if (!ctx || nlocal < 0 || nghost < 0 || !x || !type || !ucgstate || !ucgl) return UCG_ERR_INVALID;
+  return guarded(ctx, [&]() -> int {
+    const size_t nall = (size_t) nlocal + nghost, nl = (size_t) nlocal;
+    if (nall >= (size_t) UCG_NEIGHMASK) return fail(ctx, UCG_ERR_INVALID, "too many atoms for 29-bit neighbour indices");
+    ctx->pos4.reserve(nall);
+    ctx->meta.reserve(nall);
+    ctx->ucgp.reserve(nall);
+    ctx->tag.reserve(nall);
+    ctx->vel4.reserve(nl);
+    ctx->frc4.reserve(nl);
+    ctx->scores.reserve(nl);
+    ctx->mask.reserve(nl);
+    ctx->num_ucgstates.reserve(nl);
+    ctx->ucgml.reserve(nl);
+    ctx->mass.reserve((size_t) ntypes + 1);
+    std::vector<double4> p4(nall), v4(nl);
+    std::vector<int> meta(nall), tg(nall), mk(nl);
+    std::vector<double> up(nall), ml(nl);
+    for (size_t i = 0; i < nall; i++) {
+      p4[i] = make_double4(x[3 * i], x[3 * i + 1], x[3 * i + 2], ucgl[i]);
+      if (type[i] < 1 || type[i] > 0xFFFF) return fail(ctx, UCG_ERR_INVALID, "atom type out of range");
+      meta[i] = (type[i] & 0xFFFF) | ((ucgstate[i] & 1) << 16);
+      tg[i] = tag ? tag[i] : (int) i + 1;
+      up[i] = ucgp ? ucgp[i] : -1.0;
+    }
+    for (size_t i = 0; i < nl; i++) {
+      v4[i] = make_double4(v ? v[3 * i] : 0.0, v ? v[3 * i + 1] : 0.0, v ? v[3 * i + 2] : 0.0, ucgvl ? ucgvl[i] : 0.0);
+      mk[i] = mask ? mask[i] : 1;
+      ml[i] = ucgml ? ucgml[i] : 1.0;
+    }
+    h2d(ctx, ctx->pos4.get(), p4.data(), nall);
+    h2d(ctx, ctx->meta.get(), meta.data(), nall);
+    h2d(ctx, ctx->tag.get(), tg.data(), nall);
+    h2d(ctx, ctx->ucgp.get(), up.data(), nall);
+    h2d(ctx, ctx->vel4.get(), v4.data(), nl);
+    h2d(ctx, ctx->mask.get(), mk.data(), nl);
+    h2d(ctx, ctx->ucgml.get(), ml.data(), nl);
+    std::vector<double> ms((size_t) ntypes + 1, 1.0);
+    if (mass)
+      for (int t = 0; t <= ntypes; t++) ms[(size_t) t] = mass[t];
+    h2d(ctx, ctx->mass.get(), ms.data(), ms.size());
+    if (nl) {
+      UCG_HIP(hipMemsetAsync(ctx->frc4.get(), 0, nl * sizeof(double4), ctx->stream));
+      UCG_HIP(hipMemsetAsync(ctx->scores.get(), 0, nl * sizeof(double2), ctx->stream));
+      UCG_HIP(hipMemsetAsync(ctx->num_ucgstates.get(), 0, nl * sizeof(int), ctx->stream));
+    }
+    sync(ctx);
+    ctx->nlocal = nlocal;
+    ctx->nghost = nghost;
+    ctx->ntypes = ntypes;
+    ctx->list_inum = 0;
+    return UCG_OK;
+  });
+}
+
+int ucg_atoms_upload_comm(ucg_ctx *ctx, const double *x, const int *ucgstate, const double *ucgl, const double *ucgp)
+{
+  if (!ctx || !x || !ucgstate || !ucgl) return UCG_ERR_INVALID;
+  return guarded(ctx, [&]() -> int {
+    const size_t nall = (size_t) ctx->nlocal + ctx->nghost;
+    std::vector<double4> p4(nall);
+    std::vector<int> meta(nall);
+    d2h(ctx, meta.data(), ctx->meta.get(), nall);
+    sync(ctx);
+    for (size_t i = 0; i < nall; i++) {
+      p4[i] = make_double4(x[3 * i], x[3 * i + 1], x[3 * i + 2], ucgl[i]);
+      meta[i] = (meta[i] & 0xFFFF) | ((ucgstate[i] & 1) << 16);
+    }
+    h2d(ctx, ctx->pos4.get(), p4.data(), nall);
+    h2d(ctx, ctx->meta.get(), meta.data(), nall);
+    if (ucgp) h2d(ctx, ctx->ucgp.get(), ucgp, nall);
+    sync(ctx);
+    return UCG_OK;
+  });
+}
+
+int ucg_atoms_download(ucg_ctx *ctx, int with_ghosts, double *x, double *v, double *f, int *type, int *tag,
+                       int *ucgstate, int *num_ucgstates, double *ucgl, double *ucgvl, double *ucgml, double *ucgp,
+                       double *ucgforce, double *ucgsoftmaxscores)
+{
+  if (!ctx) return UCG_ERR_INVALID;
+  return guarded(ctx, [&]() -> int {
+    const size_t nl = (size_t) ctx->nlocal, nall = nl + (with_ghosts ? (size_t) ctx->nghost : 0);
+    std::vector<double4> p4, v4, f4;
+    std::vector<int> meta;
+    if (x || ucgl) {
+      p4.resize(nall);
+      d2h(ctx, p4.data(), ctx->pos4.get(), nall);
+    }
+    if (v || ucgvl) {
+      v4.resize(nl);
+      d2h(ctx, v4.data(), ctx->vel4.get(), nl);
+    }
+    if (f || ucgforce) {
+      f4.resize(nl);
+      d2h(ctx, f4.data(), ctx->frc4.get(), nl);
+    }
+    if (type || ucgstate) {
+      meta.resize(nall);
+      d2h(ctx, meta.data(), ctx->meta.get(), nall);
+    }
+    if (tag) d2h(ctx, tag, ctx->tag.get(), nall);
+    if (num_ucgstates) d2h(ctx, num_ucgstates, ctx->num_ucgstates.get(), nl);
+    if (ucgml) d2h(ctx, ucgml, ctx->ucgml.get(), nl);
+    if (ucgp) d2h(ctx, ucgp, ctx->ucgp.get(), nall);
+    if (ucgsoftmaxscores) d2h(ctx, (double2 *) ucgsoftmaxscores, ctx->scores.get(), nl);
+    sync(ctx);
+    for (size_t i = 0; i < nall; i++) {
+      if (x) { x[3 * i] = p4[i].x; x[3 * i + 1] = p4[i].y; x[3 * i + 2] = p4[i].z; }
+      if (ucgl) ucgl[i] = p4[i].w;
+      if (type) type[i] = meta[i] & 0xFFFF;
+      if (ucgstate) ucgstate[i] = (meta[i] >> 16) & 1;
+    }
+    for (size_t i = 0; i < nl; i++) {
+      if (v) { v[3 * i] = v4[i].x; v[3 * i + 1] = v4[i].y; v[3 * i + 2] = v4[i].z; }
+      if (ucgvl) ucgvl[i] = v4[i].w;
+      if (f) { f[3 * i] = f4[i].x; f[3 * i + 1] = f4[i].y; f[3 * i + 2] = f4[i].z; }
+      if (ucgforce) ucgforce[i] = f4[i].w;
+    }
+    return UCG_OK;
+  });
+}
+
+int ucg_atoms_counts(const ucg_ctx *ctx, int *nlocal, int *nghost)
+{
+  if (!ctx) return UCG_ERR_INVALID;
+  if (nlocal) *nlocal = ctx->nlocal;
+  if (nghost) *nghost = ctx->nghost;
+  return UCG_OK;
+}
+
+int ucg_force_clear(ucg_ctx *ctx)
+{
+  if (!ctx) return UCG_ERR_INVALID;
+  return guarded(ctx, [&]() -> int {
+    UCG_HIP(launch_force_clear(ctx->atoms_dev(), ctx->stream));
+    return UCG_OK;
+  });
+}
+
+/* ------------------------------------------------------------- neighbours */
+
+int ucg_neigh_upload_full(ucg_ctx *ctx, int inum, const int *numneigh, const long long *first, const int *neigh)
+{
+  if (!ctx || inum < 0 || !numneigh || !first || (!neigh && inum)) return UCG_ERR_INVALID;
+  return guarded(ctx, [&]() -> int {
+    if (inum != ctx->nlocal) return fail(ctx, UCG_ERR_INVALID, "full list must have one row per owned atom");
+    int maxrow = 0;
+    long long total = 0;
+    const int nall = ctx->nlocal + ctx->nghost;
+    for (int i = 0; i < inum; i++) {
+      if (numneigh[i] > maxrow) maxrow = numneigh[i];
+      total += numneigh[i];
+    }
+    const int pitch = ((inum + 63) / 64) * 64;
+    std::vector<int> tr((size_t) pitch * (size_t) (maxrow > 0 ? maxrow : 1), 0);
+    for (int i = 0; i < inum; i++)
+      for (int e = 0; e < numneigh[i]; e++) {
+        const int ent = neigh[first[i] + e];
+        if ((ent & UCG_NEIGHMASK) >= nall) return fail(ctx, UCG_ERR_INVALID, "neighbour index beyond nlocal+nghost");
+        tr[(size_t) e * pitch + i] = ent;
+      }
+    ctx->neigh.reserve(tr.size());
+    ctx->numneigh.reserve((size_t) pitch);
+    h2d(ctx, ctx->neigh.get(), tr.data(), tr.size());
+    h2d(ctx, ctx->numneigh.get(), numneigh, (size_t) inum);
+    sync(ctx);
+    ctx->list_inum = inum;
+    ctx->list_pitch = pitch;
+    ctx->list_maxrow = maxrow;
+    ctx->list_entries = total;
+    return UCG_OK;
+  });
+}
+
+int ucg_neigh_download(ucg_ctx *ctx, int *inum, int *numneigh, long long *first, int *neigh, long long cap, long long *total)
+{
+  if (!ctx) return UCG_ERR_INVALID;
+  return guarded(ctx, [&]() -> int {
+    if (inum) *inum = ctx->list_inum;
+    if (total) *total = ctx->list_entries;
+    if (!numneigh && !neigh) return UCG_OK;
+    const int n = ctx->list_inum;
+    std::vector<int> nn((size_t) n);
+    d2h(ctx, nn.data(), ctx->numneigh.get(), (size_t) n);
+    sync(ctx);
+    if (numneigh) std::memcpy(numneigh, nn.data(), sizeof(int) * (size_t) n);
+    if (first || neigh) {
+      std::vector<long long> fst((size_t) n);
+      long long pos = 0;
+      for (int i = 0; i < n; i++) {
+        fst[(size_t) i] = pos;
+        pos += nn[(size_t) i];
+      }
+      if (first) std::memcpy(first, fst.data(), sizeof(long long) * (size_t) n);
+      if (neigh) {
+        if (cap < pos) return fail(ctx, UCG_ERR_INVALID, "neighbour buffer too small");
+        std::vector<int> tr((size_t) ctx->list_pitch * (size_t) (ctx->list_maxrow > 0 ? ctx->list_maxrow : 1));
+        d2h(ctx, tr.data(), ctx->neigh.get(), tr.size());
+        sync(ctx);
+        for (int i = 0; i < n; i++)
+          for (int e = 0; e < nn[(size_t) i]; e++) neigh[fst[(size_t) i] + e] = tr[(size_t) e * ctx->list_pitch + i];
+      }
+    }
+    return UCG_OK;
+  });
+}
+
+/* ------------------------------------------------------------------ fixes */
+
+int ucg_fix_nve_initial(ucg_ctx *ctx, int groupbit)
+{
+  if (!ctx) return UCG_ERR_INVALID;
+  return guarded(ctx, [&]() -> int {
+    // dtv = dt, dtf = 0.5*dt*ftm2v  (UCG/fix_nve_ucgld.cpp:36-38)
+    UCG_HIP(launch_nve_initial(ctx->atoms_dev(), ctx->dt, 0.5 * ctx->dt * ctx->ftm2v, groupbit, ctx->stream));
+    return UCG_OK;
+  });
+}
+
+int ucg_fix_nve_final(ucg_ctx *ctx, int groupbit)
+{
+  if (!ctx) return UCG_ERR_INVALID;
+  return guarded(ctx, [&]() -> int {
+    UCG_HIP(launch_nve_final(ctx->atoms_dev(), 0.5 * ctx->dt * ctx->ftm2v, groupbit, ctx->stream));
+    return UCG_OK;
+  });
+}
+
+static void rng_setup(ucg_ctx *ctx, RanMarsDev &R, DevBuf<unsigned int> &h0, DevBuf<unsigned int> &h1, int seed)
+{
+  unsigned int hist[97];
+  long long count = 0;
+  ranmars_seed_host(seed, hist, &count);
+  h0.reserve(128);
+  h1.reserve(128);
+  UCG_HIP(hipMemcpyAsync(h0.get(), hist, sizeof(hist), hipMemcpyHostToDevice, ctx->stream));
+  UCG_HIP(hipStreamSynchronize(ctx->stream));
+  R.hist[0] = h0.get();
+  R.hist[1] = h1.get();
+  R.cur = 0;
+  R.count = count;
+}
+
+static void rng_draw(ucg_ctx *ctx, RanMarsDev &R, DevBuf<unsigned int> &draws, int n)
+{
+  ctx->ensure_rm_jump(n);
+  R.jump = ctx->rm_jump.get();
+  R.nchunks_max = ctx->rm_chunks;
+  draws.reserve((size_t) n + 1);
+  UCG_HIP(launch_ranmars(R, n, draws.get(), ctx->stream));
+}
+
+int ucg_fix_langevin_create(ucg_ctx *ctx, double t_start, double t_stop, double t_period, int seed, int me)
+{
+  if (!ctx) return UCG_ERR_INVALID;
+  return guarded(ctx, [&]() -> int {
+    if (t_period <= 0.0) throw InputError{"Fix langevin period must be > 0.0"};
+    if (seed <= 0) throw InputError{"Illegal fix langevin command"};
+    if (seed + me > 900000000) throw InputError{"Invalid seed for Marsaglia random # generator"};
+    FixLangevin &L = ctx->lang;
+    L.active = true;
+    L.t_start = t_start;
+    L.t_target = t_start;
+    L.t_stop = t_stop;
+    L.t_period = t_period;
+    L.seed = seed;
+    L.inited = false;
+    rng_setup(ctx, L.rng, L.hist0, L.hist1, seed + me);
+    return UCG_OK;
+  });
+}
+
+int ucg_fix_langevin_init(ucg_ctx *ctx, int ntypes, const double *gfactor1, const double *gfactor2)
+{
+  if (!ctx || !gfactor1 || !gfactor2 || ntypes < 1) return UCG_ERR_INVALID;
+  return guarded(ctx, [&]() -> int {
+    FixLangevin &L = ctx->lang;
+    if (!L.active) return fail(ctx, UCG_ERR_INVALID, "fix ucgld/langevin not created");
+    L.ntypes = ntypes;
+    L.gf1.reserve((size_t) ntypes + 1);
+    L.gf2.reserve((size_t) ntypes + 1);
+    h2d(ctx, L.gf1.get(), gfactor1, (size_t) ntypes + 1);
+    h2d(ctx, L.gf2.get(), gfactor2, (size_t) ntypes + 1);
+    sync(ctx);
+    L.inited = true;
+    return UCG_OK;
+  });
+}
+
+int ucg_fix_langevin_init_from_ucgml(ucg_ctx *ctx, int ntypes, const double *ml)
+{
+  if (!ctx || !ml || ntypes < 1) return UCG_ERR_INVALID;
+  // Fix_UCGLD_Langevin::init(), UCG/fix_ucgld_langevin.cpp:164-171 (ratio[i] = 1)
+  std::vector<double> g1((size_t) ntypes + 1, 0.0), g2((size_t) ntypes + 1, 0.0);
+  const FixLangevin &L = ctx->lang;
+  for (int i = 1; i <= ntypes; i++) {
+    g1[(size_t) i] = -ml[i] / L.t_period / ctx->ftm2v;
+    g2[(size_t) i] = std::sqrt(ml[i]) / ctx->ftm2v;
+    g2[(size_t) i] *= std::sqrt(24.0 * ctx->boltz / L.t_period / ctx->dt / ctx->mvv2e);
+    g1[(size_t) i] *= 1.0 / 1.0;
+    g2[(size_t) i] *= 1.0 / std::sqrt(1.0);
+  }
+  return ucg_fix_langevin_init(ctx, ntypes, g1.data(), g2.data());
+}
+
+int ucg_fix_langevin_post_force(ucg_ctx *ctx, int groupbit, long long ntimestep, long long beginstep, long long endstep)
+{
+  if (!ctx) return UCG_ERR_INVALID;
+  return guarded(ctx, [&]() -> int {
+    FixLangevin &L = ctx->lang;
+    if (!L.active || !L.inited) return fail(ctx, UCG_ERR_INVALID, "fix ucgld/langevin not initialised");
+    // compute_target(), :318-330
+    double delta = (double) (ntimestep - beginstep);
+    if (delta != 0.0) delta /= (double) (endstep - beginstep);
+    L.t_target = L.t_start + delta * (L.t_stop - L.t_start);
+    L.tsqrt = std::sqrt(L.t_target);
+    rng_draw(ctx, L.rng, L.draws, ctx->nlocal);
+    LangevinDev Lg;
+    Lg.gfactor1 = L.gf1.get();
+    Lg.gfactor2 = L.gf2.get();
+    Lg.tsqrt = L.tsqrt;
+    Lg.draws = L.draws.get();
+    UCG_HIP(launch_langevin(ctx->atoms_dev(), Lg, groupbit, ctx->stream));
+    return UCG_OK;
+  });
+}
+
+int ucg_fix_langevin_end_of_step(ucg_ctx *ctx, int groupbit, double *lambda_temp)
+{
+  if (!ctx) return UCG_ERR_INVALID;
+  return guarded(ctx, [&]() -> int {
+    const int nb = (ctx->nlocal + 255) / 256 + 1;
+    ctx->redpart.reserve((size_t) nb * 4);
+    UCG_HIP(launch_lambda_ke(ctx->atoms_dev(), groupbit, ctx->mvv2e, ctx->redpart.get(), ctx->redout.get(), ctx->stream));
+    double out[4];
+    d2h(ctx, out, ctx->redout.get(), 4);
+    sync(ctx);
+    // lambda_temp = lmd_ek / (0.5 * boltz * nlocal)   (:311)
+    ctx->lang.lambda_temp = out[0] / (0.5 * ctx->boltz * ctx->nlocal);
+    ctx->thermo[7] = ctx->lang.lambda_temp;
+    ctx->thermo[8] = out[1];
+    if (lambda_temp) *lambda_temp = ctx->lang.lambda_temp;
+    return UCG_OK;
+  });
+}
+
+double ucg_fix_langevin_t_target(const ucg_ctx *ctx) { return ctx ? ctx->lang.t_target : 0.0; }
+
+int ucg_fix_ucgstate_create(ucg_ctx *ctx, int ld_flag, int mc_flag, int mc_seed, double mc_rate, int me)
+{
+  if (!ctx) return UCG_ERR_INVALID;
+  return guarded(ctx, [&]() -> int {
+    FixUcgState &S = ctx->ucgst;
+    S.active = true;
+    S.ld_flag = ld_flag;
+    S.mc_flag = mc_flag;
+    S.mc_seed = mc_seed;
+    S.mc_rate = mc_rate;
+    if (mc_flag) {
+      if (mc_seed + me <= 0 || mc_seed + me > 900000000) throw InputError{"Invalid seed for Marsaglia random # generator"};
+      rng_setup(ctx, S.rng, S.hist0, S.hist1, mc_seed + me);
+    }
+    return UCG_OK;
+  });
+}
+
+int ucg_fix_ucgstate_post_force(ucg_ctx *ctx)
+{
+  if (!ctx) return UCG_ERR_INVALID;
+  return guarded(ctx, [&]() -> int {
+    FixUcgState &S = ctx->ucgst;
+    if (!S.active) return fail(ctx, UCG_ERR_INVALID, "fix ucgstate not created");
+    const unsigned int *draws = nullptr;
+    if (S.mc_flag && !S.ld_flag) {
+      // one uniform() per 2-state owned bead in index order (:117); every bead is 2-state here
+      rng_draw(ctx, S.rng, S.draws, ctx->nlocal);
+      draws = S.draws.get();
+    }
+    UCG_HIP(launch_ucgstate(ctx->atoms_dev(), S.ld_flag, S.mc_flag, S.mc_rate, draws, ctx->stream));
+    return UCG_OK;
+  });
+}
+
+int ucg_ranmars_fill(ucg_ctx *ctx, int seed, long long skip, int n, double *out)
+{
+  if (!ctx || !out || n < 0 || skip < 0) return UCG_ERR_INVALID;
+  return guarded(ctx, [&]() -> int {
+    RanMarsDev R{};
+    DevBuf<unsigned int> h0, h1, draws;
+    rng_setup(ctx, R, h0, h1, seed);
+    // skip in pieces so that the state carry-over between launches is exercised too
+    long long left = skip;
+    while (left > 0) {
+      const int piece = (int) (left > 1000003 ? 1000003 : left);
+      rng_draw(ctx, R, draws, piece);
+      left -= piece;
+    }
+    if (n) {
+      rng_draw(ctx, R, draws, n);
+      std::vector<unsigned int> host((size_t) n);
+      d2h(ctx, host.data(), draws.get(), (size_t) n);
+      sync(ctx);
+      for (int i = 0; i < n; i++) out[i] = (double) host[(size_t) i] * 5.9604644775390625e-08;
+    }
+    sync(ctx);
+    return UCG_OK;
+  });
+}
+
+/* ------------------------------------------------------------- measurement */
+
+int ucg_profile_enable(ucg_ctx *ctx, int on)
+{
+  if (!ctx) return UCG_ERR_INVALID;
+  ctx->prof_on = on != 0;
+  return UCG_OK;
+}
+
+int ucg_profile_read(ucg_ctx *ctx, long long *pair_launches, double *pair_ms, int reset)
+{
+  if (!ctx) return UCG_ERR_INVALID;
+  return guarded(ctx, [&]() -> int {
+    sync(ctx);
+    for (size_t i = 0; i + 1 < ctx->prof_ev.size(); i += 2) {
+      float ms = 0.f;
+      UCG_HIP(hipEventElapsedTime(&ms, ctx->prof_ev[i], ctx->prof_ev[i + 1]));
+      ctx->prof_ms += ms;
+      ctx->prof_launches++;
+      (void) hipEventDestroy(ctx->prof_ev[i]);
+      (void) hipEventDestroy(ctx->prof_ev[i + 1]);
+    }
+    ctx->prof_ev.clear();
+    if (pair_launches) *pair_launches = ctx->prof_launches;
+    if (pair_ms) *pair_ms = ctx->prof_ms;
+    if (reset) {
+      ctx->prof_launches = 0;
+      ctx->prof_ms = 0;
+    }
+    return UCG_OK;
+  });
+}
+
+}  // extern "C"

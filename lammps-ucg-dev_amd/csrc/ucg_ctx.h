@@ -1,0 +1,150 @@
+// ucg_ctx.h -- internal state behind the opaque ucg_ctx / ucg_pair handles.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "ucg_dev.h"
+#include "ucg_launch.h"
+#include "ucg_model.h"
+
+namespace ucg {
+
+struct HipFailure {
+  hipError_t code;
+  const char *what;
+};
+
+#define UCG_HIP(expr)                                       \
+  do {                                                      \
+    hipError_t e__ = (expr);                                \
+    if (e__ != hipSuccess) throw ucg::HipFailure{e__, #expr}; \
+  } while (0)
+
+template <typename T>
+class DevBuf {
+ public:
+  DevBuf() = default;
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() { release(); }
+  void release()
+  {
+    if (p_) (void) hipFree(p_);
+    p_ = nullptr;
+    cap_ = 0;
+  }
+  // grow (never shrink); contents are NOT preserved unless keep is set
+  void reserve(size_t n, bool keep = false, hipStream_t st = nullptr)
+  {
+    if (n <= cap_) return;
+    size_t want = n + n / 8 + 64;
+    T *q = nullptr;
+    UCG_HIP(hipMalloc((void **) &q, want * sizeof(T)));
+    if (keep && p_ && cap_) {
+      UCG_HIP(hipMemcpyAsync(q, p_, cap_ * sizeof(T), hipMemcpyDeviceToDevice, st));
+      UCG_HIP(hipStreamSynchronize(st));
+    }
+    if (p_) (void) hipFree(p_);
+    p_ = q;
+    cap_ = want;
+  }
+  T *get() const { return p_; }
+  size_t capacity() const { return cap_; }
+
+ private:
+  T *p_ = nullptr;
+  size_t cap_ = 0;
+};
+
+struct FixLangevin {
+  bool active = false;
+  double t_start = 0, t_stop = 0, t_period = 0, t_target = 0, tsqrt = 0;
+  int seed = 0, ntypes = 0;
+  bool inited = false;
+  DevBuf<double> gf1, gf2;
+  RanMarsDev rng{};
+  DevBuf<unsigned int> hist0, hist1, draws;
+  double lambda_temp = 0;
+};
+
+struct FixUcgState {
+  bool active = false;
+  int ld_flag = 0, mc_flag = 0, mc_seed = 0;
+  double mc_rate = 0.01;
+  RanMarsDev rng{};
+  DevBuf<unsigned int> hist0, hist1, draws;
+};
+
+}  // namespace ucg
+
+struct ucg_pair;
+
+struct ucg_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+  double boltz = 1, ftm2v = 1, mvv2e = 1, dt = 0.005;
+  double special_lj[4] = {1, 1, 1, 1};
+
+  // atoms
+  int nlocal = 0, nghost = 0, ntypes = 0;
+  ucg::DevBuf<double4> pos4, vel4, frc4;
+  ucg::DevBuf<double2> scores;
+  ucg::DevBuf<int> meta, tag, mask, num_ucgstates;
+  ucg::DevBuf<double> ucgp, ucgml, mass;
+  // neighbour list
+  ucg::DevBuf<int> neigh, numneigh;
+  int list_pitch = 0, list_maxrow = 0, list_inum = 0;
+  long long list_entries = 0;
+  // shared RanMars jump table
+  ucg::DevBuf<unsigned int> rm_jump;
+  int rm_chunks = 0;
+  // reductions
+  ucg::DevBuf<double> redpart, redout;
+  // fixes
+  ucg::FixLangevin lang;
+  ucg::FixUcgState ucgst;
+  // domain / rebuild (ucg_neigh.hip)
+  struct Domain *dom = nullptr;
+  // resident driver
+  ucg_pair *md_pair = nullptr;
+  bool md_nve = false, md_lang = false, md_ucgst = false;
+  long long ntimestep = 0, beginstep = 0, endstep = 0;
+  int groupbit = 1;
+  long long nrebuild = 0, pair_error_steps = 0;
+  double thermo[9] = {0};
+  // profiling
+  bool prof_on = false;
+  std::vector<hipEvent_t> prof_ev;  // pairs (start, stop) not yet read
+  long long prof_launches = 0;
+  double prof_ms = 0;
+
+  ucg::AtomsDev atoms_dev() const;
+  ucg::ListDev list_dev() const;
+  void ensure_rm_jump(int n);
+};
+
+struct ucg_pair {
+  ucg_ctx *ctx = nullptr;
+  ucg::PairModel model;
+  ucg::PairDev dev{};
+  bool uploaded = false;
+  ucg::DevBuf<double4> d_tab, d_tabpar;
+  ucg::DevBuf<int> d_pairtab;
+  ucg::DevBuf<double> d_cutsq, d_mu, d_prior;
+  ucg::DevBuf<int> d_err;
+  ucg::DevBuf<double> d_evpart, d_evout;
+  std::vector<int> tabmap;  // host table id -> device table id (or -1)
+  std::string err;
+  double host_boltz = 1.0;  // used by host-only pairs (no context)
+  explicit ucg_pair(int style) : model(style) {}
+};
+
+namespace ucg {
+// ucg_neigh.hip
+void domain_destroy(ucg_ctx *ctx);
+}

@@ -1,0 +1,63 @@
+// ucg_dev.h -- device-side layouts shared by the HIP kernels (gfx950).
+//
+// Data layout in HBM (all fp64 / int32, DESIGN.md section "HBM layout"):
+//   pos4[nall]   double4 {x, y, z, lambda}   -- lambda (ucgl) rides as the 4th coordinate
+//   vel4[nlocal] double4 {vx, vy, vz, vlambda}
+//   frc4[nlocal] double4 {fx, fy, fz, ucgforce}
+//   scores[nlocal] double2 ucgsoftmaxscores
+//   meta[nall]   int32  type | ucgstate << 16
+//   ucgp[nall]   double
+//   tag[nall], mask[nlocal], num_ucgstates[nlocal] int32; ucgml[nlocal] double
+//   neigh[maxrow][pitch] int32, row-transposed full list (entry e of bead k at e*pitch+k),
+//     so that a wavefront reads 64 consecutive ints per entry slot.
+//   tables: double4 per knot  SPLINE {e, f, e2, f2} | LINEAR {e, de, f, df} | LOOKUP {e, f, 0, 0}
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define UCG_META_TYPE(m) ((m) & 0xFFFF)
+#define UCG_META_STATE(m) (((m) >> 16) & 1)
+
+namespace ucg {
+
+struct PairDev {
+  int style, tabstyle, tablength, tlm1;
+  int n_actual;        // actual types are 1..n_actual
+  int ntab;            // tables resident on the device (those reachable through tabindex)
+  int tab_in_lds;      // 1: the kernels stage all tables in LDS
+  int pseudo_flag, prior_flag, method_flag;
+  const double4 *tab;     // [ntab * tablength]
+  const double4 *tabpar;  // [ntab] {innersq, delta, invdelta, deltasq6}
+  const int *pairtab;     // [(n_actual+1)^2 * 4] table of (ti, tj, a, b)
+  const double *cutsq;    // [(n_actual+1)^2]  cutsq[itype][jtype] as the reference indexes it
+  const double *mu;       // [(n_actual+1)*2]  chemical potential of state s of actual type t
+  const double *prior_type;  // [(n_actual+1)*2]
+  double kT;
+  double special_lj[4];
+};
+
+struct AtomsDev {
+  int nlocal, nghost;
+  double4 *pos4;
+  double4 *vel4;
+  double4 *frc4;
+  double2 *scores;
+  int *meta;
+  double *ucgp;
+  int *tag;
+  int *mask;
+  int *num_ucgstates;
+  double *ucgml;
+  const double *mass;  // [ntypes+1]
+};
+
+struct ListDev {
+  int inum;
+  int pitch;
+  int maxrow;
+  const int *neigh;
+  const int *numneigh;
+};
+
+}  // namespace ucg

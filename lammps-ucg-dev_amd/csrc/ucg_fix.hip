@@ -1,0 +1,234 @@
+// ucg_fix.hip -- per-bead kernels: fix nve/ucgld, fix ucgld/langevin, fix ucgstate,
+// force_clear and the small thermo reductions (gfx950).
+//
+//   k_nve_initial / k_nve_final   FixNVE_UCGLD::initial_integrate / final_integrate
+//                                 (UCG/fix_nve_ucgld.cpp:44-101, 104-153, per-type mass branch)
+//   k_langevin                    Fix_UCGLD_Langevin::post_force_templated<0>
+//                                 (UCG/fix_ucgld_langevin.cpp:226-297)
+//   k_lambda_ke                   Fix_UCGLD_Langevin::end_of_step (:303-312)
+//   k_ucgstate                    FixUCGState::post_force (UCG/fix_ucgstate.cpp:88-132)
+//   k_force_clear                 AtomVecUCG::force_clear (UCG/atom_vec_ucg.cpp:131-135)
+//
+// lambda rides as the 4th component of pos4 / vel4 / frc4, so the (x,v) and the
+// (lambda, v_lambda) velocity-Verlet updates are the same three double4 streams.
+// All of these are HBM-streaming kernels: one bead per lane, 32-byte accesses.
+// Compiled with -ffp-contract=off (bit parity with the scalar reference).
+#include "ucg_dev.h"
+#include "ucg_launch.h"
+#include "ucg_math.h"
+
+namespace ucg {
+
+namespace {
+
+constexpr int FIX_BLOCK = 256;
+
+__global__ __launch_bounds__(FIX_BLOCK) void k_nve_initial(const AtomsDev A, const double dtv, const double dtf,
+                                                          const int groupbit)
+{
+  const int i = blockIdx.x * FIX_BLOCK + threadIdx.x;
+  if (i >= A.nlocal) return;
+  if (!(A.mask[i] & groupbit)) return;
+  double4 x = A.pos4[i];
+  double4 v = A.vel4[i];
+  const double4 f = A.frc4[i];
+  const double dtfm = dtf / A.mass[UCG_META_TYPE(A.meta[i])];
+  v.x += dtfm * f.x;
+  v.y += dtfm * f.y;
+  v.z += dtfm * f.z;
+  x.x += dtv * v.x;
+  x.y += dtv * v.y;
+  x.z += dtv * v.z;
+  const double dtflm = dtf / A.ucgml[i];
+  v.w += dtflm * f.w;
+  x.w += dtv * v.w;
+  A.vel4[i] = v;
+  A.pos4[i] = x;
+}
+
+__global__ __launch_bounds__(FIX_BLOCK) void k_nve_final(const AtomsDev A, const double dtf, const int groupbit)
+{
+  const int i = blockIdx.x * FIX_BLOCK + threadIdx.x;
+  if (i >= A.nlocal) return;
+  if (!(A.mask[i] & groupbit)) return;
+  double4 v = A.vel4[i];
+  const double4 f = A.frc4[i];
+  const double dtfm = dtf / A.mass[UCG_META_TYPE(A.meta[i])];
+  v.x += dtfm * f.x;
+  v.y += dtfm * f.y;
+  v.z += dtfm * f.z;
+  const double dtflm = dtf / A.ucgml[i];
+  v.w += dtflm * f.w;
+  A.vel4[i] = v;
+}
+
+__global__ __launch_bounds__(FIX_BLOCK) void k_langevin(const AtomsDev A, const LangevinDev Lg, const int groupbit)
+{
+  const int i = blockIdx.x * FIX_BLOCK + threadIdx.x;
+  if (i >= A.nlocal) return;
+  if (!(A.mask[i] & groupbit)) return;
+  const int t = UCG_META_TYPE(A.meta[i]);
+  const double gamma1 = Lg.gfactor1[t];
+  const double gamma2 = Lg.gfactor2[t] * Lg.tsqrt;
+  // RanMars::uniform() is an exact multiple of 2^-24
+  const double uni = (double) Lg.draws[i] * 5.9604644775390625e-08;
+  const double fran = gamma2 * (uni - 0.5);
+  const double fdrag = gamma1 * A.vel4[i].w;
+  double4 f = A.frc4[i];
+  f.w += fdrag + fran;
+  A.frc4[i] = f;
+}
+
+__global__ __launch_bounds__(FIX_BLOCK) void k_ucgstate(const AtomsDev A, const int ld_flag, const int mc_flag,
+                                                       const double mc_rate, const unsigned int *draws)
+{
+  const int i = blockIdx.x * FIX_BLOCK + threadIdx.x;
+  if (i >= A.nlocal) return;
+  int meta = A.meta[i];
+  double ucgp;
+  if (A.num_ucgstates[i] == 1) {
+    if (!ld_flag) meta &= 0xFFFF;
+    ucgp = 1.0;
+  } else {
+    const double2 s = A.scores[i];
+    const double e0 = ucg_exp((700.0 < s.x) ? 700.0 : s.x);
+    const double e1 = ucg_exp((700.0 < s.y) ? 700.0 : s.y);
+    double softmax_denom = 0.0;
+    softmax_denom += e0;
+    softmax_denom += e1;
+    const double r = e1 / softmax_denom;
+    const double lo = (1e-6 < r) ? r : 1e-6;
+    ucgp = (lo < 1.0 - 1e-6) ? lo : 1.0 - 1e-6;
+    if (!ld_flag) {
+      int state;
+      if (mc_flag) {
+        const int cur = UCG_META_STATE(meta);
+        double mc_factor;
+        if (cur == 0) mc_factor = ucgp / (1.0 - ucgp);
+        else mc_factor = (1.0 - ucgp) / ucgp;
+        mc_factor = ((1.0 < mc_factor) ? 1.0 : mc_factor) * mc_rate;
+        const double mc_rand = (double) draws[i] * 5.9604644775390625e-08;
+        state = (mc_rand < mc_factor) ? 0 : 1;
+      } else {
+        state = (int) round(ucgp);
+      }
+      meta = (meta & 0xFFFF) | (state << 16);
+    }
+  }
+  A.ucgp[i] = ucgp;
+  if (!ld_flag) {
+    A.meta[i] = meta;
+    double4 x = A.pos4[i];
+    x.w = ucgp;
+    A.pos4[i] = x;
+  }
+}
+
+__global__ __launch_bounds__(FIX_BLOCK) void k_force_clear(const AtomsDev A)
+{
+  const int i = blockIdx.x * FIX_BLOCK + threadIdx.x;
+  if (i >= A.nlocal) return;
+  A.frc4[i] = make_double4(0.0, 0.0, 0.0, 0.0);
+  A.scores[i] = make_double2(0.0, 0.0);
+}
+
+template <int NV>
+__device__ __forceinline__ void block_sum_store(double (&v)[NV], double *red, double *out)
+{
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+  for (int c = 0; c < NV; c++) {
+    double s = v[c];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) red[wave * NV + c] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    double s = 0.0;
+    for (int w = 0; w < nw; w++) s += red[w * NV + threadIdx.x];
+    out[(size_t) blockIdx.x * NV + threadIdx.x] = s;
+  }
+}
+
+// partial sums: [0] lambda kinetic energy, [1] beads in state 1, [2] sum of lambda, [3] translational KE*2
+__global__ __launch_bounds__(FIX_BLOCK) void k_thermo_part(const AtomsDev A, const int groupbit, const double mvv2e,
+                                                          double *part)
+{
+  __shared__ double red[(FIX_BLOCK / 64) * 4];
+  const int i = blockIdx.x * FIX_BLOCK + threadIdx.x;
+  double v[4] = {0.0, 0.0, 0.0, 0.0};
+  if (i < A.nlocal) {
+    const int meta = A.meta[i];
+    v[1] = (double) UCG_META_STATE(meta);
+    v[2] = A.pos4[i].w;
+    if (A.mask[i] & groupbit) {
+      const double4 vel = A.vel4[i];
+      v[0] = 0.5 * A.ucgml[i] * vel.w * vel.w * mvv2e;
+      v[3] = A.mass[UCG_META_TYPE(meta)] * (vel.x * vel.x + vel.y * vel.y + vel.z * vel.z) * mvv2e;
+    }
+  }
+  block_sum_store<4>(v, red, part);
+}
+
+__global__ void k_thermo_final(const double *part, int nblocks, double *out)
+{
+  const int c = threadIdx.x;
+  if (c < 4) {
+    double s = 0.0;
+    for (int b = 0; b < nblocks; b++) s += part[(size_t) b * 4 + c];
+    out[c] = s;
+  }
+}
+
+inline int nblk(int n) { return (n + FIX_BLOCK - 1) / FIX_BLOCK; }
+
+}  // namespace
+
+hipError_t launch_nve_initial(const AtomsDev &A, double dtv, double dtf, int groupbit, hipStream_t st)
+{
+  if (A.nlocal == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_nve_initial, dim3(nblk(A.nlocal)), dim3(FIX_BLOCK), 0, st, A, dtv, dtf, groupbit);
+  return hipGetLastError();
+}
+
+hipError_t launch_nve_final(const AtomsDev &A, double dtf, int groupbit, hipStream_t st)
+{
+  if (A.nlocal == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_nve_final, dim3(nblk(A.nlocal)), dim3(FIX_BLOCK), 0, st, A, dtf, groupbit);
+  return hipGetLastError();
+}
+
+hipError_t launch_langevin(const AtomsDev &A, const LangevinDev &Lg, int groupbit, hipStream_t st)
+{
+  if (A.nlocal == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_langevin, dim3(nblk(A.nlocal)), dim3(FIX_BLOCK), 0, st, A, Lg, groupbit);
+  return hipGetLastError();
+}
+
+hipError_t launch_ucgstate(const AtomsDev &A, int ld_flag, int mc_flag, double mc_rate,
+                           const unsigned int *draws, hipStream_t st)
+{
+  if (A.nlocal == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_ucgstate, dim3(nblk(A.nlocal)), dim3(FIX_BLOCK), 0, st, A, ld_flag, mc_flag, mc_rate, draws);
+  return hipGetLastError();
+}
+
+hipError_t launch_force_clear(const AtomsDev &A, hipStream_t st)
+{
+  if (A.nlocal == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_force_clear, dim3(nblk(A.nlocal)), dim3(FIX_BLOCK), 0, st, A);
+  return hipGetLastError();
+}
+
+// out[0..3] = {lambda KE, state-1 count, sum lambda, 2*KE}; part must hold 4*nblk doubles
+hipError_t launch_lambda_ke(const AtomsDev &A, int groupbit, double mvv2e, double *part, double *out,
+                            hipStream_t st)
+{
+  const int nb = nblk(A.nlocal > 0 ? A.nlocal : 1);
+  hipLaunchKernelGGL(k_thermo_part, dim3(nb), dim3(FIX_BLOCK), 0, st, A, groupbit, mvv2e, part);
+  hipLaunchKernelGGL(k_thermo_final, dim3(1), dim3(64), 0, st, part, nb, out);
+  return hipGetLastError();
+}
+
+}  // namespace ucg

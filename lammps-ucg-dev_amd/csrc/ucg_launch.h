@@ -1,0 +1,51 @@
+// ucg_launch.h -- host-callable launchers of the HIP kernels (internal to libucg_hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "ucg_dev.h"
+
+#define UCG_MAX_ACTUAL 7
+#define UCG_MAX_TABLES 64
+
+namespace ucg {
+
+// ---- ucg_pair.hip
+int pair_gather_blocks(int nlocal);
+hipError_t launch_pair_gather(const PairDev &P, const AtomsDev &A, const ListDev &L, bool ev,
+                              double *evpart, double *evout, int *errflag, hipStream_t st);
+
+// ---- ucg_fix.hip
+struct LangevinDev {
+  const double *gfactor1, *gfactor2;  // [ntypes+1]
+  double tsqrt;
+  const unsigned int *draws;  // 24-bit RanMars integers, one per owned bead
+};
+hipError_t launch_nve_initial(const AtomsDev &A, double dtv, double dtf, int groupbit, hipStream_t st);
+hipError_t launch_nve_final(const AtomsDev &A, double dtf, int groupbit, hipStream_t st);
+hipError_t launch_langevin(const AtomsDev &A, const LangevinDev &Lg, int groupbit, hipStream_t st);
+hipError_t launch_lambda_ke(const AtomsDev &A, int groupbit, double mvv2e, double *part, double *out,
+                            hipStream_t st);
+hipError_t launch_ucgstate(const AtomsDev &A, int ld_flag, int mc_flag, double mc_rate,
+                           const unsigned int *draws, hipStream_t st);
+hipError_t launch_force_clear(const AtomsDev &A, hipStream_t st);
+hipError_t launch_state_count(const AtomsDev &A, double *part, double *out, hipStream_t st);
+
+// ---- ucg_ranmars.hip : exact block-parallel RANMAR
+struct RanMarsDev {
+  // two history buffers (ping-pong), 97 lag values each, oldest first, 24-bit integers
+  unsigned int *hist[2];
+  int cur;
+  long long count;           // uniform() calls made so far, constructor warm-up included
+  const unsigned int *jump;  // [nchunks_max][97] coefficients of z^(p*CHUNK) mod P(z)
+  int nchunks_max;
+};
+constexpr int RANMARS_CHUNK = 4096;
+// host: RANMAR seeding (LAMMPS convention) -> 97 lag values oldest first after the warm-up draw
+void ranmars_seed_host(int seed, unsigned int *hist97, long long *count);
+// host: jump polynomials z^(p*CHUNK) mod (z^97 + z^64 - 1) over Z/2^24, p = 0..nchunks-1
+void ranmars_jump_host(int nchunks, unsigned int *out);
+// n consecutive draws -> out[0..n) as 24-bit integers (uniform = out * 2^-24); advances R
+hipError_t launch_ranmars(RanMarsDev &R, int n, unsigned int *out, hipStream_t st);
+
+}  // namespace ucg

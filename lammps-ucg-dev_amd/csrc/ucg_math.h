@@ -20,13 +20,13 @@
 
 #include <stdint.h>
 
-#if defined(__HIPCC__)
-#define UCG_HD __host__ __device__ __forceinline__
+#if defined(__HIP__)
+#define UCG_HD __host__ __device__ inline __attribute__((always_inline))
 #else
 #define UCG_HD static inline
 #endif
 
-#if defined(__cplusplus) && defined(__HIPCC__)
+#if defined(__cplusplus) && defined(__HIP__)
 #define UCG_BITS_D2U(d) ((uint64_t)__builtin_bit_cast(unsigned long long, (d)))
 #define UCG_BITS_U2D(u) (__builtin_bit_cast(double, (unsigned long long)(u)))
 #else

@@ -1,0 +1,673 @@
+// ucg_neigh.hip -- what sits either side of the pair kernel in a resident run:
+// periodic wrap, bead sorting, periodic-image ghosts, binning, the full neighbour list,
+// the per-step halo refresh, the re-neighbour decision and the Verlet step loop.
+//
+// None of this is in the reference tree: it is upstream LAMMPS (Domain::pbc, AtomSort,
+// CommBrick::borders/forward_comm, NBin/NPair, Neighbor::decide, Verlet::setup/run).
+// The step ORDER follows upstream Verlet as summarised in SURVEY.md section 3.1; the data
+// management follows the "ucg-rebuild-v1" specification, which the CPU
+// oracle implements independently so that whole trajectories can be compared bit for bit:
+//   (1) wrap owned beads into the box; (2) bins of ~cutneigh/2 over the box extended by
+//   cutneigh; (3) sort owned beads by (bin, tag); (4) ghosts = periodic images that fall in
+//   the extended box, sorted by (bin, tag, shift code); (5) full-list rows in stencil order
+//   (dz, dy, dx ascending), owned beads of a bin before its ghosts, kept when
+//   rsq < cutneigh^2, bit 29 = (tag_row <= tag_neighbour).
+// Everything is deterministic: unique sort keys, no order-dependent atomics in outputs.
+#include <hipcub/hipcub.hpp>
+
+#include <cmath>
+#include <cstring>
+
+#include "../../include/ucg_hip.h"
+#include "ucg_ctx.h"
+
+namespace ucg {
+
+struct Domain {
+  double boxlo[3], boxhi[3], prd[3];
+  double cutforce = 0, skin = 0, cutneigh = 0;
+  int every = 1, delay = 0, check = 1;
+  int nbin[3] = {1, 1, 1}, sten[3] = {0, 0, 0}, nbins = 1;
+  double bboxlo[3], bboxhi[3], binsize[3], bininv[3];
+  int ago = 0;
+  DevBuf<int> bin_of, cell_o0, cell_o1, cell_g0, cell_g1, ghost_src, ghost_code, counter, rowcount;
+  DevBuf<double4> xhold, tmp4;
+  DevBuf<unsigned long long> keys_in, keys_out;
+  DevBuf<int> vals_in, vals_out, tmpi, cand_src, cand_code;
+  DevBuf<double> tmpd;
+  DevBuf<char> cub_tmp;
+};
+
+struct DomainDev {
+  double boxlo[3], boxhi[3], prd[3];
+  double bboxlo[3], bboxhi[3], bininv[3];
+  int nbin[3], sten[3];
+  double cutneighsq, triggersq;
+};
+
+void domain_destroy(ucg_ctx *ctx)
+{
+  delete ctx->dom;
+  ctx->dom = nullptr;
+}
+
+namespace {
+
+constexpr int NB = 256;
+inline int nblk(long long n) { return (int) ((n + NB - 1) / NB); }
+
+DomainDev make_dev(const Domain &D)
+{
+  DomainDev d;
+  for (int k = 0; k < 3; k++) {
+    d.boxlo[k] = D.boxlo[k];
+    d.boxhi[k] = D.boxhi[k];
+    d.prd[k] = D.prd[k];
+    d.bboxlo[k] = D.bboxlo[k];
+    d.bboxhi[k] = D.bboxhi[k];
+    d.bininv[k] = D.bininv[k];
+    d.nbin[k] = D.nbin[k];
+    d.sten[k] = D.sten[k];
+  }
+  d.cutneighsq = D.cutneigh * D.cutneigh;
+  d.triggersq = 0.25 * D.skin * D.skin;
+  return d;
+}
+
+__device__ __forceinline__ int coord2bin(const DomainDev &D, double x, double y, double z)
+{
+  int bx = (int) ((x - D.bboxlo[0]) * D.bininv[0]);
+  int by = (int) ((y - D.bboxlo[1]) * D.bininv[1]);
+  int bz = (int) ((z - D.bboxlo[2]) * D.bininv[2]);
+  bx = bx < 0 ? 0 : (bx > D.nbin[0] - 1 ? D.nbin[0] - 1 : bx);
+  by = by < 0 ? 0 : (by > D.nbin[1] - 1 ? D.nbin[1] - 1 : by);
+  bz = bz < 0 ? 0 : (bz > D.nbin[2] - 1 ? D.nbin[2] - 1 : bz);
+  return (bz * D.nbin[1] + by) * D.nbin[0] + bx;
+}
+
+__device__ __forceinline__ double wrap1(double x, double lo, double hi, double prd)
+{
+  // Domain::pbc(), orthogonal periodic
+  if (x < lo) x += prd;
+  if (x >= hi) {
+    x -= prd;
+    x = (x > lo) ? x : lo;
+  }
+  return x;
+}
+
+__global__ __launch_bounds__(NB) void k_wrap_and_key(const DomainDev D, int n, double4 *pos4, const int *tag,
+                                                    unsigned long long *keys, int *vals)
+{
+  const int i = blockIdx.x * NB + threadIdx.x;
+  if (i >= n) return;
+  double4 p = pos4[i];
+  p.x = wrap1(p.x, D.boxlo[0], D.boxhi[0], D.prd[0]);
+  p.y = wrap1(p.y, D.boxlo[1], D.boxhi[1], D.prd[1]);
+  p.z = wrap1(p.z, D.boxlo[2], D.boxhi[2], D.prd[2]);
+  pos4[i] = p;
+  const unsigned long long b = (unsigned long long) coord2bin(D, p.x, p.y, p.z);
+  keys[i] = (b << 37) | ((unsigned long long) (unsigned int) tag[i] << 5);
+  vals[i] = i;
+}
+
+template <typename T>
+__global__ __launch_bounds__(NB) void k_gather(int n, const int *perm, const T *src, T *dst)
+{
+  const int i = blockIdx.x * NB + threadIdx.x;
+  if (i < n) dst[i] = src[perm[i]];
+}
+
+__global__ __launch_bounds__(NB) void k_bins_from_keys(int n, const unsigned long long *keys, int *bin_of)
+{
+  const int i = blockIdx.x * NB + threadIdx.x;
+  if (i < n) bin_of[i] = (int) (keys[i] >> 37);
+}
+
+// periodic images of owned beads that fall inside the extended box; FILL=false counts only
+template <bool FILL>
+__global__ __launch_bounds__(NB) void k_ghost_candidates(const DomainDev D, int n, const double4 *pos4, const int *tag,
+                                                        int *counter, unsigned long long *keys, int *vals,
+                                                        int *cand_src, int *cand_code)
+{
+  const int i = blockIdx.x * NB + threadIdx.x;
+  if (i >= n) return;
+  const double4 p = pos4[i];
+  for (int sz = -1; sz <= 1; sz++) {
+    const double zs = p.z + sz * D.prd[2];
+    if (zs < D.bboxlo[2] || zs >= D.bboxhi[2]) continue;
+    for (int sy = -1; sy <= 1; sy++) {
+      const double ys = p.y + sy * D.prd[1];
+      if (ys < D.bboxlo[1] || ys >= D.bboxhi[1]) continue;
+      for (int sx = -1; sx <= 1; sx++) {
+        if (sx == 0 && sy == 0 && sz == 0) continue;
+        const double xs = p.x + sx * D.prd[0];
+        if (xs < D.bboxlo[0] || xs >= D.bboxhi[0]) continue;
+        const int slot = atomicAdd(counter, 1);
+        if (FILL) {
+          const int code = (sz + 1) * 9 + (sy + 1) * 3 + (sx + 1);
+          const unsigned long long b = (unsigned long long) coord2bin(D, xs, ys, zs);
+          keys[slot] = (b << 37) | ((unsigned long long) (unsigned int) tag[i] << 5) | (unsigned long long) code;
+          vals[slot] = slot;
+          cand_src[slot] = i;
+          cand_code[slot] = code;
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(NB) void k_ghost_finalize(int ng, int nlocal, const int *order, const unsigned long long *keys,
+                                                      const int *cand_src, const int *cand_code, int *ghost_src,
+                                                      int *ghost_code, int *bin_of, int *tag, int *meta)
+{
+  const int g = blockIdx.x * NB + threadIdx.x;
+  if (g >= ng) return;
+  const int c = order[g];
+  const int src = cand_src[c];
+  ghost_src[g] = src;
+  ghost_code[g] = cand_code[c];
+  bin_of[nlocal + g] = (int) (keys[g] >> 37);
+  tag[nlocal + g] = tag[src];
+  meta[nlocal + g] = meta[src];
+}
+
+// forward communication owner -> periodic image: fields_comm of UCG/atom_vec_ucg.cpp:71
+// (x + shift, ucgstate, ucgl, ucgp)
+__global__ __launch_bounds__(NB) void k_halo_forward(const DomainDev D, int ng, int nlocal, const int *ghost_src,
+                                                    const int *ghost_code, double4 *pos4, int *meta, double *ucgp)
+{
+  const int g = blockIdx.x * NB + threadIdx.x;
+  if (g >= ng) return;
+  const int src = ghost_src[g], code = ghost_code[g];
+  const int sx = code % 3 - 1, sy = (code / 3) % 3 - 1, sz = code / 9 - 1;
+  double4 p = pos4[src];
+  p.x = p.x + sx * D.prd[0];
+  p.y = p.y + sy * D.prd[1];
+  p.z = p.z + sz * D.prd[2];
+  pos4[nlocal + g] = p;
+  meta[nlocal + g] = meta[src];
+  ucgp[nlocal + g] = ucgp[src];
+}
+
+__global__ __launch_bounds__(NB) void k_cell_ranges(int n, int offset, const int *bin_of, int *cell0, int *cell1)
+{
+  const int i = blockIdx.x * NB + threadIdx.x;
+  if (i >= n) return;
+  const int b = bin_of[offset + i];
+  if (i == 0 || bin_of[offset + i - 1] != b) cell0[b] = offset + i;
+  if (i == n - 1 || bin_of[offset + i + 1] != b) cell1[b] = offset + i + 1;
+}
+
+// full-list rows; FILL=false only counts
+template <bool FILL>
+__global__ __launch_bounds__(NB) void k_build_rows(const DomainDev D, int nlocal, const double4 *pos4, const int *tag,
+                                                  const int *bin_of, const int *cell_o0, const int *cell_o1,
+                                                  const int *cell_g0, const int *cell_g1, int *rowcount, int *neigh,
+                                                  int pitch)
+{
+  const int k = blockIdx.x * NB + threadIdx.x;
+  if (k >= nlocal) return;
+  const double4 pk = pos4[k];
+  const int tk = tag[k];
+  const int b = bin_of[k];
+  const int bx = b % D.nbin[0], by = (b / D.nbin[0]) % D.nbin[1], bz = b / (D.nbin[0] * D.nbin[1]);
+  int cnt = 0;
+  for (int dz = -D.sten[2]; dz <= D.sten[2]; dz++) {
+    const int cz = bz + dz;
+    if (cz < 0 || cz >= D.nbin[2]) continue;
+    for (int dy = -D.sten[1]; dy <= D.sten[1]; dy++) {
+      const int cy = by + dy;
+      if (cy < 0 || cy >= D.nbin[1]) continue;
+      for (int dx = -D.sten[0]; dx <= D.sten[0]; dx++) {
+        const int cx = bx + dx;
+        if (cx < 0 || cx >= D.nbin[0]) continue;
+        const int c = (cz * D.nbin[1] + cy) * D.nbin[0] + cx;
+        for (int cls = 0; cls < 2; cls++) {
+          const int m0 = cls ? cell_g0[c] : cell_o0[c];
+          const int m1 = cls ? cell_g1[c] : cell_o1[c];
+          for (int m = m0; m < m1; m++) {
+            if (m == k) continue;
+            const double4 pm = pos4[m];
+            const double delx = pk.x - pm.x;
+            const double dely = pk.y - pm.y;
+            const double delz = pk.z - pm.z;
+            const double rsq = delx * delx + dely * dely + delz * delz;
+            if (rsq < D.cutneighsq) {
+              if (FILL) {
+                const int orient = (tk <= tag[m]) ? 1 : 0;
+                neigh[(size_t) cnt * pitch + k] = m | (orient << UCG_ORIENT_BIT);
+              }
+              cnt++;
+            }
+          }
+        }
+      }
+    }
+  }
+  if (!FILL) rowcount[k] = cnt;
+}
+
+__global__ __launch_bounds__(NB) void k_store_xhold(int n, const double4 *pos4, double4 *xhold)
+{
+  const int i = blockIdx.x * NB + threadIdx.x;
+  if (i < n) xhold[i] = pos4[i];
+}
+
+__global__ __launch_bounds__(NB) void k_check_distance(const DomainDev D, int n, const double4 *pos4, const double4 *xhold,
+                                                      int *flag)
+{
+  // Neighbor::check_distance: any bead moved more than skin/2 since the last build
+  const int i = blockIdx.x * NB + threadIdx.x;
+  if (i >= n) return;
+  const double4 p = pos4[i], h = xhold[i];
+  const double delx = p.x - h.x, dely = p.y - h.y, delz = p.z - h.z;
+  const double rsq = delx * delx + dely * dely + delz * delz;
+  if (rsq > D.triggersq) atomicOr(flag, 1);
+}
+
+void setup_bins(Domain &D)
+{
+  // identical host arithmetic to the specification (oracle/orc_md.c: orc_sim_setup_bins)
+  const double target = 0.5 * D.cutneigh;
+  D.nbins = 1;
+  for (int d = 0; d < 3; d++) {
+    D.bboxlo[d] = D.boxlo[d] - D.cutneigh;
+    D.bboxhi[d] = D.boxhi[d] + D.cutneigh;
+    const double ext = (D.boxhi[d] + D.cutneigh) - D.bboxlo[d];
+    int nb = (int) (ext / target);
+    if (nb < 1) nb = 1;
+    D.nbin[d] = nb;
+    D.binsize[d] = ext / nb;
+    D.bininv[d] = 1.0 / D.binsize[d];
+    int sx = (int) (D.cutneigh * D.bininv[d]);
+    if (sx * D.binsize[d] < D.cutneigh) sx++;
+    D.sten[d] = sx;
+    D.nbins *= nb;
+  }
+}
+
+void sort_pairs(ucg_ctx *ctx, Domain &D, int n)
+{
+  size_t bytes = 0;
+  UCG_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, D.keys_in.get(), D.keys_out.get(), D.vals_in.get(),
+                                             D.vals_out.get(), n, 0, 64, ctx->stream));
+  D.cub_tmp.reserve(bytes + 16);
+  UCG_HIP(hipcub::DeviceRadixSort::SortPairs(D.cub_tmp.get(), bytes, D.keys_in.get(), D.keys_out.get(), D.vals_in.get(),
+                                             D.vals_out.get(), n, 0, 64, ctx->stream));
+}
+
+template <typename T>
+void permute(ucg_ctx *ctx, int n, const int *perm, DevBuf<T> &arr, DevBuf<T> &tmp)
+{
+  tmp.reserve((size_t) n);
+  hipLaunchKernelGGL(k_gather<T>, dim3(nblk(n)), dim3(NB), 0, ctx->stream, n, perm, arr.get(), tmp.get());
+  UCG_HIP(hipMemcpyAsync(arr.get(), tmp.get(), (size_t) n * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
+}
+
+void rebuild(ucg_ctx *ctx)
+{
+  Domain &D = *ctx->dom;
+  hipStream_t st = ctx->stream;
+  const int n = ctx->nlocal;
+  if (n <= 0) throw InputError{"ucg_neigh_rebuild: no beads uploaded"};
+  for (int d = 0; d < 3; d++)
+    if (D.prd[d] < 2.0 * D.cutneigh * 0.5)
+      throw InputError{"periodic box shorter than the ghost cutoff: more than one image layer would be needed"};
+  setup_bins(D);
+  if ((long long) D.nbin[0] * D.nbin[1] * D.nbin[2] >= (1LL << 27)) throw InputError{"too many bins for the sort key"};
+  const DomainDev dd = make_dev(D);
+
+  // (1)+(3) wrap, key, sort owned beads by (bin, tag)
+  D.keys_in.reserve((size_t) n);
+  D.keys_out.reserve((size_t) n);
+  D.vals_in.reserve((size_t) n);
+  D.vals_out.reserve((size_t) n);
+  hipLaunchKernelGGL(k_wrap_and_key, dim3(nblk(n)), dim3(NB), 0, st, dd, n, ctx->pos4.get(), ctx->tag.get(),
+                     D.keys_in.get(), D.vals_in.get());
+  sort_pairs(ctx, D, n);
+  const int *perm = D.vals_out.get();
+  permute(ctx, n, perm, ctx->pos4, D.tmp4);
+  permute(ctx, n, perm, ctx->vel4, D.tmp4);
+  permute(ctx, n, perm, ctx->meta, D.tmpi);
+  permute(ctx, n, perm, ctx->tag, D.tmpi);
+  permute(ctx, n, perm, ctx->mask, D.tmpi);
+  permute(ctx, n, perm, ctx->num_ucgstates, D.tmpi);
+  permute(ctx, n, perm, ctx->ucgml, D.tmpd);
+  permute(ctx, n, perm, ctx->ucgp, D.tmpd);
+  D.bin_of.reserve((size_t) n);
+  hipLaunchKernelGGL(k_bins_from_keys, dim3(nblk(n)), dim3(NB), 0, st, n, D.keys_out.get(), D.bin_of.get());
+
+  // (4) ghosts: count, fill, sort by (bin, tag, code)
+  D.counter.reserve(4);
+  UCG_HIP(hipMemsetAsync(D.counter.get(), 0, sizeof(int), st));
+  hipLaunchKernelGGL(k_ghost_candidates<false>, dim3(nblk(n)), dim3(NB), 0, st, dd, n, ctx->pos4.get(), ctx->tag.get(),
+                     D.counter.get(), nullptr, nullptr, nullptr, nullptr);
+  int ng = 0;
+  UCG_HIP(hipMemcpyAsync(&ng, D.counter.get(), sizeof(int), hipMemcpyDeviceToHost, st));
+  UCG_HIP(hipStreamSynchronize(st));
+  const size_t nall = (size_t) n + (size_t) ng;
+  if (nall >= (size_t) UCG_NEIGHMASK) throw InputError{"too many beads + ghosts for 29-bit neighbour indices"};
+  ctx->pos4.reserve(nall, true, st);
+  ctx->meta.reserve(nall, true, st);
+  ctx->tag.reserve(nall, true, st);
+  ctx->ucgp.reserve(nall, true, st);
+  D.bin_of.reserve(nall, true, st);
+  D.ghost_src.reserve((size_t) ng + 1);
+  D.ghost_code.reserve((size_t) ng + 1);
+  if (ng > 0) {
+    D.keys_in.reserve((size_t) ng);
+    D.keys_out.reserve((size_t) ng);
+    D.vals_in.reserve((size_t) ng);
+    D.vals_out.reserve((size_t) ng);
+    D.cand_src.reserve((size_t) ng);
+    D.cand_code.reserve((size_t) ng);
+    UCG_HIP(hipMemsetAsync(D.counter.get(), 0, sizeof(int), st));
+    hipLaunchKernelGGL(k_ghost_candidates<true>, dim3(nblk(n)), dim3(NB), 0, st, dd, n, ctx->pos4.get(), ctx->tag.get(),
+                       D.counter.get(), D.keys_in.get(), D.vals_in.get(), D.cand_src.get(), D.cand_code.get());
+    sort_pairs(ctx, D, ng);
+    hipLaunchKernelGGL(k_ghost_finalize, dim3(nblk(ng)), dim3(NB), 0, st, ng, n, D.vals_out.get(), D.keys_out.get(),
+                       D.cand_src.get(), D.cand_code.get(), D.ghost_src.get(), D.ghost_code.get(), D.bin_of.get(),
+                       ctx->tag.get(), ctx->meta.get());
+    hipLaunchKernelGGL(k_halo_forward, dim3(nblk(ng)), dim3(NB), 0, st, dd, ng, n, D.ghost_src.get(), D.ghost_code.get(),
+                       ctx->pos4.get(), ctx->meta.get(), ctx->ucgp.get());
+  }
+  ctx->nghost = ng;
+
+  // (2) bin ranges of both classes
+  const size_t nb1 = (size_t) D.nbins + 1;
+  D.cell_o0.reserve(nb1);
+  D.cell_o1.reserve(nb1);
+  D.cell_g0.reserve(nb1);
+  D.cell_g1.reserve(nb1);
+  UCG_HIP(hipMemsetAsync(D.cell_o0.get(), 0, nb1 * sizeof(int), st));
+  UCG_HIP(hipMemsetAsync(D.cell_o1.get(), 0, nb1 * sizeof(int), st));
+  UCG_HIP(hipMemsetAsync(D.cell_g0.get(), 0, nb1 * sizeof(int), st));
+  UCG_HIP(hipMemsetAsync(D.cell_g1.get(), 0, nb1 * sizeof(int), st));
+  hipLaunchKernelGGL(k_cell_ranges, dim3(nblk(n)), dim3(NB), 0, st, n, 0, D.bin_of.get(), D.cell_o0.get(), D.cell_o1.get());
+  if (ng > 0)
+    hipLaunchKernelGGL(k_cell_ranges, dim3(nblk(ng)), dim3(NB), 0, st, ng, n, D.bin_of.get(), D.cell_g0.get(),
+                       D.cell_g1.get());
+
+  // (5) rows: count, size, fill
+  const int pitch = ((n + 63) / 64) * 64;
+  ctx->numneigh.reserve((size_t) pitch);
+  hipLaunchKernelGGL(k_build_rows<false>, dim3(nblk(n)), dim3(NB), 0, st, dd, n, ctx->pos4.get(), ctx->tag.get(),
+                     D.bin_of.get(), D.cell_o0.get(), D.cell_o1.get(), D.cell_g0.get(), D.cell_g1.get(),
+                     ctx->numneigh.get(), nullptr, pitch);
+  // max and total row length (hipcub reductions into counter[0..1] would need two temp buffers; rows are
+  // rebuilt rarely, so a small host pass over the counts is acceptable here)
+  std::vector<int> counts((size_t) n);
+  UCG_HIP(hipMemcpyAsync(counts.data(), ctx->numneigh.get(), (size_t) n * sizeof(int), hipMemcpyDeviceToHost, st));
+  UCG_HIP(hipStreamSynchronize(st));
+  int maxrow = 0;
+  long long total = 0;
+  for (int i = 0; i < n; i++) {
+    if (counts[(size_t) i] > maxrow) maxrow = counts[(size_t) i];
+    total += counts[(size_t) i];
+  }
+  ctx->neigh.reserve((size_t) pitch * (size_t) (maxrow > 0 ? maxrow : 1));
+  hipLaunchKernelGGL(k_build_rows<true>, dim3(nblk(n)), dim3(NB), 0, st, dd, n, ctx->pos4.get(), ctx->tag.get(),
+                     D.bin_of.get(), D.cell_o0.get(), D.cell_o1.get(), D.cell_g0.get(), D.cell_g1.get(), nullptr,
+                     ctx->neigh.get(), pitch);
+  ctx->list_inum = n;
+  ctx->list_pitch = pitch;
+  ctx->list_maxrow = maxrow;
+  ctx->list_entries = total;
+
+  D.xhold.reserve((size_t) n);
+  hipLaunchKernelGGL(k_store_xhold, dim3(nblk(n)), dim3(NB), 0, st, n, ctx->pos4.get(), D.xhold.get());
+  UCG_HIP(hipGetLastError());
+  // per-bead outputs follow the beads' new order only after the next force evaluation
+  ctx->frc4.reserve((size_t) n);
+  ctx->scores.reserve((size_t) n);
+  D.ago = 0;
+  ctx->nrebuild++;
+}
+
+void halo_forward(ucg_ctx *ctx)
+{
+  Domain &D = *ctx->dom;
+  if (ctx->nghost <= 0) return;
+  const DomainDev dd = make_dev(D);
+  hipLaunchKernelGGL(k_halo_forward, dim3(nblk(ctx->nghost)), dim3(NB), 0, ctx->stream, dd, ctx->nghost, ctx->nlocal,
+                     D.ghost_src.get(), D.ghost_code.get(), ctx->pos4.get(), ctx->meta.get(), ctx->ucgp.get());
+  UCG_HIP(hipGetLastError());
+}
+
+bool decide(ucg_ctx *ctx)
+{
+  // upstream Neighbor::decide()
+  Domain &D = *ctx->dom;
+  D.ago++;
+  if (D.ago >= D.delay && D.ago % D.every == 0) {
+    if (D.check == 0) return true;
+    const DomainDev dd = make_dev(D);
+    UCG_HIP(hipMemsetAsync(D.counter.get(), 0, sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(k_check_distance, dim3(nblk(ctx->nlocal)), dim3(NB), 0, ctx->stream, dd, ctx->nlocal,
+                       ctx->pos4.get(), D.xhold.get(), D.counter.get());
+    int flag = 0;
+    UCG_HIP(hipMemcpyAsync(&flag, D.counter.get(), sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    UCG_HIP(hipStreamSynchronize(ctx->stream));
+    return flag != 0;
+  }
+  return false;
+}
+
+template <typename F>
+int guarded(ucg_ctx *ctx, F &&fn)
+{
+  try {
+    return fn();
+  } catch (const InputError &e) {
+    ctx->err = e.msg;
+    return UCG_ERR_INPUT;
+  } catch (const HipFailure &e) {
+    ctx->err = std::string("HIP error: ") + hipGetErrorString(e.code) + " in " + e.what;
+    return UCG_ERR_HIP;
+  } catch (const std::exception &e) {
+    ctx->err = e.what();
+    return UCG_ERR_INVALID;
+  }
+}
+
+int need_domain(ucg_ctx *ctx)
+{
+  if (!ctx->dom) {
+    ctx->err = "ucg_domain_set has not been called";
+    return UCG_ERR_INVALID;
+  }
+  return UCG_OK;
+}
+
+// one force evaluation + post_force fixes, in fix-definition order (thermostat before ucgstate,
+// UCG/fix_ucgstate.cpp:143-154)
+int forces_and_post_force(ucg_ctx *ctx, int ev)
+{
+  int rc = ucg_pair_compute(ctx->md_pair, ev, ev, nullptr, nullptr);
+  if (rc) return rc;
+  if (ctx->md_lang) {
+    rc = ucg_fix_langevin_post_force(ctx, ctx->groupbit, ctx->ntimestep, ctx->beginstep, ctx->endstep);
+    if (rc) return rc;
+  }
+  if (ctx->md_ucgst) {
+    rc = ucg_fix_ucgstate_post_force(ctx);
+    if (rc) return rc;
+  }
+  return UCG_OK;
+}
+
+}  // namespace
+}  // namespace ucg
+
+using namespace ucg;
+
+extern "C" {
+
+int ucg_domain_set(ucg_ctx *ctx, const double *boxlo, const double *boxhi, double cutforce, double skin, int every,
+                   int delay, int check)
+{
+  if (!ctx || !boxlo || !boxhi) return UCG_ERR_INVALID;
+  return guarded(ctx, [&]() -> int {
+    if (!(cutforce > 0.0) || skin < 0.0 || every < 1 || delay < 0) throw InputError{"Illegal neighbor / neigh_modify settings"};
+    if (!ctx->dom) ctx->dom = new Domain();
+    Domain &D = *ctx->dom;
+    for (int d = 0; d < 3; d++) {
+      if (!(boxhi[d] > boxlo[d])) throw InputError{"Box bounds are invalid"};
+      D.boxlo[d] = boxlo[d];
+      D.boxhi[d] = boxhi[d];
+      D.prd[d] = boxhi[d] - boxlo[d];
+    }
+    D.cutforce = cutforce;
+    D.skin = skin;
+    D.cutneigh = cutforce + skin;
+    D.every = every;
+    D.delay = delay;
+    D.check = check;
+    D.counter.reserve(4);
+    return UCG_OK;
+  });
+}
+
+int ucg_neigh_rebuild(ucg_ctx *ctx)
+{
+  if (!ctx) return UCG_ERR_INVALID;
+  if (int rc = need_domain(ctx)) return rc;
+  return guarded(ctx, [&]() -> int {
+    rebuild(ctx);
+    return UCG_OK;
+  });
+}
+
+int ucg_halo_forward(ucg_ctx *ctx)
+{
+  if (!ctx) return UCG_ERR_INVALID;
+  if (int rc = need_domain(ctx)) return rc;
+  return guarded(ctx, [&]() -> int {
+    halo_forward(ctx);
+    return UCG_OK;
+  });
+}
+
+int ucg_ghosts_download(ucg_ctx *ctx, int *src, int *shift3, int cap)
+{
+  if (!ctx) return UCG_ERR_INVALID;
+  if (int rc = need_domain(ctx)) return rc;
+  return guarded(ctx, [&]() -> int {
+    const int ng = ctx->nghost;
+    if (cap < ng) {
+      ctx->err = "ghost buffers too small";
+      return UCG_ERR_INVALID;
+    }
+    std::vector<int> s((size_t) ng), c((size_t) ng);
+    if (ng) {
+      UCG_HIP(hipMemcpyAsync(s.data(), ctx->dom->ghost_src.get(), (size_t) ng * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+      UCG_HIP(hipMemcpyAsync(c.data(), ctx->dom->ghost_code.get(), (size_t) ng * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+      UCG_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    for (int g = 0; g < ng; g++) {
+      if (src) src[g] = s[(size_t) g];
+      if (shift3) {
+        const int code = c[(size_t) g];
+        shift3[3 * g + 0] = code % 3 - 1;
+        shift3[3 * g + 1] = (code / 3) % 3 - 1;
+        shift3[3 * g + 2] = code / 9 - 1;
+      }
+    }
+    return UCG_OK;
+  });
+}
+
+int ucg_md_attach(ucg_ctx *ctx, ucg_pair *pair, int use_nve, int use_langevin, int use_ucgstate)
+{
+  if (!ctx || !pair || pair->ctx != ctx) return UCG_ERR_INVALID;
+  ctx->md_pair = pair;
+  ctx->md_nve = use_nve != 0;
+  ctx->md_lang = use_langevin != 0;
+  ctx->md_ucgst = use_ucgstate != 0;
+  if (ctx->md_lang && !ctx->lang.active) {
+    ctx->err = "ucg_md_attach: fix ucgld/langevin requested but not created";
+    return UCG_ERR_INVALID;
+  }
+  if (ctx->md_ucgst && !ctx->ucgst.active) {
+    ctx->err = "ucg_md_attach: fix ucgstate requested but not created";
+    return UCG_ERR_INVALID;
+  }
+  return UCG_OK;
+}
+
+int ucg_md_setup(ucg_ctx *ctx, long long nsteps_planned)
+{
+  if (!ctx || !ctx->md_pair) return UCG_ERR_INVALID;
+  if (int rc = need_domain(ctx)) return rc;
+  // Verlet::setup(): lists, forces, then each fix's setup(); Fix_UCGLD_Langevin::setup and
+  // FixUCGState::setup both call post_force (UCG/fix_ucgld_langevin.cpp:187-197, UCG/fix_ucgstate.cpp:142-171)
+  ctx->beginstep = ctx->ntimestep;
+  ctx->endstep = ctx->ntimestep + nsteps_planned;
+  int rc = guarded(ctx, [&]() -> int {
+    if (ctx->md_lang && !ctx->lang.inited) {
+      // Fix_UCGLD_Langevin::init(): reads atom->ucgml[1..ntypes] of the CURRENT bead order (App. B #5)
+      std::vector<double> ml((size_t) ctx->ntypes + 1, 0.0);
+      const int cnt = ctx->ntypes + 1 <= ctx->nlocal ? ctx->ntypes + 1 : ctx->nlocal;
+      UCG_HIP(hipMemcpyAsync(ml.data(), ctx->ucgml.get(), (size_t) cnt * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+      UCG_HIP(hipStreamSynchronize(ctx->stream));
+      if (int r = ucg_fix_langevin_init_from_ucgml(ctx, ctx->ntypes, ml.data())) return r;
+    }
+    rebuild(ctx);
+    return UCG_OK;
+  });
+  if (rc) return rc;
+  return forces_and_post_force(ctx, 1);
+}
+
+int ucg_md_run(ucg_ctx *ctx, long long nsteps, int thermo_every)
+{
+  if (!ctx || !ctx->md_pair) return UCG_ERR_INVALID;
+  if (int rc = need_domain(ctx)) return rc;
+  for (long long s = 0; s < nsteps; s++) {
+    ctx->ntimestep++;
+    const int ev = (thermo_every > 0 && (ctx->ntimestep % thermo_every == 0)) ? 1 : 0;
+    int rc;
+    if (ctx->md_nve && (rc = ucg_fix_nve_initial(ctx, ctx->groupbit))) return rc;
+    rc = guarded(ctx, [&]() -> int {
+      if (decide(ctx)) rebuild(ctx);
+      else halo_forward(ctx);
+      return UCG_OK;
+    });
+    if (rc) return rc;
+    if ((rc = forces_and_post_force(ctx, ev))) return rc;
+    if (ctx->md_nve && (rc = ucg_fix_nve_final(ctx, ctx->groupbit))) return rc;
+    // end_of_step: the lambda temperature is a diagnostic (compute_scalar); evaluated on thermo steps
+    if (ev && ctx->md_lang && (rc = ucg_fix_langevin_end_of_step(ctx, ctx->groupbit, nullptr))) return rc;
+  }
+  return UCG_OK;
+}
+
+int ucg_md_info(ucg_ctx *ctx, long long *out)
+{
+  if (!ctx || !out) return UCG_ERR_INVALID;
+  for (int i = 0; i < 16; i++) out[i] = 0;
+  out[0] = ctx->ntimestep;
+  out[1] = ctx->nrebuild;
+  out[2] = ctx->nlocal;
+  out[3] = ctx->nghost;
+  out[4] = ctx->list_entries;
+  out[5] = ctx->pair_error_steps;
+  out[6] = ctx->list_maxrow;
+  out[7] = ctx->list_pitch;
+  if (ctx->dom) {
+    out[8] = ctx->dom->nbin[0];
+    out[9] = ctx->dom->nbin[1];
+    out[10] = ctx->dom->nbin[2];
+  }
+  return UCG_OK;
+}
+
+int ucg_md_thermo(ucg_ctx *ctx, double *out9)
+{
+  if (!ctx || !out9) return UCG_ERR_INVALID;
+  for (int i = 0; i < 9; i++) out9[i] = ctx->thermo[i];
+  return UCG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,415 @@
+// ucg_pair.hip -- neighbour-loop kernels of table_ucgld and table_ucg_bethe (gfx950).
+//
+// What is computed: Scenario 4 of PairTable_UCGLD::compute
+// (UCG/pair_table_ucgld.cpp:424-533) and of PairTable_UCG_Bethe::compute
+// (UCG/pair_table_ucg_bethe.cpp:457-620), with the prologues :170-180 / :155-162.
+//
+// How: one lane per owned bead, gathering over that bead's row of a FULL,
+// row-transposed neighbour list; nothing is scattered, so there are no atomics
+// and the per-bead sums are formed in one fixed order (row order).  Each pair is
+// evaluated in the reference's (i,j) orientation -- bit 29 of the entry says
+// whether the row owner is "i" -- so the numbers added to a bead are exactly the
+// numbers the reference's half-list sweep adds to it; only the order of the
+// additions is the canonical one ("determinism contract").
+//
+// All tables are staged in LDS (<= 160 KB per CU) when they fit; one workgroup
+// of 1024 lanes per CU then owns the whole LDS and 4 waves per SIMD hide the
+// gather latency.  Tables that do not fit are read through L1/L2.
+//
+// Compiled with -ffp-contract=off: every product and sum below rounds exactly
+// where the reference's scalar x86-64 code rounds.
+#include "ucg_dev.h"
+#include "ucg_math.h"
+#include "ucg_launch.h"
+
+namespace ucg {
+
+namespace {
+
+constexpr int PAIR_BLOCK = 1024;
+
+struct Quad {
+  double u00, u01, u10, u11;
+  double f00, f01, f10, f11;
+};
+
+// one table lookup; the open-coded block UCG/pair_table_ucgld.cpp:436-482
+template <int TS, typename TabPtr>
+__device__ __forceinline__ void table_eval(TabPtr tab, const double4 par, const int tlm1,
+                                           const double rsq, double &fval, double &eval, int &err)
+{
+  if (rsq < par.x) err |= 1;
+  int it = static_cast<int>((rsq - par.x) * par.z);
+  if (it >= tlm1) {
+    err |= 2;
+    it = tlm1 - 1;
+  }
+  if (it < 0) it = 0;
+  if (TS == 0) {  // LOOKUP
+    const double4 k = tab[it];
+    eval = k.x;
+    fval = k.y;
+  } else if (TS == 1) {  // LINEAR  {e, de, f, df}
+    const double4 k = tab[it];
+    const double rsq_it = par.x + it * par.y;
+    const double fraction = (rsq - rsq_it) * par.z;
+    fval = k.z + fraction * k.w;
+    eval = k.x + fraction * k.y;
+  } else {  // SPLINE  {e, f, e2, f2}
+    const double4 k0 = tab[it];
+    const double4 k1 = tab[it + 1];
+    const double rsq_it = par.x + it * par.y;
+    const double b = (rsq - rsq_it) * par.z;
+    const double a = 1.0 - b;
+    const double a3 = a * a * a - a;
+    const double b3 = b * b * b - b;
+    fval = a * k0.y + b * k1.y + (a3 * k0.w + b3 * k1.w) * par.w;
+    eval = a * k0.x + b * k1.x + (a3 * k0.z + b3 * k1.z) * par.w;
+  }
+}
+
+// deterministic block sum of NV doubles per lane -> out[blockIdx.x*NV + c]
+template <int NV>
+__device__ __forceinline__ void block_sum_store(double (&v)[NV], double *red, double *out)
+{
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+  for (int c = 0; c < NV; c++) {
+    double s = v[c];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) red[wave * NV + c] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    double s = 0.0;
+    for (int w = 0; w < nw; w++) s += red[w * NV + threadIdx.x];
+    out[(size_t) blockIdx.x * NV + threadIdx.x] = s;
+  }
+}
+
+// XCD-aware chunk order: blocks b and b+8 share an XCD (observed round-robin), so give
+// each XCD one contiguous range of bead chunks; beads are bin-sorted, so a range is a
+// spatial slab whose neighbour gathers stay in that XCD's L2.  Speed only, never correctness.
+__device__ __forceinline__ int xcd_chunk(int b, int nb)
+{
+  const int per = nb >> 3;
+  if (per == 0 || b >= per * 8) return b;
+  return (b & 7) * per + (b >> 3);
+}
+
+template <int STYLE, int TS, bool EV, bool LDS_TAB>
+__global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, const AtomsDev A,
+                                                           const ListDev Lst, double *evpart,
+                                                           int *errflag)
+{
+  extern __shared__ double4 s_tab[];
+  __shared__ double s_red[(PAIR_BLOCK / 64) * 8];
+  // the small per-model arrays (bounded by UCG_MAX_ACTUAL / UCG_MAX_TABLES at upload time)
+  __shared__ double4 s_par[UCG_MAX_TABLES];
+  __shared__ int s_pairtab[(UCG_MAX_ACTUAL + 1) * (UCG_MAX_ACTUAL + 1) * 4];
+  __shared__ double s_cutsq[(UCG_MAX_ACTUAL + 1) * (UCG_MAX_ACTUAL + 1)];
+
+  const int ntabent = P.ntab * P.tablength;
+  {
+    const int na1sq = (P.n_actual + 1) * (P.n_actual + 1);
+    for (int t = threadIdx.x; t < P.ntab; t += blockDim.x) s_par[t] = P.tabpar[t];
+    for (int t = threadIdx.x; t < na1sq * 4; t += blockDim.x) s_pairtab[t] = P.pairtab[t];
+    for (int t = threadIdx.x; t < na1sq; t += blockDim.x) s_cutsq[t] = P.cutsq[t];
+    if (LDS_TAB)
+      for (int t = threadIdx.x; t < ntabent; t += blockDim.x) s_tab[t] = P.tab[t];
+    __syncthreads();
+  }
+
+  const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
+  const int k = chunk * PAIR_BLOCK + threadIdx.x;
+  const int nlocal = A.nlocal;
+  const int na1 = P.n_actual + 1;
+  const double kT = P.kT;
+  double ev[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int err = 0;
+
+  if (k < nlocal) {
+    const double4 pk = A.pos4[k];
+    const int mk = A.meta[k];
+    const int tk = UCG_META_TYPE(mk);
+    const double lk = pk.w;
+    const int n = Lst.numneigh[k];
+    const int *row = Lst.neigh + k;
+    const size_t pitch = (size_t) Lst.pitch;
+
+    double fx = 0.0, fy = 0.0, fz = 0.0, uf = 0.0, s0 = 0.0, s1 = 0.0;
+    const double mu0 = P.mu[tk * 2 + 0], mu1 = P.mu[tk * 2 + 1];
+    if (STYLE == 0) {
+      const double mui = mu1 - mu0;
+      uf -= mui;
+      s1 -= mui / kT;
+    } else {
+      s0 = -mu0 / kT;
+      s1 = -mu1 / kT;
+    }
+    // priors of k for the Bethe closure
+    double pk_as_i1 = 0.0, pk_as_j1 = 0.0, pk_as_i0 = 0.0, pk_as_j0 = 0.0;
+    bool k_first_chempot = false;
+    if (STYLE == 1) {
+      const double upk = A.ucgp[k];
+      const bool first = upk < -0.999;
+      if (first && P.prior_flag == 0) {  // CHEMICAL_POTENTIAL
+        pk_as_i0 = P.prior_type[tk * 2 + 0];
+        pk_as_i1 = P.prior_type[tk * 2 + 1];
+      } else {
+        pk_as_i1 = lk;
+        pk_as_i0 = 1.0 - lk;
+      }
+      if (first) {
+        if (P.prior_flag == 0) {
+          // as shipped the neighbour's first-call prior is looked up with the ROW owner's
+          // type (UCG/pair_table_ucg_bethe.cpp:229-232); resolved per pair below
+          k_first_chempot = true;
+        } else {
+          pk_as_j0 = 1.0 - lk;
+          pk_as_j1 = lk;
+        }
+      } else {
+        pk_as_j1 = upk;
+        pk_as_j0 = 1.0 - upk;
+      }
+    }
+
+    for (int e = 0; e < n; e++) {
+      const int ent = row[(size_t) e * pitch];
+      const int m = ent & 0x1FFFFFFF;
+      const bool k_is_i = (ent >> 29) & 1;
+      const int sb = (ent >> 30) & 3;
+      const double factor_lj = sb == 0 ? P.special_lj[0] : sb == 1 ? P.special_lj[1] : sb == 2 ? P.special_lj[2] : P.special_lj[3];
+      const double4 pm = A.pos4[m];
+      const int mm = A.meta[m];
+      const int tm = UCG_META_TYPE(mm);
+      const int sm = UCG_META_STATE(mm);
+      const double lm = pm.w;
+      const double dx = pk.x - pm.x;
+      const double dy = pk.y - pm.y;
+      const double dz = pk.z - pm.z;
+      const double rsq = dx * dx + dy * dy + dz * dz;
+      if (rsq < s_cutsq[tk * na1 + tm]) {
+        // own-frame quad: u[a][b] = table(F(tk,a), F(tm,b)); equals the reference's
+        // u[b][a] when k is the pair's "j" (tabindex is symmetric after init_one)
+        const int *pt = s_pairtab + (tk * na1 + tm) * 4;
+        Quad q;
+        {
+          const int t00 = pt[0], t01 = pt[1], t10 = pt[2], t11 = pt[3];
+          if (LDS_TAB) {
+            table_eval<TS>(s_tab + t00 * P.tablength, s_par[t00], P.tlm1, rsq, q.f00, q.u00, err);
+            table_eval<TS>(s_tab + t01 * P.tablength, s_par[t01], P.tlm1, rsq, q.f01, q.u01, err);
+            if (t10 == t01) {
+              q.f10 = q.f01;
+              q.u10 = q.u01;
+            } else {
+              table_eval<TS>(s_tab + t10 * P.tablength, s_par[t10], P.tlm1, rsq, q.f10, q.u10, err);
+            }
+            table_eval<TS>(s_tab + t11 * P.tablength, s_par[t11], P.tlm1, rsq, q.f11, q.u11, err);
+          } else {
+            table_eval<TS>(P.tab + t00 * P.tablength, s_par[t00], P.tlm1, rsq, q.f00, q.u00, err);
+            table_eval<TS>(P.tab + t01 * P.tablength, s_par[t01], P.tlm1, rsq, q.f01, q.u01, err);
+            if (t10 == t01) {
+              q.f10 = q.f01;
+              q.u10 = q.u01;
+            } else {
+              table_eval<TS>(P.tab + t10 * P.tablength, s_par[t10], P.tlm1, rsq, q.f10, q.u10, err);
+            }
+            table_eval<TS>(P.tab + t11 * P.tablength, s_par[t11], P.tlm1, rsq, q.f11, q.u11, err);
+          }
+          q.f00 = factor_lj * q.f00; q.u00 *= factor_lj;
+          q.f01 = factor_lj * q.f01; q.u01 *= factor_lj;
+          q.f10 = factor_lj * q.f10; q.u10 *= factor_lj;
+          q.f11 = factor_lj * q.f11; q.u11 *= factor_lj;
+        }
+
+        double evdwl, fpair;
+        if (STYLE == 0 || P.pseudo_flag == 0) {
+          // pseudo-likelihood scores (:492-502): S[k][a] -= u[a][state of the neighbour] / kT
+          s0 -= (sm ? q.u01 : q.u00) / kT;
+          s1 -= (sm ? q.u11 : q.u10) / kT;
+        }
+        if (STYLE == 0) {
+          // lambda-bilinear mix (:507-517).  In the reference's orientation the sum is
+          // ((t00 + t01) + t10) + t11; seen from the "j" bead the middle terms swap.
+          const double w00 = (1. - lk) * (1. - lm);
+          const double w11 = lk * lm;
+          const double wA = (1. - lk) * lm;  // weight of own-frame (0,1)
+          const double wB = (1. - lm) * lk;  // weight of own-frame (1,0)
+          const double eA = wA * q.u01, eB = wB * q.u10;
+          const double fA = wA * q.f01, fB = wB * q.f10;
+          if (k_is_i) {
+            fpair = w00 * q.f00 + fA + fB + w11 * q.f11;
+            if (EV) evdwl = w00 * q.u00 + eA + eB + w11 * q.u11;
+          } else {
+            fpair = w00 * q.f00 + fB + fA + w11 * q.f11;
+            if (EV) evdwl = w00 * q.u00 + eB + eA + w11 * q.u11;
+          }
+          uf -= lm * (q.u11 - q.u01) + (1. - lm) * (q.u10 - q.u00);
+        } else {
+          // Bethe closure in the reference's orientation (UCG/pair_table_ucg_bethe.cpp:544-604)
+          const double cu01 = k_is_i ? q.u01 : q.u10, cu10 = k_is_i ? q.u10 : q.u01;
+          const double cf01 = k_is_i ? q.f01 : q.f10, cf10 = k_is_i ? q.f10 : q.f01;
+          double pm_as_i1, pm_as_i0, pm_as_j1, pm_as_j0;
+          {
+            const double upm = A.ucgp[m];
+            const bool firstm = upm < -0.999;
+            if (firstm && P.prior_flag == 0) {
+              pm_as_i0 = P.prior_type[tm * 2 + 0];
+              pm_as_i1 = P.prior_type[tm * 2 + 1];
+            } else {
+              pm_as_i1 = lm;
+              pm_as_i0 = 1.0 - lm;
+            }
+            if (firstm) {
+              if (P.prior_flag == 0) {
+                pm_as_j0 = P.prior_type[tk * 2 + 0];  // row owner's type, as shipped
+                pm_as_j1 = P.prior_type[tk * 2 + 1];
+              } else {
+                pm_as_j0 = 1.0 - lm;
+                pm_as_j1 = lm;
+              }
+            } else {
+              pm_as_j1 = upm;
+              pm_as_j0 = 1.0 - upm;
+            }
+          }
+          double kj0 = pk_as_j0, kj1 = pk_as_j1;
+          if (k_first_chempot) {  // k is "j" on its first call with the chemical-potential prior
+            kj0 = P.prior_type[tm * 2 + 0];
+            kj1 = P.prior_type[tm * 2 + 1];
+          }
+          const double pi0 = k_is_i ? pk_as_i0 : pm_as_i0, pi1 = k_is_i ? pk_as_i1 : pm_as_i1;
+          const double pj0 = k_is_i ? pm_as_j0 : kj0, pj1 = k_is_i ? pm_as_j1 : kj1;
+
+          double Jij = q.u11 + q.u00 - cu01 - cu10;
+          if (Jij / kT < -709.0) Jij = -700.0 * kT;
+          const double bij = ucg_exp(-Jij / kT);
+          const double aij = ucg_expm1(-Jij / kT);
+          const double Qij = (pi1 + pj1) * aij + 1.;
+          double Dij = Qij * Qij - 4. * aij * bij * pi1 * pj1;
+          Dij = (Dij > 0.0) ? Dij : 0.0;
+          double pij11;
+          if (P.method_flag == 1) {
+            if (fabs(aij) < 1.0e-6) pij11 = pi1 * pj1;
+            else if (Qij < 0.0) pij11 = (Qij - sqrt(Dij)) / (2. * aij);
+            else pij11 = (2. * bij * pi1 * pj1) / (Qij + sqrt(Dij));
+          } else {
+            pij11 = pi1 * pj1;
+          }
+          const double pij00 = 1. + pij11 - pi1 - pj1;
+          const double pij10 = pi1 - pij11;
+          const double pij01 = pj1 - pij11;
+          if (P.pseudo_flag == 1) {
+            // full-SCE scores exactly as shipped (:583-601)
+            if (k_is_i) {
+              const double pj0i0 = pij00 / pi0, pj0i1 = pij01 / pi0, pj1i0 = pij10 / pi1, pj1i1 = pij11 / pi1;
+              s0 -= (pj0i0 * q.u00 + pj1i0 * cu01) / kT;
+              s1 -= (pj0i1 * cu10 + pj1i1 * q.u11) / kT;
+            } else {
+              const double pi0j0 = pij00 / pj0, pi0j1 = pij10 / pj0, pi1j0 = pij01 / pj1, pi1j1 = pij11 / pj1;
+              s0 -= (pi0j0 * q.u00 + pi0j1 * cu01) / kT;
+              s1 -= (pi1j0 * cu10 + pi1j1 * q.u11) / kT;
+            }
+          }
+          fpair = pij00 * q.f00 + pij01 * cf01 + pij10 * cf10 + pij11 * q.f11;
+          if (EV) evdwl = pij00 * q.u00 + pij01 * cu01 + pij10 * cu10 + pij11 * q.u11;
+        }
+        fx += dx * fpair;
+        fy += dy * fpair;
+        fz += dz * fpair;
+        if (EV) {
+          ev[0] += 0.5 * evdwl;
+          ev[1] += 0.5 * (dx * dx * fpair);
+          ev[2] += 0.5 * (dy * dy * fpair);
+          ev[3] += 0.5 * (dz * dz * fpair);
+          ev[4] += 0.5 * (dx * dy * fpair);
+          ev[5] += 0.5 * (dx * dz * fpair);
+          ev[6] += 0.5 * (dy * dz * fpair);
+        }
+      }
+    }
+    if (STYLE == 0) {
+      A.frc4[k] = make_double4(fx, fy, fz, uf);
+    } else {
+      // table_ucg_bethe never touches ucgforce: it stays at its cleared value
+      A.frc4[k] = make_double4(fx, fy, fz, 0.0);
+    }
+    A.scores[k] = make_double2(s0, s1);
+    A.num_ucgstates[k] = 2;
+  }
+  if (err) atomicOr(errflag, err);
+  if (EV) block_sum_store<8>(ev, s_red, evpart);
+}
+
+__global__ void k_ev_final(const double *part, int nblocks, double *out)
+{
+  // fixed-order sum of the per-block partials
+  const int c = threadIdx.x;
+  if (c < 8) {
+    double s = 0.0;
+    for (int b = 0; b < nblocks; b++) s += part[(size_t) b * 8 + c];
+    out[c] = s;
+  }
+}
+
+template <int STYLE, int TS>
+hipError_t launch_style_ts(const PairDev &P, const AtomsDev &A, const ListDev &L, bool ev, double *evpart,
+                           int *errflag, hipStream_t st, int nblocks)
+{
+  const size_t ldsbytes = P.tab_in_lds ? (size_t) P.ntab * P.tablength * sizeof(double4) : 0;
+#define UCG_LAUNCH(EVF, LDSF)                                                                          \
+  do {                                                                                                 \
+    auto kern = k_pair_gather<STYLE, TS, EVF, LDSF>;                                                   \
+    if (ldsbytes > 48 * 1024) {                                                                        \
+      hipError_t e = hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                         (int) ldsbytes);                                              \
+      if (e != hipSuccess) return e;                                                                   \
+    }                                                                                                  \
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(PAIR_BLOCK), ldsbytes, st, P, A, L, evpart, errflag); \
+  } while (0)
+  if (P.tab_in_lds) {
+    if (ev) UCG_LAUNCH(true, true);
+    else UCG_LAUNCH(false, true);
+  } else {
+    if (ev) UCG_LAUNCH(true, false);
+    else UCG_LAUNCH(false, false);
+  }
+#undef UCG_LAUNCH
+  return hipGetLastError();
+}
+
+template <int STYLE>
+hipError_t launch_style(const PairDev &P, const AtomsDev &A, const ListDev &L, bool ev, double *evpart,
+                        int *errflag, hipStream_t st, int nblocks)
+{
+  switch (P.tabstyle) {
+    case 0: return launch_style_ts<STYLE, 0>(P, A, L, ev, evpart, errflag, st, nblocks);
+    case 1: return launch_style_ts<STYLE, 1>(P, A, L, ev, evpart, errflag, st, nblocks);
+    default: return launch_style_ts<STYLE, 2>(P, A, L, ev, evpart, errflag, st, nblocks);
+  }
+}
+
+}  // namespace
+
+int pair_gather_blocks(int nlocal) { return (nlocal + PAIR_BLOCK - 1) / PAIR_BLOCK; }
+
+hipError_t launch_pair_gather(const PairDev &P, const AtomsDev &A, const ListDev &L, bool ev,
+                              double *evpart, double *evout, int *errflag, hipStream_t st)
+{
+  const int nblocks = pair_gather_blocks(A.nlocal);
+  if (nblocks == 0) return hipSuccess;
+  hipError_t e;
+  if (P.style == 0) e = launch_style<0>(P, A, L, ev, evpart, errflag, st, nblocks);
+  else e = launch_style<1>(P, A, L, ev, evpart, errflag, st, nblocks);
+  if (e != hipSuccess) return e;
+  if (ev) {
+    hipLaunchKernelGGL(k_ev_final, dim3(1), dim3(64), 0, st, evpart, nblocks, evout);
+    e = hipGetLastError();
+  }
+  return e;
+}
+
+}  // namespace ucg

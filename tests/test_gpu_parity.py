@@ -1,0 +1,178 @@
+"""GPU parity tests proper: HIP path (through the C ABI) vs the CPU oracle on the same inputs.
+
+Bar: bit-exact against the oracle's canonical-order mode for every per-bead output
+(f, ucgforce, ucgsoftmaxscores, ucgp, states, RNG streams); <= 1e-11 relative against the
+oracle's reference-order mode (half list + scatter, the reference's own summation order),
+which differs from the canonical order only by floating-point re-association.
+"""
+import numpy as np
+import pytest
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+REL_REFORDER = 1e-11
+
+
+def test_library_loads_and_device(gpu_ctx, pkg):
+    assert pkg.capi.lib().ucg_abi_version() == 1
+    assert gpu_ctx.counts() == (0, 0)
+
+
+@pytest.mark.parametrize("seed,skip,n", [(48279, 0, 10000), (12345, 99, 70000), (900000000, 1234567, 5000), (1, 0, 4097)])
+def test_ranmars_device_stream(gpu_ctx, orc, seed, skip, n):
+    L = orc.lib()
+    r = orc.RanMars()
+    L.orc_ranmars_init(r, seed)
+    ref = np.zeros(skip + n)
+    L.orc_ranmars_fill(r, skip + n, ref.ctypes.data_as(orc.c_double_p))
+    got = gpu_ctx.ranmars_fill(seed, skip, n)
+    assert util.bits_equal(got, ref[skip:])
+
+
+def test_ranmars_published_check_values(gpu_ctx):
+    # Marsaglia, Zaman & Tsang: seeds ij=1802, kl=9373 -> after 20000 draws the next six * 2^24
+    got = gpu_ctx.ranmars_fill(1802 * 30082 + 9373 + 1, 19999, 6)
+    assert [int(v * 16777216.0) for v in got] == [6533892, 14220222, 7275067, 6172232, 8354498, 10633180]
+
+
+@pytest.mark.parametrize("tabstyle,tablength", [("spline", 1024), ("linear", 4096), ("lookup", 2000), ("spline", 8000)])
+@pytest.mark.parametrize("ncell", [6, 12])
+def test_pair_ucgld_parity(gpu_ctx, pkg, orc, tabstyle, tablength, ncell):
+    deck = util.make_deck(tabstyle, tablength)
+    beads = pkg.synth.make_beads(ncell, seed=100 + ncell)
+    op = util.oracle_pair("table_ucgld", deck)
+    sim = util.oracle_sim(beads, op, mode=1)
+    sim.rebuild()
+    util.upload_from_oracle(gpu_ctx, sim, beads)
+    gp = util.gpu_pair(gpu_ctx, "table_ucgld", deck)
+    eng, vir = gp.compute(1, 1)
+    gp.check_errors()
+    G = gpu_ctx.atoms_download()
+    assert sim.compute_forces(1, 1) == 0
+    O = sim.arrays()
+    for k in ("f", "ucgforce", "scores", "num_ucgstates"):
+        assert np.array_equal(G[k], O[k]), k
+    assert util.bits_equal(G["f"], O["f"]) and util.bits_equal(G["scores"], O["scores"])
+    ev = sim.ev()
+    assert abs(eng - ev["eng_vdwl"]) <= 1e-12 * abs(ev["eng_vdwl"])
+    assert np.allclose(vir, ev["virial"], rtol=1e-11, atol=1e-9)
+    # reference order (half list, scatter, reverse sum): same numbers, different association
+    sim0 = util.oracle_sim(beads, op, mode=0)
+    sim0.rebuild()
+    assert sim0.compute_forces(1, 1) == 0
+    R = sim0.arrays()
+    scale = np.abs(R["f"]).max()
+    assert np.abs(G["f"] - R["f"]).max() <= REL_REFORDER * scale
+    assert np.abs(G["ucgforce"] - R["ucgforce"]).max() <= REL_REFORDER * np.abs(R["ucgforce"]).max()
+    assert np.abs(G["scores"] - R["scores"]).max() <= REL_REFORDER * np.abs(R["scores"]).max()
+    assert abs(eng - sim0.ev()["eng_vdwl"]) <= 1e-11 * abs(eng)
+
+
+@pytest.mark.parametrize("extra", [(), ("pseudo", "no"), ("method", "mf"), ("prior", "chemical_potential")])
+@pytest.mark.parametrize("first_call", [True, False])
+def test_pair_bethe_parity(gpu_ctx, pkg, orc, extra, first_call):
+    deck = util.make_deck("spline", 1024, extra_keywords=extra)
+    beads = pkg.synth.make_beads(8, seed=77)
+    if not first_call:
+        rng = np.random.default_rng(5)
+        beads.ucgp = np.clip(rng.uniform(size=beads.n), 1e-6, 1 - 1e-6)
+    op = util.oracle_pair("table_ucg_bethe", deck)
+    sim = util.oracle_sim(beads, op, mode=1)
+    sim.rebuild()
+    util.upload_from_oracle(gpu_ctx, sim, beads)
+    gp = util.gpu_pair(gpu_ctx, "table_ucg_bethe", deck)
+    eng, vir = gp.compute(1, 1)
+    gp.check_errors()
+    G = gpu_ctx.atoms_download()
+    assert sim.compute_forces(1, 1) == 0
+    O = sim.arrays()
+    assert util.bits_equal(G["f"], O["f"])
+    assert util.bits_equal(G["scores"], O["scores"])
+    assert np.array_equal(G["ucgforce"], np.zeros_like(G["ucgforce"]))
+    ev = sim.ev()
+    assert abs(eng - ev["eng_vdwl"]) <= 1e-12 * abs(ev["eng_vdwl"])
+    sim0 = util.oracle_sim(beads, op, mode=0)
+    sim0.rebuild()
+    assert sim0.compute_forces(1, 1) == 0
+    R = sim0.arrays()
+    assert np.abs(G["f"] - R["f"]).max() <= REL_REFORDER * np.abs(R["f"]).max()
+    assert np.abs(G["scores"] - R["scores"]).max() <= REL_REFORDER * np.abs(R["scores"]).max()
+
+
+def test_table_range_error_is_reported(gpu_ctx, pkg, orc):
+    deck = util.make_deck("spline", 512)
+    beads = pkg.synth.make_beads(6, seed=3)
+    beads.x[1] = beads.x[0] + np.array([0.3, 0.0, 0.0])  # closer than the table's inner cutoff 0.6
+    op = util.oracle_pair("table_ucgld", deck)
+    sim = util.oracle_sim(beads, op, mode=1)
+    sim.rebuild()
+    util.upload_from_oracle(gpu_ctx, sim, beads)
+    gp = util.gpu_pair(gpu_ctx, "table_ucgld", deck)
+    gp.compute(0, 0)
+    with pytest.raises(pkg.capi.UcgError) as ei:
+        gp.check_errors()
+    assert "inner cutoff" in str(ei.value)
+    assert sim.compute_forces(0, 0) != 0  # the oracle flags the same pair
+
+
+@pytest.mark.parametrize("mode", ["ld", None, "mc"])
+def test_fix_hooks_parity(gpu_ctx, pkg, orc, mode):
+    """one Verlet step assembled from the individual hooks, compared hook by hook"""
+    L = orc.lib()
+    deck = util.make_deck("spline", 1024)
+    beads = pkg.synth.make_beads(8, seed=11)
+    dt = 0.002
+    op = util.oracle_pair("table_ucgld", deck)
+    sim = util.oracle_sim(beads, op, mode=1, dt=dt)
+    sim.rebuild()
+    gpu_ctx.set_units(1.0, 1.0, 1.0, dt)
+    util.upload_from_oracle(gpu_ctx, sim, beads)
+    gp = util.gpu_pair(gpu_ctx, "table_ucgld", deck)
+    # --- pair
+    gp.compute(0, 0)
+    assert sim.compute_forces(0, 0) == 0
+    a = L.orc_sim_atoms(sim.h)
+    # --- langevin
+    lang = L.orc_fix_langevin_create(2, 1.0, 1.5, 0.7, 48279, 0)
+    L.orc_fix_langevin_init(lang, a, dt, 1.0, 1.0, 1.0)
+    O0 = sim.arrays()
+    gpu_ctx.fix_ucgld_langevin(1.0, 1.5, 0.7, 48279)
+    gpu_ctx.fix_ucgld_langevin_init(2, O0["ucgml"][:3])
+    for step in (3, 4):
+        L.orc_fix_langevin_post_force(lang, a, 1, step, 0, 10)
+        gpu_ctx.fix_ucgld_langevin_post_force(step, 0, 10)
+    assert abs(gpu_ctx.fix_ucgld_langevin_t_target() - (1.0 + 0.4 * 0.5)) < 1e-15
+    G = gpu_ctx.atoms_download()
+    O = sim.arrays()
+    assert util.bits_equal(G["ucgforce"], O["ucgforce"])
+    # --- ucgstate
+    fx = L.orc_fix_ucgstate_create(1 if mode == "ld" else 0, 1 if mode == "mc" else 0, 9127, 0.3, 0)
+    gpu_ctx.fix_ucgstate(mode, 9127, 0.3)
+    for _ in range(2):
+        L.orc_fix_ucgstate_post_force(fx, a)
+        gpu_ctx.fix_ucgstate_post_force()
+    G = gpu_ctx.atoms_download()
+    O = sim.arrays()
+    assert util.bits_equal(G["ucgp"], O["ucgp"])
+    assert np.array_equal(G["ucgstate"], O["ucgstate"])
+    assert util.bits_equal(G["ucgl"], O["ucgl"])
+    if mode == "mc":
+        assert 0 < G["ucgstate"].sum() < beads.n
+    # --- nve
+    L.orc_fix_nve_final(a, dt, 1.0, 1)
+    gpu_ctx.fix_nve_ucgld_final_integrate()
+    L.orc_fix_nve_initial(a, dt, 1.0, 1)
+    gpu_ctx.fix_nve_ucgld_initial_integrate()
+    G = gpu_ctx.atoms_download()
+    O = sim.arrays()
+    for k in ("x", "v", "ucgl", "ucgvl"):
+        assert util.bits_equal(G[k], O[k]), k
+    L.orc_fix_langevin_end_of_step(lang, a, 1, 1.0, 1.0)
+    out = np.zeros(16)
+    L.orc_fix_langevin_get(lang, out.ctypes.data_as(orc.c_double_p))
+    lt = gpu_ctx.fix_ucgld_langevin_end_of_step()
+    assert abs(lt - out[2]) <= 1e-13 * abs(out[2])
+    L.orc_fix_langevin_destroy(lang)
+    L.orc_fix_ucgstate_destroy(fx)

@@ -1,0 +1,64 @@
+"""helpers shared by the tests: build the same setup on the oracle and on the GPU library"""
+import tempfile
+
+import numpy as np
+
+from conftest import load_oracle, load_package
+
+
+def make_deck(tabstyle="spline", tablength=1024, **kw):
+    pkg = load_package()
+    return pkg.synth.make_deck(tempfile.mkdtemp(prefix="ucgdeck_"), tabstyle, tablength, **kw)
+
+
+def oracle_pair(style, deck, T=1.0, ntypes=2):
+    orc = load_oracle()
+    p = orc.Pair(style)
+    p.settings(deck.pair_style_args())
+    p.coeff(deck.pair_coeff_args(), ntypes)
+    p.init(ntypes, T, 1.0)
+    return p
+
+
+def gpu_pair(ctx, style, deck, T=1.0, ntypes=2):
+    pkg = load_package()
+    p = pkg.capi.Pair(ctx, style)
+    p.settings(deck.pair_style_args())
+    p.coeff(deck.pair_coeff_args(), ntypes)
+    p.init(ntypes, T)
+    return p
+
+
+def oracle_sim(beads, pair, mode=1, dt=0.002, langevin=None, nve=True, ucgstate=None, every=1, cutforce=2.5, skin=0.3):
+    orc = load_oracle()
+    s = orc.Sim(beads, cutforce, skin)
+    s.set_run_params(dt=dt, every=every, delay=0, check=1, mode=mode)
+    s.attach(pair, langevin=langevin, nve=nve, ucgstate=ucgstate)
+    return s
+
+
+def upload_from_oracle(ctx, sim, beads):
+    """put the oracle's current owned+ghost beads and its full list on the GPU"""
+    A = sim.arrays(ghosts=True)
+    nl, ng = A["nlocal"], A["nghost"]
+    ctx.atoms_upload(nl, ng, beads.ntypes, A["x"], A["v"], A["type"], A["tag"], A["mask"][:nl], A["ucgstate"],
+                     A["ucgl"], A["ucgvl"], A["ucgml"], A["ucgp"], beads.mass)
+    il, nn, fi, ne = sim.full_list()
+    ctx.neigh_upload_full(nn, fi, ne)
+    return A
+
+
+def bits_equal(a, b):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    return a.shape == b.shape and np.array_equal(a.view(np.uint64), b.view(np.uint64))
+
+
+def max_ulp(a, b):
+    a = np.ascontiguousarray(a, dtype=np.float64).ravel()
+    b = np.ascontiguousarray(b, dtype=np.float64).ravel()
+    ia = a.view(np.int64).copy()
+    ib = b.view(np.int64).copy()
+    ia[ia < 0] = np.int64(-2**63) - ia[ia < 0]
+    ib[ib < 0] = np.int64(-2**63) - ib[ib < 0]
+    return int(np.abs(ia - ib).max()) if a.size else 0
