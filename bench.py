@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- UCG hot path on MI355X: timesteps/s at 1 M UCG beads.
+
+  python bench.py --gpus N --steps K --warmup W
+
+One "step" is one full Verlet step of the resident path on synthetic input:
+fix nve/ucgld initial_integrate -> re-neighbour decision (every 10 steps, rebuild when a
+bead moved skin/2) / halo refresh -> pair_style table_ucgld (spline 1024, 2-state, the
+north-star neighbour loop) -> fix ucgld/langevin -> fix ucgstate ld -> final_integrate.
+Workload (BASELINE.md config 4 at N GPUs, config-2 styles at 1 M beads): 100^3 beads at
+rho* = 0.8, rc = 2.5, skin = 0.3, dt = 0.002, fp64 throughout.  For N > 1 the SAME 1 M beads
+are split across the ranks (strong scaling).  Inputs are resident in HBM before timing.
+
+The JSON line also carries
+  roofline     -- the pair kernel's algorithmic bytes (44 B per half-list entry + 96 B per bead,
+                  SURVEY.md 8d) / its mean duration from HIP events on its own stream, vs 8 TB/s
+  cpu_baseline -- the oracle's reference-order (half list, scalar) loop timed on this box's host
+                  cores on a bounded sample; a reported baseline, not a target.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+
+
+def cpu_baseline(pkg, deck, ncell, nsteps, dt):
+    """oracle, reference order (sequential half list + scatter + reverse sum), 1 core"""
+    orc = entry.load_oracle()
+    beads = pkg.synth.make_beads(ncell, seed=12345)
+    op = orc.Pair("table_ucgld")
+    op.settings(deck.pair_style_args())
+    op.coeff(deck.pair_coeff_args())
+    op.init(2, 1.0, 1.0)
+    sim = orc.Sim(beads)
+    sim.set_run_params(dt=dt, every=10, delay=0, check=1, mode=0)
+    sim.attach(op, langevin=(1.0, 1.0, 1.0, 48279), nve=True, ucgstate="ld")
+    sim.setup(nsteps)
+    t0 = time.perf_counter()
+    sim.run(nsteps, 0)
+    t = time.perf_counter() - t0
+    info = sim.info()
+    atom_steps = beads.n * nsteps / t
+    return dict(seconds=t, n=beads.n, steps=nsteps, atom_steps_per_s=atom_steps, nhalf=info["nhalf"],
+                ns_per_entry=t / nsteps / max(info["nhalf"], 1) * 1e9)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--ncell", type=int, default=100, help="beads = ncell^3 (default 100 -> 1 M)")
+    ap.add_argument("--tabstyle", default="spline")
+    ap.add_argument("--tablength", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-ncell", type=int, default=64)
+    ap.add_argument("--cpu-steps", type=int, default=10)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    import torch
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the UCG hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    pkg = entry.load_package()
+    capi, synth = pkg.capi, pkg.synth
+    dt = 0.002
+    workdir = tempfile.mkdtemp(prefix=f"ucgbench_r{rank}_")
+    deck = synth.make_deck(workdir, args.tabstyle, args.tablength)
+
+    if world > 1:
+        from lammps_ucg_dev_amd import multi  # spatial decomposition + RCCL halo
+
+        result = multi.run_bench(args, deck, rank, world, local_rank, dist)
+    else:
+        beads = synth.make_beads(args.ncell, seed=12345)
+        ctx = capi.Context(local_rank, dt=dt)
+        ctx.upload_beads(beads)
+        ctx.domain_set(beads.boxlo, beads.boxhi, 2.5, 0.3, every=10, delay=0, check=1)
+        pair = capi.Pair(ctx, "table_ucgld")
+        pair.settings(deck.pair_style_args())
+        pair.coeff(deck.pair_coeff_args())
+        pair.init(2, 1.0)
+        ctx.fix_ucgld_langevin(1.0, 1.0, 1.0, 48279)
+        ctx.fix_ucgstate("ld")
+        ctx.md_attach(pair, nve=True, langevin=True, ucgstate=True)
+        ctx.md_setup(args.warmup + args.steps)
+        ctx.md_run(args.warmup, 0)
+        ctx.synchronize()
+        ctx.profile_enable(True)
+        ctx.profile_read(reset=True)
+        info0 = ctx.md_info()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ctx.md_run(args.steps, 0)
+        ctx.synchronize()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        launches, pair_ms = ctx.profile_read(reset=True)
+        ctx.profile_enable(False)
+        pair.check_errors()
+        info = ctx.md_info()
+        result = dict(elapsed=elapsed, n=beads.n, pair_launches=launches, pair_ms=pair_ms,
+                      list_entries=info["list_entries"], nghost=info["nghost"],
+                      rebuilds=info["nrebuild"] - info0["nrebuild"], maxrow=info["maxrow"])
+
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    n = result["n"]
+    steps_per_s = args.steps / result["elapsed"]
+    e_half = result["list_entries"] / 2.0
+    alg_bytes = 44.0 * e_half + 96.0 * n  # B_alg(ucgld) = 44 E + 96 N per launch
+    pair_avg_s = (result["pair_ms"] / max(result["pair_launches"], 1)) * 1e-3
+    achieved = alg_bytes / pair_avg_s / 1e9 if pair_avg_s > 0 else 0.0
+    out = {
+        "metric": "timesteps/sec at 1M UCG beads (table_ucgld + nve/ucgld + ucgld/langevin + ucgstate ld)",
+        "value": steps_per_s,
+        "unit": "timesteps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * result["elapsed"] / args.steps,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "atom_steps_per_s": steps_per_s * n,
+        "config": {
+            "workload": f"{n} beads (sc lattice {args.ncell}^3 + jitter), rho*=0.8, rc=2.5, skin=0.3, dt=0.002, "
+                        f"pair_style table_ucgld {args.tabstyle} {args.tablength} (2-state, 4 LJ-like tables) + "
+                        "fix nve/ucgld + fix ucgld/langevin 1.0 1.0 1.0 48279 + fix ucgstate ld; "
+                        "neigh_modify every 10 check yes; rebuilds inside the timed region: "
+                        f"{result['rebuilds']}",
+            "beads": n,
+            "full_list_entries": int(result["list_entries"]),
+            "ghosts": int(result["nghost"]),
+            "parallelism": f"spatial {world} GPU" if world > 1 else "1 GPU",
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "k_pair_gather<table_ucgld>",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "avg_launch_us": pair_avg_s * 1e6,
+            "launches": int(result["pair_launches"]),
+        },
+    }
+    if not args.no_cpu_baseline:
+        cb = cpu_baseline(pkg, deck, args.cpu_ncell, args.cpu_steps, dt)
+        out["cpu_baseline"] = {
+            "value": cb["atom_steps_per_s"] / n,
+            "unit": "timesteps/s",
+            "cores": 1,
+            "kind": "port",
+            "sample": f"oracle reference-order loop (half list, scalar, gcc -O2 -ffp-contract=off), {cb['n']} beads x "
+                      f"{cb['steps']} full steps in {cb['seconds']:.2f} s = {cb['atom_steps_per_s']:.4g} bead-steps/s "
+                      f"({cb['ns_per_entry']:.1f} ns per half-list entry per step), scaled to {n} beads",
+        }
+    print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -81,6 +81,9 @@ struct FixUcgState {
 }  // namespace ucg
 
 struct ucg_pair;
+namespace ucg {
+struct Domain;
+}
 
 struct ucg_ctx {
   int device = 0;
@@ -109,7 +112,7 @@ struct ucg_ctx {
   ucg::FixLangevin lang;
   ucg::FixUcgState ucgst;
   // domain / rebuild (ucg_neigh.hip)
-  struct Domain *dom = nullptr;
+  ucg::Domain *dom = nullptr;
   // resident driver
   ucg_pair *md_pair = nullptr;
   bool md_nve = false, md_lang = false, md_ucgst = false;

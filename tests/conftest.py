@@ -52,3 +52,11 @@ def gpu_ctx(pkg):
     ctx = pkg.capi.Context(-1)
     yield ctx
     ctx.close()
+
+
+@pytest.fixture
+def fresh_ctx(pkg):
+    """a context of its own (fix state, step counters and RNG streams start from scratch)"""
+    ctx = pkg.capi.Context(-1)
+    yield ctx
+    ctx.close()

@@ -1,0 +1,103 @@
+"""Resident path: device rebuild (wrap, sort, ghosts, bins, full list) and whole Verlet
+trajectories on the GPU against the oracle, bit for bit (the "ucg-rebuild-v1" spec)."""
+import numpy as np
+import pytest
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup_gpu(gpu_ctx, beads, dt, every):
+    gpu_ctx.set_units(1.0, 1.0, 1.0, dt)
+    gpu_ctx.upload_beads(beads)
+    gpu_ctx.domain_set(beads.boxlo, beads.boxhi, 2.5, 0.3, every=every, delay=0, check=1)
+
+
+@pytest.mark.parametrize("ncell", [5, 8, 14])
+def test_device_rebuild_matches_spec(gpu_ctx, pkg, orc, ncell):
+    deck = util.make_deck("spline", 1024)
+    beads = pkg.synth.make_beads(ncell, seed=ncell)
+    # push a few beads out of the box so that the wrap is exercised
+    beads.x[0] += beads.boxhi
+    beads.x[1] -= beads.boxhi
+    beads.x[2, 0] += beads.boxhi[0]
+    op = util.oracle_pair("table_ucgld", deck)
+    sim = util.oracle_sim(beads, op, mode=1)
+    sim.rebuild()
+    _setup_gpu(gpu_ctx, beads, 0.002, 1)
+    gpu_ctx.neigh_rebuild()
+    G = gpu_ctx.atoms_download(with_ghosts=True)
+    O = sim.arrays(ghosts=True)
+    assert (G["nlocal"], G["nghost"]) == (O["nlocal"], O["nghost"])
+    nl = G["nlocal"]
+    assert np.array_equal(G["tag"], O["tag"])
+    assert util.bits_equal(G["x"], O["x"])
+    assert np.array_equal(G["type"], O["type"]) and np.array_equal(G["ucgstate"], O["ucgstate"])
+    assert util.bits_equal(G["ucgl"], O["ucgl"]) and util.bits_equal(G["ucgp"], O["ucgp"])
+    assert util.bits_equal(G["v"], O["v"]) and util.bits_equal(G["ucgml"], O["ucgml"])
+    gs, gsh = gpu_ctx.ghosts_download()
+    os_, osh = sim.ghost_map()
+    assert np.array_equal(gs, os_) and np.array_equal(gsh, osh)
+    gl = gpu_ctx.neigh_download()
+    ol = sim.full_list()
+    for a, b in zip(gl, ol):
+        assert np.array_equal(a, b)
+    # and the forces on that list
+    gp = util.gpu_pair(gpu_ctx, "table_ucgld", deck)
+    gp.compute(0, 0)
+    assert sim.compute_forces(0, 0) == 0
+    assert util.bits_equal(gpu_ctx.atoms_download()["f"], sim.arrays()["f"])
+    assert nl == beads.n
+
+
+CASES = [
+    # style, extra keywords, langevin, ucgstate, dt, steps, every
+    ("table_ucgld", (), (1.0, 1.0, 1.0, 48279), "ld", 0.004, 120, 1),
+    ("table_ucgld", (), (1.0, 2.0, 0.5, 777), "ld", 0.004, 100, 5),
+    ("table_ucg_bethe", (), None, "plain", 0.004, 80, 1),
+    ("table_ucg_bethe", ("pseudo", "no"), None, ("mc", 9127, 0.2), 0.004, 80, 2),
+    ("table_ucgld", (), None, None, 0.004, 60, 1),
+]
+
+
+@pytest.mark.parametrize("style,extra,langevin,ucgstate,dt,steps,every", CASES)
+def test_md_trajectory_bitwise(fresh_ctx, pkg, orc, style, extra, langevin, ucgstate, dt, steps, every):
+    deck = util.make_deck("spline", 1024, extra_keywords=extra)
+    beads = pkg.synth.make_beads(8, seed=31)
+    op = util.oracle_pair(style, deck)
+    sim = util.oracle_sim(beads, op, mode=1, dt=dt, langevin=langevin, nve=True, ucgstate=ucgstate, every=every)
+    assert sim.setup(steps) == 0
+    assert sim.run(steps, 10) == 0
+
+    gpu_ctx = fresh_ctx
+    _setup_gpu(gpu_ctx, beads, dt, every)
+    gp = util.gpu_pair(gpu_ctx, style, deck)
+    if langevin is not None:
+        gpu_ctx.fix_ucgld_langevin(*langevin)
+    if ucgstate is not None:
+        if ucgstate == "ld":
+            gpu_ctx.fix_ucgstate("ld")
+        elif ucgstate == "plain":
+            gpu_ctx.fix_ucgstate(None)
+        else:
+            gpu_ctx.fix_ucgstate("mc", ucgstate[1], ucgstate[2])
+    gpu_ctx.md_attach(gp, nve=True, langevin=langevin is not None, ucgstate=ucgstate is not None)
+    gpu_ctx.md_setup(steps)
+    gpu_ctx.md_run(steps, 10)
+    gp.check_errors()
+    info, oinfo = gpu_ctx.md_info(), sim.info()
+    assert info["nrebuild"] == oinfo["nrebuild"] and info["nrebuild"] >= 2
+    assert info["nghost"] == oinfo["nghost"] and info["list_entries"] == oinfo["nfull"]
+    G = gpu_ctx.atoms_download()
+    O = sim.arrays()
+    assert np.array_equal(G["tag"], O["tag"])
+    for k in ("x", "v", "f", "ucgl", "ucgvl", "ucgforce", "scores", "ucgp"):
+        assert util.bits_equal(G[k], O[k]), k
+    assert np.array_equal(G["ucgstate"], O["ucgstate"])
+    th, oth = gpu_ctx.md_thermo(), sim.ev()
+    assert abs(th["eng_vdwl"] - oth["eng_vdwl"]) <= 1e-12 * abs(oth["eng_vdwl"])
+    if langevin is not None:
+        assert abs(th["lambda_temp"] - oth["lambda_temp"]) <= 1e-12 * abs(oth["lambda_temp"])
+    if isinstance(ucgstate, tuple):  # mc: both states stay populated
+        assert 0 < G["ucgstate"].sum() < beads.n

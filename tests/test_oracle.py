@@ -1,0 +1,258 @@
+"""CPU tier: the oracle against every known answer available for this path.
+
+The reference ships no tests, fixtures or golden vectors, so the
+oracle is pinned by (a) the published RANMAR check values, (b) libm for the shared math
+kernels, (c) analytic invariants of the UCG arithmetic, (d) closed-form properties of the
+spline/table pipeline.  "Parity unpinned" by the reference itself -- see oracle/orc.h.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import util
+
+
+def test_ranmar_published_check_values(orc):
+    # Marsaglia, Zaman & Tsang (1990): RMARIN(1802, 9373), 20000 draws, next six * 4096^2.
+    # LAMMPS seeding: ij = (seed-1)/30082, kl = (seed-1) - 30082*ij; its constructor's
+    # warm-up draw is the first of the 20000.
+    L = orc.lib()
+    r = orc.RanMars()
+    L.orc_ranmars_init(r, 1802 * 30082 + 9373 + 1)
+    for _ in range(19999):
+        L.orc_ranmars_uniform(r)
+    got = [int(L.orc_ranmars_uniform(r) * 4096.0 * 4096.0) for _ in range(6)]
+    assert got == [6533892, 14220222, 7275067, 6172232, 8354498, 10633180]
+
+
+def test_ranmars_values_are_24bit_fractions(orc):
+    L = orc.lib()
+    r = orc.RanMars()
+    L.orc_ranmars_init(r, 48279)
+    out = np.zeros(5000)
+    L.orc_ranmars_fill(r, 5000, out.ctypes.data_as(orc.c_double_p))
+    assert np.all(out >= 0) and np.all(out < 1)
+    assert np.array_equal(out * 2**24, np.round(out * 2**24))
+    assert abs(out.mean() - 0.5) < 0.02
+
+
+def test_math_kernels_within_one_ulp_of_libm(orc):
+    L = orc.lib()
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([rng.uniform(-745, 709, 20000), rng.uniform(-2, 2, 20000), rng.uniform(-1e-3, 1e-3, 5000),
+                         np.array([0.0, 1.0, -1.0, 700.0, -700.0, 0.5, 1e-300])])
+    worst = {"exp": 0, "expm1": 0, "log": 0, "tanh": 0}
+    for x in xs:
+        for name in ("exp", "expm1", "tanh"):
+            L.orc_set_math(0)
+            a = getattr(L, "orc_" + name)(float(x))
+            L.orc_set_math(1)
+            b = getattr(L, "orc_" + name)(float(x))
+            worst[name] = max(worst[name], util.max_ulp(np.array([a]), np.array([b])))
+        p = abs(float(x)) + 1e-300
+        L.orc_set_math(0)
+        a = L.orc_log(p)
+        L.orc_set_math(1)
+        b = L.orc_log(p)
+        worst["log"] = max(worst["log"], util.max_ulp(np.array([a]), np.array([b])))
+    L.orc_set_math(0)
+    assert worst["exp"] <= 1 and worst["expm1"] <= 1 and worst["log"] <= 1
+    assert worst["tanh"] <= 4  # fdlibm's tanh (via expm1) is a few ulp, like glibc's
+
+
+def test_spline_reproduces_a_cubic_exactly(orc):
+    # a clamped cubic spline through samples of a cubic IS that cubic
+    L = orc.lib()
+    L.orc_spline.argtypes = [orc.c_double_p, orc.c_double_p, C.c_int, C.c_double, C.c_double, orc.c_double_p]
+    L.orc_splint.argtypes = [orc.c_double_p, orc.c_double_p, orc.c_double_p, C.c_int, C.c_double]
+    L.orc_splint.restype = C.c_double
+    x = np.linspace(0.5, 3.0, 41)
+    f = lambda t: 2.0 - t + 0.3 * t**2 - 0.1 * t**3
+    df = lambda t: -1.0 + 0.6 * t - 0.3 * t**2
+    y = f(x)
+    y2 = np.zeros_like(x)
+    L.orc_spline(x.ctypes.data_as(orc.c_double_p), y.ctypes.data_as(orc.c_double_p), len(x), df(x[0]), df(x[-1]),
+                 y2.ctypes.data_as(orc.c_double_p))
+    assert np.allclose(y2, 0.6 - 0.6 * x, atol=1e-10)
+    for t in np.linspace(0.5, 3.0, 97):
+        v = L.orc_splint(x.ctypes.data_as(orc.c_double_p), y.ctypes.data_as(orc.c_double_p),
+                         y2.ctypes.data_as(orc.c_double_p), len(x), float(t))
+        assert abs(v - f(t)) < 1e-12
+
+
+@pytest.mark.parametrize("tabstyle,tablength,tol", [("spline", 1024, 2e-5), ("linear", 4096, 2e-4), ("lookup", 8000, 2e-3)])
+def test_tables_reproduce_the_analytic_potential(orc, pkg, tabstyle, tablength, tol):
+    deck = util.make_deck(tabstyle, tablength)
+    p = util.oracle_pair("table_ucgld", deck)
+    L = orc.lib()
+    L.orc_table_eval.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, orc.c_double_p, orc.c_double_p]
+    info = p.table_info(0)
+    assert info["innersq"] == 0.36 and info["cut"] == 2.5
+    # knots uniform in r^2 and stored as innersq + i*delta
+    if tabstyle != "lookup":
+        rsq = p.table_array(0, "rsq")
+        assert np.array_equal(rsq, info["innersq"] + np.arange(tablength) * info["delta"])
+    # values against 4 eps [(1/r)^12 - (1/r)^6], eps_00 = 1
+    e = p.table_array(0, "e")
+    f = p.table_array(0, "f")
+    k = np.arange(len(e))
+    r2 = info["innersq"] + (k + (0.5 if tabstyle == "lookup" else 0.0)) * info["delta"]
+    r = np.sqrt(r2)
+    u, fr = pkg.synth.lj_energy_force(r, 1.0)
+    sel = r > 0.8
+    assert np.max(np.abs(e[sel] - u[sel])) < tol
+    assert np.max(np.abs(f[sel] - fr[sel] / r[sel])) < 10 * tol
+
+
+def test_state_settings_and_coeff_mapping(orc):
+    deck = util.make_deck("spline", 256, mu=(0.25, 0.75))
+    p = util.oracle_pair("table_ucgld", deck)
+    assert list(p.int_array("n_states_per_type")) == [0, 2]
+    assert list(p.int_array("formal_from_actual")) == [0, 0, 1, 2]
+    assert list(p.dbl_array("chem_pot")) == [0.0, 0.25, 0.75]
+    ti = p.int_array("tabindex").reshape(3, 3)
+    # init_one forces tabindex[2][1] = tabindex[1][2]: table "10" is dropped
+    assert ti[1, 1] == 0 and ti[1, 2] == 1 and ti[2, 1] == 1 and ti[2, 2] == 3
+    assert np.allclose(p.dbl_array("cutsq").reshape(3, 3)[1:, 1:], 6.25)
+
+
+def test_input_errors_are_reported(orc):
+    deck = util.make_deck("spline", 256)
+    p = orc.Pair("table_ucgld")
+    with pytest.raises(orc.OracleError):
+        p.settings(["spline", "1", deck.conf_file])
+    with pytest.raises(orc.OracleError):
+        p.settings(["cubic", "100", deck.conf_file])
+    p.settings(deck.pair_style_args())
+    with pytest.raises(orc.OracleError):
+        p.coeff(deck.pair_coeff_args()[:-1])
+    bad = deck.pair_coeff_args()
+    bad[6] = "3.5"  # cutoff beyond the table
+    with pytest.raises(orc.OracleError):
+        p.coeff(bad)
+    with pytest.raises(orc.OracleError):
+        orc.Pair("table_ucgld").settings(["spline", "100", "/no/such/file"])
+
+
+def _tiny(orc, pkg, style, ncell=5, mode=1, seed=1, extra=(), eps=None, mu=(0.0, 0.5)):
+    deck = util.make_deck("spline", 1024, extra_keywords=extra, eps=eps, mu=mu)
+    beads = pkg.synth.make_beads(ncell, seed=seed)
+    op = util.oracle_pair(style, deck)
+    sim = util.oracle_sim(beads, op, mode=mode)
+    sim.rebuild()
+    return deck, beads, op, sim
+
+
+def test_identical_tables_reduce_to_plain_pair_table(orc, pkg):
+    # all four tables equal => forces are the plain table force for any lambda, ucgforce = -(mu1-mu0)
+    eps = {"00": 1.0, "01": 1.0, "10": 1.0, "11": 1.0}
+    deck, beads, op, sim = _tiny(orc, pkg, "table_ucgld", eps=eps, mu=(0.1, 0.4))
+    assert sim.compute_forces(1, 1) == 0
+    A = sim.arrays(ghosts=True)
+    il, nn, fi, ne = sim.full_list()
+    x = A["x"]
+    fref = np.zeros((A["nlocal"], 3))
+    L = orc.lib()
+    for k in range(A["nlocal"]):
+        for ent in ne[fi[k]:fi[k] + nn[k]]:
+            m = ent & orc.NEIGHMASK
+            d = x[k] - x[m]
+            r2 = d @ d
+            if r2 < 6.25:
+                u, f = pkg.synth.lj_energy_force(np.sqrt(r2), 1.0)
+                fref[k] += d * f / np.sqrt(r2)
+    assert np.max(np.abs(A["f"][:A["nlocal"]] - fref)) < 5e-4 * np.max(np.abs(fref))
+    assert np.allclose(A["ucgforce"][:A["nlocal"]], -(0.4 - 0.1), atol=1e-9)
+
+
+def test_newton_third_law_and_orders_agree(orc, pkg):
+    for style in ("table_ucgld", "table_ucg_bethe"):
+        deck, beads, op, sim = _tiny(orc, pkg, style, seed=4)
+        assert sim.compute_forces(1, 1) == 0
+        A = sim.arrays()
+        assert np.max(np.abs(A["f"].sum(axis=0))) < 1e-9
+        deck0, beads0, op0, sim0 = _tiny(orc, pkg, style, seed=4, mode=0)
+        assert sim0.compute_forces(1, 1) == 0
+        B = sim0.arrays()
+        o1, o0 = np.argsort(A["tag"]), np.argsort(B["tag"])
+        for k in ("f", "ucgforce", "scores"):
+            assert np.max(np.abs(A[k][o1] - B[k][o0])) <= 1e-11 * max(1.0, np.max(np.abs(B[k])))
+        assert abs(sim.ev()["eng_vdwl"] - sim0.ev()["eng_vdwl"]) < 1e-10 * abs(sim0.ev()["eng_vdwl"])
+
+
+def test_lambda_limits_select_single_tables(orc, pkg):
+    # lambda in {0,1} everywhere: the bilinear mix collapses onto one table per pair
+    deck = util.make_deck("spline", 1024)
+    beads = pkg.synth.make_beads(5, seed=9)
+    beads.ucgl[:] = 0.0
+    op = util.oracle_pair("table_ucgld", deck)
+    sim = util.oracle_sim(beads, op)
+    sim.rebuild()
+    sim.compute_forces(1, 1)
+    f0 = sim.arrays()
+    e0 = sim.ev()["eng_vdwl"]
+    # same system with only table 00 everywhere and arbitrary lambda
+    eps = {"00": 1.0, "01": 1.0, "10": 1.0, "11": 1.0}
+    deck1 = util.make_deck("spline", 1024, eps=eps)
+    beads1 = pkg.synth.make_beads(5, seed=9)
+    op1 = util.oracle_pair("table_ucgld", deck1)
+    sim1 = util.oracle_sim(beads1, op1)
+    sim1.rebuild()
+    sim1.compute_forces(1, 1)
+    f1 = sim1.arrays()
+    assert np.max(np.abs(f0["f"] - f1["f"])) <= 1e-9 * np.max(np.abs(f1["f"]))
+    assert abs(e0 - sim1.ev()["eng_vdwl"]) <= 1e-10 * abs(e0)
+
+
+def test_ucgforce_is_minus_dU_dlambda(orc, pkg):
+    # finite difference of the total pair energy w.r.t. one bead's lambda (mu term included analytically)
+    deck = util.make_deck("spline", 1024, mu=(0.0, 0.5))
+    base = pkg.synth.make_beads(5, seed=21)
+
+    def energy(lam_shift, idx):
+        b = pkg.synth.make_beads(5, seed=21)
+        b.ucgl[idx] += lam_shift
+        op = util.oracle_pair("table_ucgld", deck)
+        s = util.oracle_sim(b, op)
+        s.rebuild()
+        s.compute_forces(1, 1)
+        A = s.arrays()
+        pos = int(np.where(A["tag"] == idx + 1)[0][0])
+        return s.ev()["eng_vdwl"], A["ucgforce"][pos]
+
+    h = 1e-5
+    for idx in (0, 7, 50):
+        ep, _ = energy(+h, idx)
+        em, _ = energy(-h, idx)
+        _, uf = energy(0.0, idx)
+        dU = (ep - em) / (2 * h)
+        assert abs(uf - (-(0.5 - 0.0) - dU)) < 1e-6 * max(1.0, abs(dU))
+
+
+def test_bethe_mean_field_limit_when_tables_equal(orc, pkg):
+    # J = u11 + u00 - u01 - u10 = 0 => a = 0 => p11 = pi1 * pj1 (mean field), for both methods
+    eps = {"00": 0.7, "01": 0.7, "10": 0.7, "11": 0.7}
+    res = {}
+    for method in ("bethe", "mf"):
+        deck, beads, op, sim = _tiny(orc, pkg, "table_ucg_bethe", extra=("method", method), eps=eps)
+        assert sim.compute_forces(1, 1) == 0
+        res[method] = (sim.arrays(), sim.ev()["eng_vdwl"])
+    assert np.array_equal(res["bethe"][0]["f"], res["mf"][0]["f"])
+    assert res["bethe"][1] == res["mf"][1]
+
+
+def test_md_reference_and_canonical_orders_track_each_other(orc, pkg):
+    deck = util.make_deck("spline", 1024)
+    out = {}
+    for mode in (0, 1):
+        beads = pkg.synth.make_beads(6, seed=3)
+        op = util.oracle_pair("table_ucgld", deck)
+        sim = util.oracle_sim(beads, op, mode=mode, dt=0.002, langevin=(1.0, 1.0, 1.0, 48279), ucgstate="ld")
+        assert sim.setup(40) == 0
+        assert sim.run(40, 10) == 0
+        out[mode] = sim.arrays()
+    a, b = out[0], out[1]
+    oa, ob = np.argsort(a["tag"]), np.argsort(b["tag"])
+    assert np.max(np.abs(a["x"][oa] - b["x"][ob])) < 1e-11
+    assert np.max(np.abs(a["ucgl"][oa] - b["ucgl"][ob])) < 1e-11
