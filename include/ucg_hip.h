@@ -65,6 +65,13 @@ int ucg_ctx_synchronize(ucg_ctx *ctx);
 int ucg_ctx_set_units(ucg_ctx *ctx, double boltz, double ftm2v, double mvv2e, double dt,
                       const double *special_lj);
 
+/* options: "generic_kernels" = 1 keeps the pair kernels on their general code path (per-table
+ * grid lookup, IEEE division) even when the faster equivalent variants apply; takes effect
+ * at the next ucg_pair_init.  Used by the tests to check that both give the same bits. */
+int ucg_ctx_set_option(ucg_ctx *ctx, const char *name, int value);
+/* device self-test: n random operands, counts a / b != div_by_const(a, b) (must be 0) */
+int ucg_selftest_div(ucg_ctx *ctx, double b, long long seed, int n, long long *mismatches);
+
 /* --------------------------------------------------------------- pair styles
  * replaces PairTable_UCGLD / PairTable_UCG_Bethe / PairTable_UCG_Bethe_Density
  *   settings()   UCG/pair_table_ucgld.cpp:654-716, UCG/pair_table_ucg_bethe.cpp:746-886,

@@ -31,7 +31,7 @@ NEIGHMASK = 0x1FFFFFFF
 # every symbol include/ucg_hip.h declares (checked by the CPU test-suite against the .so)
 SYMBOLS = [
     "ucg_abi_version", "ucg_ctx_create", "ucg_ctx_destroy", "ucg_last_error", "ucg_ctx_set_stream",
-    "ucg_ctx_synchronize", "ucg_ctx_set_units",
+    "ucg_ctx_synchronize", "ucg_ctx_set_units", "ucg_ctx_set_option", "ucg_selftest_div",
     "ucg_pair_create", "ucg_pair_create_host", "ucg_pair_last_error", "ucg_pair_destroy", "ucg_pair_settings", "ucg_pair_coeff", "ucg_pair_init",
     "ucg_pair_cut", "ucg_pair_cutforce", "ucg_pair_single", "ucg_pair_table_count",
     "ucg_pair_table_params", "ucg_pair_table_array", "ucg_pair_tabindex", "ucg_pair_compute",
@@ -75,6 +75,8 @@ def lib():
     L.ucg_ctx_set_stream.argtypes = [vp, vp]
     L.ucg_ctx_synchronize.argtypes = [vp]
     L.ucg_ctx_set_units.argtypes = [vp, C.c_double, C.c_double, C.c_double, C.c_double, c_double_p]
+    L.ucg_ctx_set_option.argtypes = [vp, C.c_char_p, C.c_int]
+    L.ucg_selftest_div.argtypes = [vp, C.c_double, C.c_longlong, C.c_int, c_ll_p]
     L.ucg_pair_create.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.ucg_pair_create_host.argtypes = [C.c_int, C.c_double, C.POINTER(vp)]
     L.ucg_pair_last_error.argtypes = [vp]
@@ -181,6 +183,14 @@ class Context:
     def set_units(self, boltz, ftm2v, mvv2e, dt, special_lj=(1.0, 1.0, 1.0, 1.0)):
         s = _f64(special_lj)
         self.chk(self.L.ucg_ctx_set_units(self.h, boltz, ftm2v, mvv2e, dt, _dp(s)))
+
+    def set_option(self, name, value):
+        self.chk(self.L.ucg_ctx_set_option(self.h, name.encode(), int(value)))
+
+    def selftest_div(self, b, seed, n):
+        m = C.c_longlong(0)
+        self.chk(self.L.ucg_selftest_div(self.h, float(b), int(seed), int(n), C.byref(m)))
+        return m.value
 
     def set_stream(self, stream_ptr):
         self.chk(self.L.ucg_ctx_set_stream(self.h, C.c_void_p(stream_ptr) if stream_ptr else None))

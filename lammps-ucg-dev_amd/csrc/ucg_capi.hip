@@ -352,7 +352,37 @@ int ucg_pair_init(ucg_pair *p, int ntypes, double T)
     D.mu = p->d_mu.get();
     D.prior_type = p->d_prior.get();
     D.kT = M.kT;
+    D.rkT = 1.0 / M.kT;
     for (int i = 0; i < 4; i++) D.special_lj[i] = ctx->special_lj[i];
+    {
+      // FAST kernels: same arithmetic, less work (see ucg_pair.hip).  Conditions checked here.
+      bool fast = true;
+      for (int d = 1; d < ntab; d++)
+        if (std::memcmp(&par[(size_t) d], &par[0], sizeof(double4)) != 0) fast = false;
+      for (int i = 0; i < 4; i++)
+        if (ctx->special_lj[i] != 1.0) fast = false;
+      unsigned long long kb;
+      std::memcpy(&kb, &M.kT, sizeof kb);
+      const unsigned long long mant = kb & 0xFFFFFFFFFFFFFull, ex = (kb >> 52) & 0x7FF;
+      if (mant == 0xFFFFFFFFFFFFFull || ex < 1023 - 200 || ex > 1023 + 200 || (kb >> 63)) fast = false;
+      if (ctx->force_generic_kernels) fast = false;
+      D.fast = fast ? 1 : 0;
+      D.fast_stride = 2 * ntab + 1;
+      const size_t nslots = (size_t) tl * D.fast_stride;
+      std::vector<double2> tf(nslots + 2, make_double2(0, 0));
+      for (int k = 0; k < tl; k++)
+        for (int d = 0; d < ntab; d++) {
+          const double4 v = tab[(size_t) d * tl + k];
+          tf[(size_t) k * D.fast_stride + 2 * d] = make_double2(v.x, v.y);
+          tf[(size_t) k * D.fast_stride + 2 * d + 1] = make_double2(v.z, v.w);
+        }
+      p->d_tab_fast.reserve((nslots + 2) / 2 + 1);
+      h2d(ctx, (double2 *) p->d_tab_fast.get(), tf.data(), nslots + 2);
+      sync(ctx);
+      D.tab_fast = p->d_tab_fast.get();
+      const size_t bytes = fast ? ((nslots + 1) / 2) * sizeof(double4) : (size_t) ntab * tl * sizeof(double4);
+      D.tab_in_lds = (bytes <= 152 * 1024) ? 1 : 0;
+    }
     if (M.style == STYLE_BETHE && M.prior_flag == PRIOR_CHEMPOT_NOISE)
       return fail(ctx, UCG_ERR_UNSUPPORTED,
                   "prior chemical_potential noise draws RanMars inside the neighbour loop in list order "
@@ -898,6 +928,33 @@ int ucg_ranmars_fill(ucg_ctx *ctx, int seed, long long skip, int n, double *out)
     sync(ctx);
     return UCG_OK;
   });
+}
+
+int ucg_selftest_div(ucg_ctx *ctx, double b, long long seed, int n, long long *mismatches)
+{
+  if (!ctx || !mismatches || n < 0) return UCG_ERR_INVALID;
+  return guarded(ctx, [&]() -> int {
+    DevBuf<unsigned long long> d;
+    d.reserve(2);
+    UCG_HIP(hipMemsetAsync(d.get(), 0, sizeof(unsigned long long), ctx->stream));
+    UCG_HIP(launch_selftest_div(b, (unsigned long long) seed, n, d.get(), ctx->stream));
+    unsigned long long h = 0;
+    d2h(ctx, &h, d.get(), 1);
+    sync(ctx);
+    *mismatches = (long long) h;
+    return UCG_OK;
+  });
+}
+
+int ucg_ctx_set_option(ucg_ctx *ctx, const char *name, int value)
+{
+  if (!ctx || !name) return UCG_ERR_INVALID;
+  if (std::strcmp(name, "generic_kernels") == 0) {
+    ctx->force_generic_kernels = value != 0;
+    return UCG_OK;
+  }
+  ctx->err = std::string("unknown option ") + name;
+  return UCG_ERR_INVALID;
 }
 
 /* ------------------------------------------------------------- measurement */

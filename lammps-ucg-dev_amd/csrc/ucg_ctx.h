@@ -92,6 +92,7 @@ struct ucg_ctx {
   std::string err;
   double boltz = 1, ftm2v = 1, mvv2e = 1, dt = 0.005;
   double special_lj[4] = {1, 1, 1, 1};
+  bool force_generic_kernels = false;  // option "generic_kernels": never pick the FAST variants
 
   // atoms
   int nlocal = 0, nghost = 0, ntypes = 0;
@@ -136,7 +137,7 @@ struct ucg_pair {
   ucg::PairModel model;
   ucg::PairDev dev{};
   bool uploaded = false;
-  ucg::DevBuf<double4> d_tab, d_tabpar;
+  ucg::DevBuf<double4> d_tab, d_tabpar, d_tab_fast;
   ucg::DevBuf<int> d_pairtab;
   ucg::DevBuf<double> d_cutsq, d_mu, d_prior;
   ucg::DevBuf<int> d_err;

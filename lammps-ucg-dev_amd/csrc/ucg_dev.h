@@ -28,12 +28,16 @@ struct PairDev {
   int tab_in_lds;      // 1: the kernels stage all tables in LDS
   int pseudo_flag, prior_flag, method_flag;
   const double4 *tab;     // [ntab * tablength]
+  const double4 *tab_fast;  // FAST layout: [tablength][2*ntab+1] 16-byte slots (see ucg_pair.hip)
+  int fast_stride;        // 2*ntab+1
   const double4 *tabpar;  // [ntab] {innersq, delta, invdelta, deltasq6}
   const int *pairtab;     // [(n_actual+1)^2 * 4] table of (ti, tj, a, b)
   const double *cutsq;    // [(n_actual+1)^2]  cutsq[itype][jtype] as the reference indexes it
   const double *mu;       // [(n_actual+1)*2]  chemical potential of state s of actual type t
   const double *prior_type;  // [(n_actual+1)*2]
   double kT;
+  double rkT;          // RN(1/kT), used by the FAST kernels' exact division
+  int fast;            // 1: one shared r^2 grid, all special_lj == 1, kT usable for div_by_const
   double special_lj[4];
 };
 

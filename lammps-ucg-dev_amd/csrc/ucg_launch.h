@@ -15,6 +15,8 @@ int pair_gather_blocks(int nlocal);
 hipError_t launch_pair_gather(const PairDev &P, const AtomsDev &A, const ListDev &L, bool ev,
                               double *evpart, double *evout, int *errflag, hipStream_t st);
 
+hipError_t launch_selftest_div(double b, unsigned long long seed, int n, unsigned long long *d_mismatches, hipStream_t st);
+
 // ---- ucg_fix.hip
 struct LangevinDev {
   const double *gfactor1, *gfactor2;  // [ntypes+1]
@@ -29,7 +31,6 @@ hipError_t launch_lambda_ke(const AtomsDev &A, int groupbit, double mvv2e, doubl
 hipError_t launch_ucgstate(const AtomsDev &A, int ld_flag, int mc_flag, double mc_rate,
                            const unsigned int *draws, hipStream_t st);
 hipError_t launch_force_clear(const AtomsDev &A, hipStream_t st);
-hipError_t launch_state_count(const AtomsDev &A, double *part, double *out, hipStream_t st);
 
 // ---- ucg_ranmars.hip : exact block-parallel RANMAR
 struct RanMarsDev {

@@ -11,7 +11,8 @@
 //   cutneigh; (3) sort owned beads by (bin, tag); (4) ghosts = periodic images that fall in
 //   the extended box, sorted by (bin, tag, shift code); (5) full-list rows in stencil order
 //   (dz, dy, dx ascending), owned beads of a bin before its ghosts, kept when
-//   rsq < cutneigh^2, bit 29 = (tag_row <= tag_neighbour).
+//   rsq < cutneigh^2, bit 29 = (tag_row <= tag_neighbour); each row stably partitioned into
+//   four build-time distance classes (inside the force cutoff, then thirds of the skin).
 // Everything is deterministic: unique sort keys, no order-dependent atomics in outputs.
 #include <hipcub/hipcub.hpp>
 
@@ -30,7 +31,7 @@ struct Domain {
   int nbin[3] = {1, 1, 1}, sten[3] = {0, 0, 0}, nbins = 1;
   double bboxlo[3], bboxhi[3], binsize[3], bininv[3];
   int ago = 0;
-  DevBuf<int> bin_of, cell_o0, cell_o1, cell_g0, cell_g1, ghost_src, ghost_code, counter, rowcount;
+  DevBuf<int> bin_of, cell_o0, cell_o1, cell_g0, cell_g1, ghost_src, ghost_code, counter, rowclass;
   DevBuf<double4> xhold, tmp4;
   DevBuf<unsigned long long> keys_in, keys_out;
   DevBuf<int> vals_in, vals_out, tmpi, cand_src, cand_code;
@@ -43,6 +44,7 @@ struct DomainDev {
   double bboxlo[3], bboxhi[3], bininv[3];
   int nbin[3], sten[3];
   double cutneighsq, triggersq;
+  double cls_sq[3];  // build-time distance classes of a row: force cutoff, then thirds of the skin
 };
 
 void domain_destroy(ucg_ctx *ctx)
@@ -71,6 +73,10 @@ DomainDev make_dev(const Domain &D)
   }
   d.cutneighsq = D.cutneigh * D.cutneigh;
   d.triggersq = 0.25 * D.skin * D.skin;
+  for (int c = 0; c < 3; c++) {
+    const double rc = D.cutforce + D.skin * c / 3.0;
+    d.cls_sq[c] = rc * rc;
+  }
   return d;
 }
 
@@ -199,12 +205,14 @@ __global__ __launch_bounds__(NB) void k_cell_ranges(int n, int offset, const int
   if (i == n - 1 || bin_of[offset + i + 1] != b) cell1[b] = offset + i + 1;
 }
 
-// full-list rows; FILL=false only counts
+// full-list rows.  FILL=false counts the row and its four build-time distance classes
+// (class 0: inside the force cutoff; 1..3: thirds of the skin shell); FILL=true writes the
+// entries, each class contiguous and in stencil-traversal order (stable partition).
 template <bool FILL>
 __global__ __launch_bounds__(NB) void k_build_rows(const DomainDev D, int nlocal, const double4 *pos4, const int *tag,
                                                   const int *bin_of, const int *cell_o0, const int *cell_o1,
-                                                  const int *cell_g0, const int *cell_g1, int *rowcount, int *neigh,
-                                                  int pitch)
+                                                  const int *cell_g0, const int *cell_g1, int *rowcount, int *rowclass,
+                                                  int *neigh, int pitch)
 {
   const int k = blockIdx.x * NB + threadIdx.x;
   if (k >= nlocal) return;
@@ -212,7 +220,12 @@ __global__ __launch_bounds__(NB) void k_build_rows(const DomainDev D, int nlocal
   const int tk = tag[k];
   const int b = bin_of[k];
   const int bx = b % D.nbin[0], by = (b / D.nbin[0]) % D.nbin[1], bz = b / (D.nbin[0] * D.nbin[1]);
-  int cnt = 0;
+  int p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+  if (FILL) {
+    p1 = rowclass[k];
+    p2 = p1 + rowclass[pitch + k];
+    p3 = p2 + rowclass[2 * pitch + k];
+  }
   for (int dz = -D.sten[2]; dz <= D.sten[2]; dz++) {
     const int cz = bz + dz;
     if (cz < 0 || cz >= D.nbin[2]) continue;
@@ -234,18 +247,27 @@ __global__ __launch_bounds__(NB) void k_build_rows(const DomainDev D, int nlocal
             const double delz = pk.z - pm.z;
             const double rsq = delx * delx + dely * dely + delz * delz;
             if (rsq < D.cutneighsq) {
+              int slot;
+              if (rsq < D.cls_sq[0]) slot = p0++;
+              else if (rsq < D.cls_sq[1]) slot = p1++;
+              else if (rsq < D.cls_sq[2]) slot = p2++;
+              else slot = p3++;
               if (FILL) {
                 const int orient = (tk <= tag[m]) ? 1 : 0;
-                neigh[(size_t) cnt * pitch + k] = m | (orient << UCG_ORIENT_BIT);
+                neigh[(size_t) slot * pitch + k] = m | (orient << UCG_ORIENT_BIT);
               }
-              cnt++;
             }
           }
         }
       }
     }
   }
-  if (!FILL) rowcount[k] = cnt;
+  if (!FILL) {
+    rowcount[k] = p0 + p1 + p2 + p3;
+    rowclass[k] = p0;
+    rowclass[pitch + k] = p1;
+    rowclass[2 * pitch + k] = p2;
+  }
 }
 
 __global__ __launch_bounds__(NB) void k_store_xhold(int n, const double4 *pos4, double4 *xhold)
@@ -392,9 +414,10 @@ void rebuild(ucg_ctx *ctx)
   // (5) rows: count, size, fill
   const int pitch = ((n + 63) / 64) * 64;
   ctx->numneigh.reserve((size_t) pitch);
+  D.rowclass.reserve((size_t) pitch * 3);
   hipLaunchKernelGGL(k_build_rows<false>, dim3(nblk(n)), dim3(NB), 0, st, dd, n, ctx->pos4.get(), ctx->tag.get(),
                      D.bin_of.get(), D.cell_o0.get(), D.cell_o1.get(), D.cell_g0.get(), D.cell_g1.get(),
-                     ctx->numneigh.get(), nullptr, pitch);
+                     ctx->numneigh.get(), D.rowclass.get(), nullptr, pitch);
   // max and total row length (hipcub reductions into counter[0..1] would need two temp buffers; rows are
   // rebuilt rarely, so a small host pass over the counts is acceptable here)
   std::vector<int> counts((size_t) n);
@@ -409,7 +432,7 @@ void rebuild(ucg_ctx *ctx)
   ctx->neigh.reserve((size_t) pitch * (size_t) (maxrow > 0 ? maxrow : 1));
   hipLaunchKernelGGL(k_build_rows<true>, dim3(nblk(n)), dim3(NB), 0, st, dd, n, ctx->pos4.get(), ctx->tag.get(),
                      D.bin_of.get(), D.cell_o0.get(), D.cell_o1.get(), D.cell_g0.get(), D.cell_g1.get(), nullptr,
-                     ctx->neigh.get(), pitch);
+                     D.rowclass.get(), ctx->neigh.get(), pitch);
   ctx->list_inum = n;
   ctx->list_pitch = pitch;
   ctx->list_maxrow = maxrow;

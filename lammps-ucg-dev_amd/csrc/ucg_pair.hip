@@ -16,6 +16,14 @@
 // of 1024 lanes per CU then owns the whole LDS and 4 waves per SIMD hide the
 // gather latency.  Tables that do not fit are read through L1/L2.
 //
+// FAST variants (chosen on the host when every table shares one r^2 grid, all
+// special_lj are 1 and kT is a usable divisor) do the same arithmetic with less
+// work: the knot index and the interpolation basis are computed once per pair
+// instead of once per table (identical inputs give identical bits), the
+// multiplications by factor_lj = 1.0 are dropped (x*1.0 == x), and u/kT uses a
+// host-computed reciprocal with two fused residual corrections, which returns the
+// correctly rounded quotient (Markstein): same bits as the IEEE division.
+//
 // Compiled with -ffp-contract=off: every product and sum below rounds exactly
 // where the reference's scalar x86-64 code rounds.
 #include "ucg_dev.h"
@@ -33,10 +41,20 @@ struct Quad {
   double f00, f01, f10, f11;
 };
 
-// one table lookup; the open-coded block UCG/pair_table_ucgld.cpp:436-482
-template <int TS, typename TabPtr>
-__device__ __forceinline__ void table_eval(TabPtr tab, const double4 par, const int tlm1,
-                                           const double rsq, double &fval, double &eval, int &err)
+// correctly rounded a / b from y = RN(1/b): q0 = RN(a*y), then two FMA residual steps.
+// Exact for normal-range operands when b's significand is not all ones (checked on the host).
+__device__ __forceinline__ double div_by_const(const double a, const double b, const double y)
+{
+  if (!(fabs(a) > 1.0e-280 && fabs(a) < 1.0e280)) return a / b;
+  double q = a * y;
+  double r = fma(-b, q, a);
+  q = fma(r, y, q);
+  r = fma(-b, q, a);
+  return fma(r, y, q);
+}
+
+// knot index of rsq on one table's r^2 grid (the shared part of UCG/pair_table_ucgld.cpp:436-459)
+__device__ __forceinline__ int grid_locate(const double4 par, const int tlm1, const double rsq, int &err)
 {
   if (rsq < par.x) err |= 1;
   int it = static_cast<int>((rsq - par.x) * par.z);
@@ -45,26 +63,125 @@ __device__ __forceinline__ void table_eval(TabPtr tab, const double4 par, const 
     it = tlm1 - 1;
   }
   if (it < 0) it = 0;
-  if (TS == 0) {  // LOOKUP
+  return it;
+}
+
+struct Basis {
+  double a, b, a3, b3;  // SPLINE: a, b, a^3-a, b^3-b ; LINEAR: b = fraction
+};
+
+template <int TS>
+__device__ __forceinline__ Basis grid_basis(const double4 par, const int it, const double rsq)
+{
+  Basis B;
+  B.a = B.b = B.a3 = B.b3 = 0.0;
+  if (TS != 0) {
+    const double rsq_it = par.x + it * par.y;  // == tb->rsq[it] bit for bit (:1159,:1196)
+    B.b = (rsq - rsq_it) * par.z;
+    if (TS == 2) {
+      B.a = 1.0 - B.b;
+      B.a3 = B.a * B.a * B.a - B.a;
+      B.b3 = B.b * B.b * B.b - B.b;
+    }
+  }
+  return B;
+}
+
+// (f/r, e) of one table at a located knot; UCG/pair_table_ucgld.cpp:440-481
+template <int TS, typename TabPtr>
+__device__ __forceinline__ void knot_eval(TabPtr tab, const double deltasq6, const int it, const Basis &B,
+                                          double &fval, double &eval)
+{
+  if (TS == 0) {  // LOOKUP {e, f, -, -}
     const double4 k = tab[it];
     eval = k.x;
     fval = k.y;
-  } else if (TS == 1) {  // LINEAR  {e, de, f, df}
+  } else if (TS == 1) {  // LINEAR {e, de, f, df}
     const double4 k = tab[it];
-    const double rsq_it = par.x + it * par.y;
-    const double fraction = (rsq - rsq_it) * par.z;
-    fval = k.z + fraction * k.w;
-    eval = k.x + fraction * k.y;
-  } else {  // SPLINE  {e, f, e2, f2}
+    fval = k.z + B.b * k.w;
+    eval = k.x + B.b * k.y;
+  } else {  // SPLINE {e, f, e2, f2}
     const double4 k0 = tab[it];
     const double4 k1 = tab[it + 1];
-    const double rsq_it = par.x + it * par.y;
-    const double b = (rsq - rsq_it) * par.z;
-    const double a = 1.0 - b;
-    const double a3 = a * a * a - a;
-    const double b3 = b * b * b - b;
-    fval = a * k0.y + b * k1.y + (a3 * k0.w + b3 * k1.w) * par.w;
-    eval = a * k0.x + b * k1.x + (a3 * k0.z + b3 * k1.z) * par.w;
+    fval = B.a * k0.y + B.b * k1.y + (B.a3 * k0.w + B.b3 * k1.w) * deltasq6;
+    eval = B.a * k0.x + B.b * k1.x + (B.a3 * k0.z + B.b3 * k1.z) * deltasq6;
+  }
+}
+
+// FAST layout: knot-major, the tables of one knot side by side, each {e,f | e2,f2} (or the
+// LINEAR / LOOKUP quartet) as two 16-byte slots, plus ONE padding slot per knot so that the
+// knot stride (2*ntab+1 slots) is odd: a random knot index then lands on any of the 16
+// ds_read_b128 bank slots, instead of only 8 of them with a 32-byte stride.
+template <int TS>
+__device__ __forceinline__ void knot_eval_fast(const double2 *rec, const int stride, const double deltasq6,
+                                               const Basis &B, double &fval, double &eval)
+{
+  if (TS == 0) {
+    const double2 k = rec[0];
+    eval = k.x;
+    fval = k.y;
+  } else if (TS == 1) {
+    const double2 ka = rec[0], kb = rec[1];  // {e, de}, {f, df}
+    fval = kb.x + B.b * kb.y;
+    eval = ka.x + B.b * ka.y;
+  } else {
+    const double2 k0a = rec[0], k0b = rec[1];            // {e, f}, {e2, f2} at knot it
+    const double2 k1a = rec[stride], k1b = rec[stride + 1];  // ... at knot it+1
+    fval = B.a * k0a.y + B.b * k1a.y + (B.a3 * k0b.y + B.b3 * k1b.y) * deltasq6;
+    eval = B.a * k0a.x + B.b * k1a.x + (B.a3 * k0b.x + B.b3 * k1b.x) * deltasq6;
+  }
+}
+
+// own-frame quad: u[a][b] = table(F(tk,a), F(tm,b)); equals the reference's u[b][a] when the
+// row owner is the pair's "j" (tabindex is symmetric after init_one)
+template <int TS, bool FAST, typename TabPtr>
+__device__ __forceinline__ void eval_quad(TabPtr tab, const double4 *s_par, const int *pt, const int tablength,
+                                          const int tlm1, const int fast_stride, const double rsq,
+                                          const double factor_lj, Quad &q, int &err)
+{
+  const int t00 = pt[0], t01 = pt[1], t10 = pt[2], t11 = pt[3];
+  if (FAST) {
+    const double4 par = s_par[0];
+    const int it = grid_locate(par, tlm1, rsq, err);
+    const Basis B = grid_basis<TS>(par, it, rsq);
+    const double2 *rec = reinterpret_cast<const double2 *>(tab) + it * fast_stride;
+    knot_eval_fast<TS>(rec + 2 * t00, fast_stride, par.w, B, q.f00, q.u00);
+    knot_eval_fast<TS>(rec + 2 * t01, fast_stride, par.w, B, q.f01, q.u01);
+    if (t10 == t01) {
+      q.f10 = q.f01;
+      q.u10 = q.u01;
+    } else {
+      knot_eval_fast<TS>(rec + 2 * t10, fast_stride, par.w, B, q.f10, q.u10);
+    }
+    knot_eval_fast<TS>(rec + 2 * t11, fast_stride, par.w, B, q.f11, q.u11);
+  } else {
+    {
+      const double4 par = s_par[t00];
+      const int it = grid_locate(par, tlm1, rsq, err);
+      knot_eval<TS>(tab + t00 * tablength, par.w, it, grid_basis<TS>(par, it, rsq), q.f00, q.u00);
+    }
+    {
+      const double4 par = s_par[t01];
+      const int it = grid_locate(par, tlm1, rsq, err);
+      knot_eval<TS>(tab + t01 * tablength, par.w, it, grid_basis<TS>(par, it, rsq), q.f01, q.u01);
+    }
+    if (t10 == t01) {
+      q.f10 = q.f01;
+      q.u10 = q.u01;
+    } else {
+      const double4 par = s_par[t10];
+      const int it = grid_locate(par, tlm1, rsq, err);
+      knot_eval<TS>(tab + t10 * tablength, par.w, it, grid_basis<TS>(par, it, rsq), q.f10, q.u10);
+    }
+    {
+      const double4 par = s_par[t11];
+      const int it = grid_locate(par, tlm1, rsq, err);
+      knot_eval<TS>(tab + t11 * tablength, par.w, it, grid_basis<TS>(par, it, rsq), q.f11, q.u11);
+    }
+    q.f00 = factor_lj * q.f00; q.u00 *= factor_lj;
+    q.f01 = factor_lj * q.f01; q.u01 *= factor_lj;
+    q.f10 = factor_lj * q.f10; q.u10 *= factor_lj;
+    q.f11 = factor_lj * q.f11; q.u11 *= factor_lj;
   }
 }
 
@@ -98,7 +215,7 @@ __device__ __forceinline__ int xcd_chunk(int b, int nb)
   return (b & 7) * per + (b >> 3);
 }
 
-template <int STYLE, int TS, bool EV, bool LDS_TAB>
+template <int STYLE, int TS, bool EV, bool LDS_TAB, bool FAST>
 __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, const AtomsDev A,
                                                            const ListDev Lst, double *evpart,
                                                            int *errflag)
@@ -110,14 +227,15 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
   __shared__ int s_pairtab[(UCG_MAX_ACTUAL + 1) * (UCG_MAX_ACTUAL + 1) * 4];
   __shared__ double s_cutsq[(UCG_MAX_ACTUAL + 1) * (UCG_MAX_ACTUAL + 1)];
 
-  const int ntabent = P.ntab * P.tablength;
+  // in double4 units; the FAST layout is tablength * (2*ntab+1) 16-byte slots
+  const int ntabent = FAST ? (P.tablength * P.fast_stride + 1) / 2 : P.ntab * P.tablength;
   {
     const int na1sq = (P.n_actual + 1) * (P.n_actual + 1);
     for (int t = threadIdx.x; t < P.ntab; t += blockDim.x) s_par[t] = P.tabpar[t];
     for (int t = threadIdx.x; t < na1sq * 4; t += blockDim.x) s_pairtab[t] = P.pairtab[t];
     for (int t = threadIdx.x; t < na1sq; t += blockDim.x) s_cutsq[t] = P.cutsq[t];
     if (LDS_TAB)
-      for (int t = threadIdx.x; t < ntabent; t += blockDim.x) s_tab[t] = P.tab[t];
+      for (int t = threadIdx.x; t < ntabent; t += blockDim.x) s_tab[t] = (FAST ? P.tab_fast : P.tab)[t];
     __syncthreads();
   }
 
@@ -125,7 +243,7 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
   const int k = chunk * PAIR_BLOCK + threadIdx.x;
   const int nlocal = A.nlocal;
   const int na1 = P.n_actual + 1;
-  const double kT = P.kT;
+  const double kT = P.kT, rkT = P.rkT;
   double ev[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int err = 0;
 
@@ -135,7 +253,7 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
     const int tk = UCG_META_TYPE(mk);
     const double lk = pk.w;
     const int n = Lst.numneigh[k];
-    const int *row = Lst.neigh + k;
+    const int *rp = Lst.neigh + k;
     const size_t pitch = (size_t) Lst.pitch;
 
     double fx = 0.0, fy = 0.0, fz = 0.0, uf = 0.0, s0 = 0.0, s1 = 0.0;
@@ -176,14 +294,23 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
       }
     }
 
+    // software pipeline: the gather of entry e+1 is in flight while entry e is evaluated
+    int ent = (n > 0) ? rp[0] : 0;
+    double4 pm = A.pos4[ent & 0x1FFFFFFF];
+    int mm = A.meta[ent & 0x1FFFFFFF];
     for (int e = 0; e < n; e++) {
-      const int ent = row[(size_t) e * pitch];
+      rp += pitch;
+      const int ent_n = (e + 1 < n) ? rp[0] : ent;
+      const double4 pm_n = A.pos4[ent_n & 0x1FFFFFFF];
+      const int mm_n = A.meta[ent_n & 0x1FFFFFFF];
+
       const int m = ent & 0x1FFFFFFF;
       const bool k_is_i = (ent >> 29) & 1;
-      const int sb = (ent >> 30) & 3;
-      const double factor_lj = sb == 0 ? P.special_lj[0] : sb == 1 ? P.special_lj[1] : sb == 2 ? P.special_lj[2] : P.special_lj[3];
-      const double4 pm = A.pos4[m];
-      const int mm = A.meta[m];
+      double factor_lj = 1.0;
+      if (!FAST) {
+        const int sb = (ent >> 30) & 3;
+        factor_lj = sb == 0 ? P.special_lj[0] : sb == 1 ? P.special_lj[1] : sb == 2 ? P.special_lj[2] : P.special_lj[3];
+      }
       const int tm = UCG_META_TYPE(mm);
       const int sm = UCG_META_STATE(mm);
       const double lm = pm.w;
@@ -192,44 +319,22 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
       const double dz = pk.z - pm.z;
       const double rsq = dx * dx + dy * dy + dz * dz;
       if (rsq < s_cutsq[tk * na1 + tm]) {
-        // own-frame quad: u[a][b] = table(F(tk,a), F(tm,b)); equals the reference's
-        // u[b][a] when k is the pair's "j" (tabindex is symmetric after init_one)
         const int *pt = s_pairtab + (tk * na1 + tm) * 4;
         Quad q;
-        {
-          const int t00 = pt[0], t01 = pt[1], t10 = pt[2], t11 = pt[3];
-          if (LDS_TAB) {
-            table_eval<TS>(s_tab + t00 * P.tablength, s_par[t00], P.tlm1, rsq, q.f00, q.u00, err);
-            table_eval<TS>(s_tab + t01 * P.tablength, s_par[t01], P.tlm1, rsq, q.f01, q.u01, err);
-            if (t10 == t01) {
-              q.f10 = q.f01;
-              q.u10 = q.u01;
-            } else {
-              table_eval<TS>(s_tab + t10 * P.tablength, s_par[t10], P.tlm1, rsq, q.f10, q.u10, err);
-            }
-            table_eval<TS>(s_tab + t11 * P.tablength, s_par[t11], P.tlm1, rsq, q.f11, q.u11, err);
-          } else {
-            table_eval<TS>(P.tab + t00 * P.tablength, s_par[t00], P.tlm1, rsq, q.f00, q.u00, err);
-            table_eval<TS>(P.tab + t01 * P.tablength, s_par[t01], P.tlm1, rsq, q.f01, q.u01, err);
-            if (t10 == t01) {
-              q.f10 = q.f01;
-              q.u10 = q.u01;
-            } else {
-              table_eval<TS>(P.tab + t10 * P.tablength, s_par[t10], P.tlm1, rsq, q.f10, q.u10, err);
-            }
-            table_eval<TS>(P.tab + t11 * P.tablength, s_par[t11], P.tlm1, rsq, q.f11, q.u11, err);
-          }
-          q.f00 = factor_lj * q.f00; q.u00 *= factor_lj;
-          q.f01 = factor_lj * q.f01; q.u01 *= factor_lj;
-          q.f10 = factor_lj * q.f10; q.u10 *= factor_lj;
-          q.f11 = factor_lj * q.f11; q.u11 *= factor_lj;
-        }
+        if (LDS_TAB) eval_quad<TS, FAST>(s_tab, s_par, pt, P.tablength, P.tlm1, P.fast_stride, rsq, factor_lj, q, err);
+        else eval_quad<TS, FAST>(FAST ? P.tab_fast : P.tab, s_par, pt, P.tablength, P.tlm1, P.fast_stride, rsq, factor_lj, q, err);
 
-        double evdwl, fpair;
+        double evdwl = 0.0, fpair;
         if (STYLE == 0 || P.pseudo_flag == 0) {
           // pseudo-likelihood scores (:492-502): S[k][a] -= u[a][state of the neighbour] / kT
-          s0 -= (sm ? q.u01 : q.u00) / kT;
-          s1 -= (sm ? q.u11 : q.u10) / kT;
+          const double ua = sm ? q.u01 : q.u00, ub = sm ? q.u11 : q.u10;
+          if (FAST) {
+            s0 -= div_by_const(ua, kT, rkT);
+            s1 -= div_by_const(ub, kT, rkT);
+          } else {
+            s0 -= ua / kT;
+            s1 -= ub / kT;
+          }
         }
         if (STYLE == 0) {
           // lambda-bilinear mix (:507-517).  In the reference's orientation the sum is
@@ -238,14 +343,13 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
           const double w11 = lk * lm;
           const double wA = (1. - lk) * lm;  // weight of own-frame (0,1)
           const double wB = (1. - lm) * lk;  // weight of own-frame (1,0)
-          const double eA = wA * q.u01, eB = wB * q.u10;
           const double fA = wA * q.f01, fB = wB * q.f10;
-          if (k_is_i) {
-            fpair = w00 * q.f00 + fA + fB + w11 * q.f11;
-            if (EV) evdwl = w00 * q.u00 + eA + eB + w11 * q.u11;
-          } else {
-            fpair = w00 * q.f00 + fB + fA + w11 * q.f11;
-            if (EV) evdwl = w00 * q.u00 + eB + eA + w11 * q.u11;
+          const double f1st = k_is_i ? fA : fB, f2nd = k_is_i ? fB : fA;
+          fpair = w00 * q.f00 + f1st + f2nd + w11 * q.f11;
+          if (EV) {
+            const double eA = wA * q.u01, eB = wB * q.u10;
+            const double e1st = k_is_i ? eA : eB, e2nd = k_is_i ? eB : eA;
+            evdwl = w00 * q.u00 + e1st + e2nd + w11 * q.u11;
           }
           uf -= lm * (q.u11 - q.u01) + (1. - lm) * (q.u10 - q.u00);
         } else {
@@ -330,6 +434,9 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
           ev[6] += 0.5 * (dy * dz * fpair);
         }
       }
+      ent = ent_n;
+      pm = pm_n;
+      mm = mm_n;
     }
     if (STYLE == 0) {
       A.frc4[k] = make_double4(fx, fy, fz, uf);
@@ -355,14 +462,36 @@ __global__ void k_ev_final(const double *part, int nblocks, double *out)
   }
 }
 
+// exactness check of div_by_const against the IEEE division on random operands
+__global__ void k_selftest_div(const double b, const double y, const unsigned long long seed, const int n,
+                               unsigned long long *mismatches)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  // splitmix64 -> a double with a random sign, exponent in [-40, 40] and random significand
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long) (i + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  const unsigned long long mant = z & 0xFFFFFFFFFFFFFull;
+  const unsigned long long ex = 1023ull - 40ull + ((z >> 52) % 81ull);
+  const unsigned long long sg = (z >> 63) << 63;
+  const double a = __builtin_bit_cast(double, sg | (ex << 52) | mant);
+  const double q1 = a / b;
+  const double q2 = div_by_const(a, b, y);
+  if (__builtin_bit_cast(unsigned long long, q1) != __builtin_bit_cast(unsigned long long, q2)) atomicAdd(mismatches, 1ull);
+}
+
 template <int STYLE, int TS>
 hipError_t launch_style_ts(const PairDev &P, const AtomsDev &A, const ListDev &L, bool ev, double *evpart,
                            int *errflag, hipStream_t st, int nblocks)
 {
-  const size_t ldsbytes = P.tab_in_lds ? (size_t) P.ntab * P.tablength * sizeof(double4) : 0;
-#define UCG_LAUNCH(EVF, LDSF)                                                                          \
+  const size_t tabbytes = P.fast ? ((size_t) (P.tablength * P.fast_stride + 1) / 2) * sizeof(double4)
+                                 : (size_t) P.ntab * P.tablength * sizeof(double4);
+  const size_t ldsbytes = P.tab_in_lds ? tabbytes : 0;
+#define UCG_LAUNCH(EVF, LDSF, FASTF)                                                                   \
   do {                                                                                                 \
-    auto kern = k_pair_gather<STYLE, TS, EVF, LDSF>;                                                   \
+    auto kern = k_pair_gather<STYLE, TS, EVF, LDSF, FASTF>;                                            \
     if (ldsbytes > 48 * 1024) {                                                                        \
       hipError_t e = hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                          (int) ldsbytes);                                              \
@@ -370,12 +499,16 @@ hipError_t launch_style_ts(const PairDev &P, const AtomsDev &A, const ListDev &L
     }                                                                                                  \
     hipLaunchKernelGGL(kern, dim3(nblocks), dim3(PAIR_BLOCK), ldsbytes, st, P, A, L, evpart, errflag); \
   } while (0)
-  if (P.tab_in_lds) {
-    if (ev) UCG_LAUNCH(true, true);
-    else UCG_LAUNCH(false, true);
-  } else {
-    if (ev) UCG_LAUNCH(true, false);
-    else UCG_LAUNCH(false, false);
+  const int sel = (P.tab_in_lds ? 4 : 0) | (ev ? 2 : 0) | (P.fast ? 1 : 0);
+  switch (sel) {
+    case 0: UCG_LAUNCH(false, false, false); break;
+    case 1: UCG_LAUNCH(false, false, true); break;
+    case 2: UCG_LAUNCH(true, false, false); break;
+    case 3: UCG_LAUNCH(true, false, true); break;
+    case 4: UCG_LAUNCH(false, true, false); break;
+    case 5: UCG_LAUNCH(false, true, true); break;
+    case 6: UCG_LAUNCH(true, true, false); break;
+    default: UCG_LAUNCH(true, true, true); break;
   }
 #undef UCG_LAUNCH
   return hipGetLastError();
@@ -410,6 +543,12 @@ hipError_t launch_pair_gather(const PairDev &P, const AtomsDev &A, const ListDev
     e = hipGetLastError();
   }
   return e;
+}
+
+hipError_t launch_selftest_div(double b, unsigned long long seed, int n, unsigned long long *d_mismatches, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_selftest_div, dim3((n + 255) / 256), dim3(256), 0, st, b, 1.0 / b, seed, n, d_mismatches);
+  return hipGetLastError();
 }
 
 }  // namespace ucg

@@ -45,9 +45,12 @@ def write_table_file(path: str, sections: dict, n: int = 2000, rlo: float = 0.6,
     ``sections`` maps keyword -> (eps, extra_exp).  ``rmode`` is "R" (uniform in r) or
     "RSQ" (uniform in r^2), written on the parameter line as the reference expects.
     """
+    rlo0 = rlo
     with open(path, "w") as fh:
         fh.write("# UCG synthetic LJ-like tables (generated)\n\n")
-        for key, (eps, extra) in sections.items():
+        for key, spec in sections.items():
+            eps, extra = spec[0], spec[1]
+            rlo = spec[2] if len(spec) > 2 and spec[2] is not None else rlo0
             if rmode == "R":
                 r = rlo + (rhi - rlo) * np.arange(n) / (n - 1)
             elif rmode == "RSQ":
@@ -118,14 +121,14 @@ class Deck:
 def make_deck(workdir: str, tabstyle: str = "spline", tablength: int = 1024, mu=(0.0, 0.5),
               density=None, entropy: bool = False, eps=None, extra11: float = 0.0, n_file: int = 2000,
               rlo: float = 0.6, rhi: float = 2.5, cut: float = 2.5, rmode: str = "R",
-              extra_keywords=()) -> Deck:
+              extra_keywords=(), rlo11=None) -> Deck:
     os.makedirs(workdir, exist_ok=True)
     eps = dict(DEFAULT_EPS if eps is None else eps)
     sections = {
         "UCG_00": (eps["00"], 0.0),
         "UCG_01": (eps["01"], 0.0),
         "UCG_10": (eps["10"], 0.0),
-        "UCG_11": (eps["11"], extra11),
+        "UCG_11": (eps["11"], extra11, rlo11),
     }
     tfile = write_table_file(os.path.join(workdir, "ucg_lj.table"), sections, n_file, rlo, rhi, rmode)
     cfile = write_state_settings(os.path.join(workdir, "ucg.conf"), mu, density, entropy)

@@ -71,6 +71,11 @@ const double *orc_pair_dbl_array(const orc_pair *p, const char *name, int *n)
   return NULL;
 }
 
+void orc_pair_set_special_lj(orc_pair *p, const double *s)
+{
+  for (int i = 0; i < 4; i++) p->special_lj[i] = s[i];
+}
+
 void orc_pair_set_compat(orc_pair *p, int flags) { p->density_proximity_as_shipped = flags & 1; }
 
 void orc_fix_langevin_get(const orc_fix_langevin *fx, double *out)

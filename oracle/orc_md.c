@@ -16,7 +16,9 @@
  *                falls in the extended box, sorted by (bin, tag, shift code);
  *            (5) full list rows: stencil bins in (dz,dy,dx) ascending order, owned
  *                atoms of the bin then ghost atoms of the bin, entry kept when
- *                rsq < cutneigh^2; bit 29 = (tag_k < tag_m) or equal tags.
+ *                rsq < cutneigh^2; bit 29 = (tag_k <= tag_m); the row is then stably
+ *                partitioned into 4 distance classes (inside the force cutoff, then
+ *                thirds of the skin shell).
  *   decide : every `every` steps, rebuild when any owned atom moved more than
  *            skin/2 since the last build (Neighbor::check_distance form).
  */
@@ -331,8 +333,20 @@ static void build_lists(orc_sim *s)
   const int n = a->nlocal;
   const double cutsq = s->cutneigh * s->cutneigh;
   const double *x = a->x;
-  /* pass 0 counts, pass 1 fills */
+  /* Rows are partitioned by the distance at BUILD time into four classes, each kept in
+     stencil-traversal order: class 0 = inside the force cutoff, classes 1..3 = thirds of the
+     skin shell.  Beads that start inside the cutoff therefore sit at the front of every row
+     and the tail of a row is (at first) all skin: a wavefront whose 64 rows have all run
+     into their skin part skips the pair arithmetic.  The order is part of the canonical
+     summation order, so the CPU and the GPU builders must agree on it. */
+  double cls_sq[3];
+  for (int c = 0; c < 3; c++) {
+    const double rc = s->cutforce + s->skin * c / 3.0;
+    cls_sq[c] = rc * rc;
+  }
+  /* pass 0 counts per class, pass 1 fills */
   long long total = 0;
+  int *ccount = (int *) malloc(sizeof(int) * 4 * (size_t) (n > 0 ? n : 1));
   for (int pass = 0; pass < 2; pass++) {
     if (pass == 1) list_reserve(&s->full, n, total);
     long long pos = 0;
@@ -340,6 +354,12 @@ static void build_lists(orc_sim *s)
       const int b = s->bin_of[k];
       const int bx = b % s->nbin[0], by = (b / s->nbin[0]) % s->nbin[1], bz = b / (s->nbin[0] * s->nbin[1]);
       const long long start = pos;
+      int cnt[4] = {0, 0, 0, 0};
+      long long cpos[4] = {0, 0, 0, 0};
+      if (pass == 1) {
+        cpos[0] = start;
+        for (int c = 1; c < 4; c++) cpos[c] = cpos[c - 1] + ccount[4 * k + c - 1];
+      }
       for (int dz = -s->sten[2]; dz <= s->sten[2]; dz++) {
         const int cz = bz + dz;
         if (cz < 0 || cz >= s->nbin[2]) continue;
@@ -359,10 +379,12 @@ static void build_lists(orc_sim *s)
                 const double delz = x[3 * k + 2] - x[3 * m + 2];
                 const double rsq = delx * delx + dely * dely + delz * delz;
                 if (rsq < cutsq) {
+                  const int rc = (rsq < cls_sq[0]) ? 0 : (rsq < cls_sq[1]) ? 1 : (rsq < cls_sq[2]) ? 2 : 3;
                   if (pass == 1) {
                     const int orient = (a->tag[k] <= a->tag[m]) ? 1 : 0;
-                    s->full.neigh[pos] = m | (orient << ORC_ORIENT_BIT);
+                    s->full.neigh[cpos[rc]++] = m | (orient << ORC_ORIENT_BIT);
                   }
+                  cnt[rc]++;
                   pos++;
                 }
               }
@@ -370,7 +392,9 @@ static void build_lists(orc_sim *s)
           }
         }
       }
-      if (pass == 1) {
+      if (pass == 0) {
+        for (int c = 0; c < 4; c++) ccount[4 * k + c] = cnt[c];
+      } else {
         s->full.ilist[k] = k;
         s->full.first[k] = start;
         s->full.numneigh[k] = (int) (pos - start);
@@ -378,6 +402,7 @@ static void build_lists(orc_sim *s)
     }
     total = pos;
   }
+  free(ccount);
   s->full.inum = n;
 
   /* half list for the reference-order mode: each pair once.  owned-owned: the

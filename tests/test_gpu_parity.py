@@ -177,3 +177,79 @@ def test_fix_hooks_parity(gpu_ctx, pkg, orc, mode):
     assert abs(lt - out[2]) <= 1e-13 * abs(out[2])
     L.orc_fix_langevin_destroy(lang)
     L.orc_fix_ucgstate_destroy(fx)
+
+
+@pytest.mark.parametrize("kT", [1.0, 0.7, 2.4942, 1e-3, 300.0 * 0.0019872067])
+def test_exact_division_by_constant(gpu_ctx, kT):
+    # the FAST kernels' u / kT: reciprocal + two FMA corrections must equal the IEEE quotient
+    assert gpu_ctx.selftest_div(kT, 12345, 4_000_000) == 0
+
+
+@pytest.mark.parametrize("style", ["table_ucgld", "table_ucg_bethe"])
+@pytest.mark.parametrize("tabstyle,tablength,T", [("spline", 1024, 0.7), ("linear", 2048, 1.3), ("lookup", 3000, 1.0)])
+def test_fast_and_generic_kernels_give_the_same_bits(fresh_ctx, pkg, orc, style, tabstyle, tablength, T):
+    ctx = fresh_ctx
+    deck = util.make_deck(tabstyle, tablength)
+    beads = pkg.synth.make_beads(9, seed=55)
+    beads.ucgp = np.clip(np.random.default_rng(2).uniform(size=beads.n), 1e-6, 1 - 1e-6)
+    op = util.oracle_pair(style, deck, T=T)
+    sim = util.oracle_sim(beads, op, mode=1)
+    sim.rebuild()
+    assert sim.compute_forces(1, 1) == 0
+    O = sim.arrays()
+    res = {}
+    for generic in (0, 1):
+        ctx.set_option("generic_kernels", generic)
+        util.upload_from_oracle(ctx, sim, beads)
+        gp = util.gpu_pair(ctx, style, deck, T=T)
+        res[generic] = (gp.compute(1, 1), ctx.atoms_download())
+        gp.check_errors()
+        gp.close()
+    for generic in (0, 1):
+        G = res[generic][1]
+        assert util.bits_equal(G["f"], O["f"]) and util.bits_equal(G["scores"], O["scores"]), generic
+        assert util.bits_equal(G["ucgforce"], O["ucgforce"]), generic
+    assert res[0][0][0] == res[1][0][0]
+
+
+def test_generic_path_nonuniform_grids_and_special_lj(fresh_ctx, pkg, orc):
+    # table 11 starts at a different inner radius (its own r^2 grid), and special_lj != 1 with
+    # flagged entries: exercises the per-table lookup and factor_lj of the general kernels
+    ctx = fresh_ctx
+    deck = util.make_deck("spline", 700, rlo11=0.7)
+    beads = pkg.synth.make_beads(8, seed=8)
+    op = util.oracle_pair("table_ucgld", deck)
+    L = orc.lib()
+    sim = util.oracle_sim(beads, op, mode=1)
+    sim.rebuild()
+    il, nn, fi, ne = sim.full_list()
+    ne = ne.copy()
+    rng = np.random.default_rng(1)
+    flag = rng.integers(0, 4, size=ne.size).astype(np.int64)
+    ne = (ne.astype(np.int64) | (flag << 30)).astype(np.uint32).view(np.int32)
+    special = (1.0, 0.0, 0.5, 0.25)
+    # oracle on the flagged list
+    A = sim.arrays(ghosts=True)
+    arr = orc.AtomArrays(A["nlocal"], A["nghost"])
+    for k in ("x", "type", "tag", "ucgstate", "ucgl", "ucgp"):
+        getattr(arr, k)[...] = A[k]
+    lst, keep = orc.list_from_csr(il, nn, fi, ne)
+    import ctypes as C
+    sl = (C.c_double * 4)(*special)
+    L.orc_pair_set_special_lj.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    L.orc_pair_set_special_lj(op.h, sl)
+    ev = orc.Ev()
+    cs = arr.cstruct()
+    assert L.orc_pair_compute_gather(op.h, C.byref(cs), C.byref(lst), 1, 1, C.byref(ev)) == 0
+    ctx.set_units(1.0, 1.0, 1.0, 0.002, special)
+    nl, ng = A["nlocal"], A["nghost"]
+    ctx.atoms_upload(nl, ng, 2, A["x"], A["v"], A["type"], A["tag"], A["mask"][:nl], A["ucgstate"], A["ucgl"],
+                     A["ucgvl"], A["ucgml"], A["ucgp"], beads.mass)
+    ctx.neigh_upload_full(nn, fi, ne)
+    gp = util.gpu_pair(ctx, "table_ucgld", deck)
+    eng, vir = gp.compute(1, 1)
+    gp.check_errors()
+    G = ctx.atoms_download()
+    assert util.bits_equal(G["f"], arr.f[:nl]) and util.bits_equal(G["scores"], arr.scores[:nl])
+    assert util.bits_equal(G["ucgforce"], arr.ucgforce[:nl])
+    assert abs(eng - ev.eng_vdwl) <= 1e-12 * abs(ev.eng_vdwl)
