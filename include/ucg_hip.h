@@ -58,7 +58,9 @@ int ucg_abi_version(void);
 int ucg_ctx_create(int device, ucg_ctx **out);
 void ucg_ctx_destroy(ucg_ctx *ctx);
 const char *ucg_last_error(const ucg_ctx *ctx);
-/* run on a caller-owned hipStream_t (passed as void*); NULL = the context's own stream */
+/* run on a caller-owned hipStream_t (passed as void*), e.g. torch's current stream so that
+ * the kernels are ordered with RCCL collectives; NULL = the legacy default stream.  A new
+ * context starts with a non-blocking stream of its own. */
 int ucg_ctx_set_stream(ucg_ctx *ctx, void *hip_stream);
 int ucg_ctx_synchronize(ucg_ctx *ctx);
 /* force->boltz, force->ftm2v, force->mvv2e, update->dt, force->special_lj[0..3] */
@@ -156,6 +158,31 @@ int ucg_neigh_download(ucg_ctx *ctx, int *inum, int *numneigh, long long *first,
                        long long cap, long long *total);
 /* ghost map of the device builder: source owned index + periodic shift of each ghost */
 int ucg_ghosts_download(ucg_ctx *ctx, int *src, int *shift3, int cap);
+
+/* ----------------------------------------------------- multi-rank (one process per GPU)
+ * Spatial decomposition of the periodic box into procgrid[0] x procgrid[1] x procgrid[2]
+ * bricks, rank me = ix + px*(iy + py*iz).  These calls only count / pack / unpack on the
+ * device; the caller moves the buffers (torch.distributed all_to_all over RCCL, or MPI in a
+ * LAMMPS build).  Replaces upstream CommBrick::exchange / borders / forward_comm driven by
+ * the field lists of UCG/atom_vec_ucg.cpp:66-82.  There is no reverse halo: the gather
+ * kernels accumulate nothing on ghosts.  Call order at a rebuild:
+ *   exchange_count -> (all_to_all counts) -> exchange_pack -> (all_to_all data) ->
+ *   exchange_unpack -> border_count -> (counts) -> border_pack -> (data) -> border_unpack
+ * and every other step: halo_pack -> (all_to_all, same counts) -> halo_unpack.
+ * sendcounts arrays are `world` long; buffers are device pointers holding records of
+ * ucg_record_bytes() bytes grouped by destination rank in rank order. */
+int ucg_decomp_set(ucg_ctx *ctx, const int *procgrid3, int me);
+int ucg_record_bytes(int *atom_record_bytes, int *halo_record_bytes);
+int ucg_exchange_count(ucg_ctx *ctx, long long *sendcounts);
+int ucg_exchange_pack(ucg_ctx *ctx, void *sendbuf);
+int ucg_exchange_unpack(ucg_ctx *ctx, const void *recvbuf, long long nrecv);
+int ucg_border_count(ucg_ctx *ctx, long long *sendcounts);
+int ucg_border_pack(ucg_ctx *ctx, void *sendbuf);
+int ucg_border_unpack(ucg_ctx *ctx, const void *recvbuf, long long nrecv);
+int ucg_halo_pack(ucg_ctx *ctx, void *sendbuf);
+int ucg_halo_unpack(ucg_ctx *ctx, const void *recvbuf);
+/* Neighbor::decide(): *due = a check is scheduled this step, *flag = a local bead moved > skin/2 */
+int ucg_decide_local(ucg_ctx *ctx, int *due, int *flag);
 
 /* ---------------------------------------------------------------- fix nve/ucgld
  * replaces FixNVE_UCGLD::initial_integrate / final_integrate

@@ -43,6 +43,8 @@ SYMBOLS = [
     "ucg_fix_langevin_create", "ucg_fix_langevin_init", "ucg_fix_langevin_init_from_ucgml",
     "ucg_fix_langevin_post_force", "ucg_fix_langevin_end_of_step", "ucg_fix_langevin_t_target",
     "ucg_fix_ucgstate_create", "ucg_fix_ucgstate_post_force",
+    "ucg_decomp_set", "ucg_record_bytes", "ucg_exchange_count", "ucg_exchange_pack", "ucg_exchange_unpack",
+    "ucg_border_count", "ucg_border_pack", "ucg_border_unpack", "ucg_halo_pack", "ucg_halo_unpack", "ucg_decide_local",
     "ucg_ranmars_fill",
     "ucg_md_attach", "ucg_md_setup", "ucg_md_run", "ucg_md_info", "ucg_md_thermo",
     "ucg_profile_enable", "ucg_profile_read",
@@ -121,6 +123,17 @@ def lib():
     L.ucg_fix_langevin_t_target.restype = C.c_double
     L.ucg_fix_ucgstate_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int]
     L.ucg_fix_ucgstate_post_force.argtypes = [vp]
+    L.ucg_decomp_set.argtypes = [vp, c_int_p, C.c_int]
+    L.ucg_record_bytes.argtypes = [c_int_p, c_int_p]
+    L.ucg_exchange_count.argtypes = [vp, c_ll_p]
+    L.ucg_exchange_pack.argtypes = [vp, vp]
+    L.ucg_exchange_unpack.argtypes = [vp, vp, C.c_longlong]
+    L.ucg_border_count.argtypes = [vp, c_ll_p]
+    L.ucg_border_pack.argtypes = [vp, vp]
+    L.ucg_border_unpack.argtypes = [vp, vp, C.c_longlong]
+    L.ucg_halo_pack.argtypes = [vp, vp]
+    L.ucg_halo_unpack.argtypes = [vp, vp]
+    L.ucg_decide_local.argtypes = [vp, c_int_p, c_int_p]
     L.ucg_ranmars_fill.argtypes = [vp, C.c_int, C.c_longlong, C.c_int, c_double_p]
     L.ucg_md_attach.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int]
     L.ucg_md_setup.argtypes = [vp, C.c_longlong]
@@ -193,7 +206,7 @@ class Context:
         return m.value
 
     def set_stream(self, stream_ptr):
-        self.chk(self.L.ucg_ctx_set_stream(self.h, C.c_void_p(stream_ptr) if stream_ptr else None))
+        self.chk(self.L.ucg_ctx_set_stream(self.h, C.c_void_p(stream_ptr or 0)))
 
     def synchronize(self):
         self.chk(self.L.ucg_ctx_synchronize(self.h))
@@ -307,6 +320,50 @@ class Context:
 
     def fix_ucgstate_post_force(self):
         self.chk(self.L.ucg_fix_ucgstate_post_force(self.h))
+
+    # ---- multi-rank support (count / pack / unpack; the caller moves the buffers)
+    def decomp_set(self, procgrid, me):
+        g = _i32(procgrid)
+        self.chk(self.L.ucg_decomp_set(self.h, _ip(g), int(me)))
+        self._world = int(g[0] * g[1] * g[2])
+
+    def record_bytes(self):
+        a, b = C.c_int(0), C.c_int(0)
+        self.L.ucg_record_bytes(C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def exchange_count(self):
+        out = np.zeros(self._world, np.int64)
+        self.chk(self.L.ucg_exchange_count(self.h, out.ctypes.data_as(c_ll_p)))
+        return out
+
+    def exchange_pack(self, ptr):
+        self.chk(self.L.ucg_exchange_pack(self.h, C.c_void_p(ptr)))
+
+    def exchange_unpack(self, ptr, nrecv):
+        self.chk(self.L.ucg_exchange_unpack(self.h, C.c_void_p(ptr), int(nrecv)))
+
+    def border_count(self):
+        out = np.zeros(self._world, np.int64)
+        self.chk(self.L.ucg_border_count(self.h, out.ctypes.data_as(c_ll_p)))
+        return out
+
+    def border_pack(self, ptr):
+        self.chk(self.L.ucg_border_pack(self.h, C.c_void_p(ptr)))
+
+    def border_unpack(self, ptr, nrecv):
+        self.chk(self.L.ucg_border_unpack(self.h, C.c_void_p(ptr), int(nrecv)))
+
+    def halo_pack(self, ptr):
+        self.chk(self.L.ucg_halo_pack(self.h, C.c_void_p(ptr)))
+
+    def halo_unpack(self, ptr):
+        self.chk(self.L.ucg_halo_unpack(self.h, C.c_void_p(ptr)))
+
+    def decide_local(self):
+        due, flag = C.c_int(0), C.c_int(0)
+        self.chk(self.L.ucg_decide_local(self.h, C.byref(due), C.byref(flag)))
+        return due.value, flag.value
 
     # ---- RanMars
     def ranmars_fill(self, seed, skip, n):

@@ -158,13 +158,10 @@ int ucg_ctx_set_stream(ucg_ctx *ctx, void *hip_stream)
   return guarded(ctx, [&]() -> int {
     UCG_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->own_stream && ctx->stream) UCG_HIP(hipStreamDestroy(ctx->stream));
-    if (hip_stream) {
-      ctx->stream = (hipStream_t) hip_stream;
-      ctx->own_stream = false;
-    } else {
-      UCG_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-      ctx->own_stream = true;
-    }
+    // the caller's stream exactly as given; NULL is the legacy default stream (what
+    // torch.cuda.current_stream().cuda_stream returns for torch's default stream)
+    ctx->stream = (hipStream_t) hip_stream;
+    ctx->own_stream = false;
     return UCG_OK;
   });
 }

@@ -26,6 +26,14 @@ namespace ucg {
 
 struct Domain {
   double boxlo[3], boxhi[3], prd[3];
+  // spatial decomposition (1x1x1 = the whole periodic box on one GPU)
+  int procgrid[3] = {1, 1, 1}, myloc[3] = {0, 0, 0}, me = 0, world = 1;
+  double sublo[3], subhi[3];
+  // multi-rank halo: send lists grouped by destination rank, fixed between rebuilds
+  DevBuf<int> send_src, send_code, ghost_perm, dest_of, slot_of, offsets;
+  DevBuf<char> sendbuf;
+  std::vector<long long> send_counts, recv_counts;
+  long long nsend = 0;
   double cutforce = 0, skin = 0, cutneigh = 0;
   int every = 1, delay = 0, check = 1;
   int nbin[3] = {1, 1, 1}, sten[3] = {0, 0, 0}, nbins = 1;
@@ -41,6 +49,7 @@ struct Domain {
 
 struct DomainDev {
   double boxlo[3], boxhi[3], prd[3];
+  int procgrid[3], me;
   double bboxlo[3], bboxhi[3], bininv[3];
   int nbin[3], sten[3];
   double cutneighsq, triggersq;
@@ -70,7 +79,9 @@ DomainDev make_dev(const Domain &D)
     d.bininv[k] = D.bininv[k];
     d.nbin[k] = D.nbin[k];
     d.sten[k] = D.sten[k];
+    d.procgrid[k] = D.procgrid[k];
   }
+  d.me = D.me;
   d.cutneighsq = D.cutneigh * D.cutneigh;
   d.triggersq = 0.25 * D.skin * D.skin;
   for (int c = 0; c < 3; c++) {
@@ -294,9 +305,9 @@ void setup_bins(Domain &D)
   const double target = 0.5 * D.cutneigh;
   D.nbins = 1;
   for (int d = 0; d < 3; d++) {
-    D.bboxlo[d] = D.boxlo[d] - D.cutneigh;
-    D.bboxhi[d] = D.boxhi[d] + D.cutneigh;
-    const double ext = (D.boxhi[d] + D.cutneigh) - D.bboxlo[d];
+    D.bboxlo[d] = D.sublo[d] - D.cutneigh;
+    D.bboxhi[d] = D.subhi[d] + D.cutneigh;
+    const double ext = (D.subhi[d] + D.cutneigh) - D.bboxlo[d];
     int nb = (int) (ext / target);
     if (nb < 1) nb = 1;
     D.nbin[d] = nb;
@@ -327,19 +338,14 @@ void permute(ucg_ctx *ctx, int n, const int *perm, DevBuf<T> &arr, DevBuf<T> &tm
   UCG_HIP(hipMemcpyAsync(arr.get(), tmp.get(), (size_t) n * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
 }
 
-void rebuild(ucg_ctx *ctx)
+// (1)+(3): wrap (optional), key, radix-sort owned beads by (bin, tag), permute the per-bead arrays
+void sort_owned(ucg_ctx *ctx, bool wrap)
 {
   Domain &D = *ctx->dom;
   hipStream_t st = ctx->stream;
   const int n = ctx->nlocal;
-  if (n <= 0) throw InputError{"ucg_neigh_rebuild: no beads uploaded"};
-  for (int d = 0; d < 3; d++)
-    if (D.prd[d] < 2.0 * D.cutneigh * 0.5)
-      throw InputError{"periodic box shorter than the ghost cutoff: more than one image layer would be needed"};
-  setup_bins(D);
-  if ((long long) D.nbin[0] * D.nbin[1] * D.nbin[2] >= (1LL << 27)) throw InputError{"too many bins for the sort key"};
   const DomainDev dd = make_dev(D);
-
+  (void) wrap;
   // (1)+(3) wrap, key, sort owned beads by (bin, tag)
   D.keys_in.reserve((size_t) n);
   D.keys_out.reserve((size_t) n);
@@ -359,6 +365,25 @@ void rebuild(ucg_ctx *ctx)
   permute(ctx, n, perm, ctx->ucgp, D.tmpd);
   D.bin_of.reserve((size_t) n);
   hipLaunchKernelGGL(k_bins_from_keys, dim3(nblk(n)), dim3(NB), 0, st, n, D.keys_out.get(), D.bin_of.get());
+
+}
+
+void build_bins_and_rows(ucg_ctx *ctx);
+
+void rebuild(ucg_ctx *ctx)
+{
+  Domain &D = *ctx->dom;
+  hipStream_t st = ctx->stream;
+  const int n = ctx->nlocal;
+  if (n <= 0) throw InputError{"ucg_neigh_rebuild: no beads uploaded"};
+  for (int d = 0; d < 3; d++)
+    if (D.prd[d] < 2.0 * D.cutneigh * 0.5)
+      throw InputError{"periodic box shorter than the ghost cutoff: more than one image layer would be needed"};
+  setup_bins(D);
+  if ((long long) D.nbin[0] * D.nbin[1] * D.nbin[2] >= (1LL << 27)) throw InputError{"too many bins for the sort key"};
+  const DomainDev dd = make_dev(D);
+
+  sort_owned(ctx, true);
 
   // (4) ghosts: count, fill, sort by (bin, tag, code)
   D.counter.reserve(4);
@@ -396,6 +421,15 @@ void rebuild(ucg_ctx *ctx)
   }
   ctx->nghost = ng;
 
+  build_bins_and_rows(ctx);
+}
+
+void build_bins_and_rows(ucg_ctx *ctx)
+{
+  Domain &D = *ctx->dom;
+  hipStream_t st = ctx->stream;
+  const int n = ctx->nlocal, ng = ctx->nghost;
+  const DomainDev dd = make_dev(D);
   // (2) bin ranges of both classes
   const size_t nb1 = (size_t) D.nbins + 1;
   D.cell_o0.reserve(nb1);
@@ -477,6 +511,206 @@ bool decide(ucg_ctx *ctx)
   return false;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// multi-rank (one process per GPU): bead migration, ghost ("border") construction and the
+// per-step forward halo.  Transport is the caller's (torch.distributed all_to_all over RCCL);
+// these routines only count, pack and unpack on the device.  The gather formulation needs
+// no reverse halo.  Replaces what upstream CommBrick::exchange/borders/forward_comm do with
+// the field lists of UCG/atom_vec_ucg.cpp:66-82.
+
+struct AtomRec {  // fields_exchange: everything a bead owns (96 bytes)
+  double x, y, z, w, vx, vy, vz, vw, ucgp, ucgml;
+  int meta, tag, mask, nstates;
+};
+struct HaloRec {  // fields_border / fields_comm: x (+shift), ucgl, ucgp, ucgstate, type, tag (48 bytes)
+  double x, y, z, w, ucgp;
+  int meta, tag;  // meta bits 24..28 carry the shift code at border time
+};
+static_assert(sizeof(AtomRec) == 96 && sizeof(HaloRec) == 48, "record layout");
+
+__device__ __forceinline__ double proc_bound(const DomainDev &D, int d, int i)
+{
+  // same expression as the host's sublo/subhi (LAMMPS: boxlo + prd*i/procgrid, last = boxhi)
+  return (i >= D.procgrid[d]) ? D.boxhi[d] : D.boxlo[d] + D.prd[d] * i / D.procgrid[d];
+}
+
+__device__ __forceinline__ int own_loc(const DomainDev &D, int d, double x)
+{
+  int loc = 0;
+  for (int i = 1; i < D.procgrid[d]; i++)
+    if (x >= proc_bound(D, d, i)) loc = i;
+  return loc;
+}
+
+__global__ __launch_bounds__(NB) void k_exchange_dest(const DomainDev D, int n, double4 *pos4, int *counts, int *dest_of,
+                                                     int *slot_of)
+{
+  const int i = blockIdx.x * NB + threadIdx.x;
+  if (i >= n) return;
+  double4 p = pos4[i];
+  p.x = wrap1(p.x, D.boxlo[0], D.boxhi[0], D.prd[0]);
+  p.y = wrap1(p.y, D.boxlo[1], D.boxhi[1], D.prd[1]);
+  p.z = wrap1(p.z, D.boxlo[2], D.boxhi[2], D.prd[2]);
+  pos4[i] = p;
+  const int lx = own_loc(D, 0, p.x), ly = own_loc(D, 1, p.y), lz = own_loc(D, 2, p.z);
+  const int r = lx + D.procgrid[0] * (ly + D.procgrid[1] * lz);
+  dest_of[i] = r;
+  slot_of[i] = atomicAdd(&counts[r], 1);
+}
+
+__global__ __launch_bounds__(NB) void k_exchange_pack(int n, const int *dest_of, const int *slot_of, const int *offsets,
+                                                     const double4 *pos4, const double4 *vel4, const double *ucgp,
+                                                     const double *ucgml, const int *meta, const int *tag,
+                                                     const int *mask, const int *nstates, AtomRec *out)
+{
+  const int i = blockIdx.x * NB + threadIdx.x;
+  if (i >= n) return;
+  AtomRec r;
+  const double4 p = pos4[i], v = vel4[i];
+  r.x = p.x; r.y = p.y; r.z = p.z; r.w = p.w;
+  r.vx = v.x; r.vy = v.y; r.vz = v.z; r.vw = v.w;
+  r.ucgp = ucgp[i];
+  r.ucgml = ucgml[i];
+  r.meta = meta[i];
+  r.tag = tag[i];
+  r.mask = mask[i];
+  r.nstates = nstates[i];
+  out[offsets[dest_of[i]] + slot_of[i]] = r;
+}
+
+__global__ __launch_bounds__(NB) void k_exchange_unpack(int n, const AtomRec *in, double4 *pos4, double4 *vel4,
+                                                       double *ucgp, double *ucgml, int *meta, int *tag, int *mask,
+                                                       int *nstates)
+{
+  const int i = blockIdx.x * NB + threadIdx.x;
+  if (i >= n) return;
+  const AtomRec r = in[i];
+  pos4[i] = make_double4(r.x, r.y, r.z, r.w);
+  vel4[i] = make_double4(r.vx, r.vy, r.vz, r.vw);
+  ucgp[i] = r.ucgp;
+  ucgml[i] = r.ucgml;
+  meta[i] = r.meta;
+  tag[i] = r.tag;
+  mask[i] = r.mask;
+  nstates[i] = r.nstates;
+}
+
+// every (bead, shift) image that falls in some rank's extended sub-box, except the bead itself
+// on its own rank.  FILL=false counts per destination; FILL=true writes the send lists.
+template <bool FILL>
+__global__ __launch_bounds__(NB) void k_border_candidates(const DomainDev D, double cut, int n, const double4 *pos4,
+                                                         int *counts, const int *offsets, int *send_src,
+                                                         int *send_code)
+{
+  const int i = blockIdx.x * NB + threadIdx.x;
+  if (i >= n) return;
+  const double4 p = pos4[i];
+  const double xyz[3] = {p.x, p.y, p.z};
+  for (int code = 0; code < 27; code++) {
+    const int s[3] = {code % 3 - 1, (code / 3) % 3 - 1, code / 9 - 1};
+    double xs[3];
+    int lo[3], hi[3];
+    bool any = true;
+    for (int d = 0; d < 3; d++) {
+      xs[d] = xyz[d] + s[d] * D.prd[d];
+      lo[d] = D.procgrid[d];
+      hi[d] = -1;
+      for (int l = 0; l < D.procgrid[d]; l++) {
+        if (xs[d] >= proc_bound(D, d, l) - cut && xs[d] < proc_bound(D, d, l + 1) + cut) {
+          if (l < lo[d]) lo[d] = l;
+          if (l > hi[d]) hi[d] = l;
+        }
+      }
+      if (hi[d] < 0) any = false;
+    }
+    if (!any) continue;
+    for (int lz = lo[2]; lz <= hi[2]; lz++)
+      for (int ly = lo[1]; ly <= hi[1]; ly++)
+        for (int lx = lo[0]; lx <= hi[0]; lx++) {
+          // with procgrid <= 2 per dimension [lo,hi] is exactly the matching set; for larger grids
+          // re-test the box (ranges are contiguous because sub-boxes are ordered)
+          const int r = lx + D.procgrid[0] * (ly + D.procgrid[1] * lz);
+          if (r == D.me && code == 13) continue;
+          const int slot = atomicAdd(&counts[r], 1);
+          if (FILL) {
+            send_src[offsets[r] + slot] = i;
+            send_code[offsets[r] + slot] = code;
+          }
+        }
+  }
+}
+
+__global__ __launch_bounds__(NB) void k_halo_pack(const DomainDev D, int nsend, const int *send_src, const int *send_code,
+                                                 const double4 *pos4, const double *ucgp, const int *meta,
+                                                 const int *tag, HaloRec *out, int with_code)
+{
+  const int j = blockIdx.x * NB + threadIdx.x;
+  if (j >= nsend) return;
+  const int src = send_src[j], code = send_code[j];
+  const int sx = code % 3 - 1, sy = (code / 3) % 3 - 1, sz = code / 9 - 1;
+  const double4 p = pos4[src];
+  HaloRec r;
+  r.x = p.x + sx * D.prd[0];
+  r.y = p.y + sy * D.prd[1];
+  r.z = p.z + sz * D.prd[2];
+  r.w = p.w;
+  r.ucgp = ucgp[src];
+  r.meta = (meta[src] & 0xFFFFFF) | (with_code ? (code << 24) : 0);
+  r.tag = tag[src];
+  out[j] = r;
+}
+
+__global__ __launch_bounds__(NB) void k_border_keys(const DomainDev D, int ng, const HaloRec *in, unsigned long long *keys,
+                                                   int *vals)
+{
+  const int j = blockIdx.x * NB + threadIdx.x;
+  if (j >= ng) return;
+  const HaloRec r = in[j];
+  const unsigned long long b = (unsigned long long) coord2bin(D, r.x, r.y, r.z);
+  const unsigned long long code = (unsigned long long) ((r.meta >> 24) & 31);
+  keys[j] = (b << 37) | ((unsigned long long) (unsigned int) r.tag << 5) | code;
+  vals[j] = j;
+}
+
+__global__ __launch_bounds__(NB) void k_border_finalize(int ng, int nlocal, const int *order, const unsigned long long *keys,
+                                                       int *perm, int *bin_of)
+{
+  const int g = blockIdx.x * NB + threadIdx.x;
+  if (g >= ng) return;
+  perm[g] = order[g];
+  bin_of[nlocal + g] = (int) (keys[g] >> 37);
+}
+
+__global__ __launch_bounds__(NB) void k_halo_unpack(int ng, int nlocal, const int *perm, const HaloRec *in, double4 *pos4,
+                                                   int *meta, double *ucgp, int *tag, int with_tag)
+{
+  const int g = blockIdx.x * NB + threadIdx.x;
+  if (g >= ng) return;
+  const HaloRec r = in[perm[g]];
+  pos4[nlocal + g] = make_double4(r.x, r.y, r.z, r.w);
+  meta[nlocal + g] = r.meta & 0xFFFFFF;
+  ucgp[nlocal + g] = r.ucgp;
+  if (with_tag) tag[nlocal + g] = r.tag;
+}
+
+void counts_to_host(ucg_ctx *ctx, Domain &D, long long *out)
+{
+  std::vector<int> h((size_t) D.world);
+  UCG_HIP(hipMemcpyAsync(h.data(), D.counter.get(), (size_t) D.world * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  UCG_HIP(hipStreamSynchronize(ctx->stream));
+  for (int r = 0; r < D.world; r++) out[r] = h[(size_t) r];
+}
+
+void offsets_to_device(ucg_ctx *ctx, Domain &D, const std::vector<long long> &counts, DevBuf<int> &dst)
+{
+  std::vector<int> off((size_t) D.world + 1, 0);
+  for (int r = 0; r < D.world; r++) off[(size_t) r + 1] = off[(size_t) r] + (int) counts[(size_t) r];
+  dst.reserve((size_t) D.world + 1);
+  UCG_HIP(hipMemcpyAsync(dst.get(), off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  UCG_HIP(hipStreamSynchronize(ctx->stream));
+}
+
 template <typename F>
 int guarded(ucg_ctx *ctx, F &&fn)
 {
@@ -541,6 +775,14 @@ int ucg_domain_set(ucg_ctx *ctx, const double *boxlo, const double *boxhi, doubl
       D.boxhi[d] = boxhi[d];
       D.prd[d] = boxhi[d] - boxlo[d];
     }
+    for (int d = 0; d < 3; d++) {
+      D.procgrid[d] = 1;
+      D.myloc[d] = 0;
+      D.sublo[d] = D.boxlo[d];
+      D.subhi[d] = D.boxhi[d];
+    }
+    D.me = 0;
+    D.world = 1;
     D.cutforce = cutforce;
     D.skin = skin;
     D.cutneigh = cutforce + skin;
@@ -690,6 +932,259 @@ int ucg_md_thermo(ucg_ctx *ctx, double *out9)
 {
   if (!ctx || !out9) return UCG_ERR_INVALID;
   for (int i = 0; i < 9; i++) out9[i] = ctx->thermo[i];
+  return UCG_OK;
+}
+
+/* ----------------------------------------------------------------- multi-rank support */
+
+int ucg_decomp_set(ucg_ctx *ctx, const int *procgrid, int me)
+{
+  if (!ctx || !procgrid) return UCG_ERR_INVALID;
+  if (int rc = need_domain(ctx)) return rc;
+  return guarded(ctx, [&]() -> int {
+    Domain &D = *ctx->dom;
+    const int world = procgrid[0] * procgrid[1] * procgrid[2];
+    if (procgrid[0] < 1 || procgrid[1] < 1 || procgrid[2] < 1 || me < 0 || me >= world)
+      throw InputError{"Bad processor grid"};
+    D.world = world;
+    D.me = me;
+    for (int d = 0; d < 3; d++) D.procgrid[d] = procgrid[d];
+    D.myloc[0] = me % procgrid[0];
+    D.myloc[1] = (me / procgrid[0]) % procgrid[1];
+    D.myloc[2] = me / (procgrid[0] * procgrid[1]);
+    for (int d = 0; d < 3; d++) {
+      D.sublo[d] = D.boxlo[d] + D.prd[d] * D.myloc[d] / D.procgrid[d];
+      D.subhi[d] = (D.myloc[d] + 1 >= D.procgrid[d]) ? D.boxhi[d] : D.boxlo[d] + D.prd[d] * (D.myloc[d] + 1) / D.procgrid[d];
+      if (D.subhi[d] - D.sublo[d] < D.cutneigh)
+        throw InputError{"sub-domain thinner than the ghost cutoff: one halo layer would not be enough"};
+    }
+    D.counter.reserve((size_t) world + 4);
+    D.send_counts.assign((size_t) world, 0);
+    D.recv_counts.assign((size_t) world, 0);
+    return UCG_OK;
+  });
+}
+
+int ucg_exchange_count(ucg_ctx *ctx, long long *sendcounts)
+{
+  if (!ctx || !sendcounts) return UCG_ERR_INVALID;
+  if (int rc = need_domain(ctx)) return rc;
+  return guarded(ctx, [&]() -> int {
+    Domain &D = *ctx->dom;
+    const int n = ctx->nlocal;
+    const DomainDev dd = make_dev(D);
+    D.counter.reserve((size_t) D.world + 4);
+    D.dest_of.reserve((size_t) n + 1);
+    D.slot_of.reserve((size_t) n + 1);
+    UCG_HIP(hipMemsetAsync(D.counter.get(), 0, (size_t) D.world * sizeof(int), ctx->stream));
+    if (n > 0)
+      hipLaunchKernelGGL(k_exchange_dest, dim3(nblk(n)), dim3(NB), 0, ctx->stream, dd, n, ctx->pos4.get(),
+                         D.counter.get(), D.dest_of.get(), D.slot_of.get());
+    counts_to_host(ctx, D, sendcounts);
+    for (int r = 0; r < D.world; r++) D.send_counts[(size_t) r] = sendcounts[r];
+    return UCG_OK;
+  });
+}
+
+int ucg_exchange_pack(ucg_ctx *ctx, void *sendbuf)
+{
+  if (!ctx) return UCG_ERR_INVALID;
+  if (int rc = need_domain(ctx)) return rc;
+  return guarded(ctx, [&]() -> int {
+    Domain &D = *ctx->dom;
+    const int n = ctx->nlocal;
+    if (n == 0) return UCG_OK;
+    if (!sendbuf) return UCG_ERR_INVALID;
+    offsets_to_device(ctx, D, D.send_counts, D.offsets);
+    hipLaunchKernelGGL(k_exchange_pack, dim3(nblk(n)), dim3(NB), 0, ctx->stream, n, D.dest_of.get(), D.slot_of.get(),
+                       D.offsets.get(), ctx->pos4.get(), ctx->vel4.get(), ctx->ucgp.get(), ctx->ucgml.get(),
+                       ctx->meta.get(), ctx->tag.get(), ctx->mask.get(), ctx->num_ucgstates.get(), (AtomRec *) sendbuf);
+    UCG_HIP(hipGetLastError());
+    return UCG_OK;
+  });
+}
+
+int ucg_exchange_unpack(ucg_ctx *ctx, const void *recvbuf, long long nrecv)
+{
+  if (!ctx || nrecv < 0 || (nrecv > 0 && !recvbuf)) return UCG_ERR_INVALID;
+  if (int rc = need_domain(ctx)) return rc;
+  return guarded(ctx, [&]() -> int {
+    const size_t n = (size_t) nrecv;
+    ctx->pos4.reserve(n);
+    ctx->vel4.reserve(n);
+    ctx->frc4.reserve(n);
+    ctx->scores.reserve(n);
+    ctx->ucgp.reserve(n);
+    ctx->ucgml.reserve(n);
+    ctx->meta.reserve(n);
+    ctx->tag.reserve(n);
+    ctx->mask.reserve(n);
+    ctx->num_ucgstates.reserve(n);
+    if (n)
+      hipLaunchKernelGGL(k_exchange_unpack, dim3(nblk((long long) n)), dim3(NB), 0, ctx->stream, (int) n,
+                         (const AtomRec *) recvbuf, ctx->pos4.get(), ctx->vel4.get(), ctx->ucgp.get(), ctx->ucgml.get(),
+                         ctx->meta.get(), ctx->tag.get(), ctx->mask.get(), ctx->num_ucgstates.get());
+    UCG_HIP(hipGetLastError());
+    ctx->nlocal = (int) n;
+    ctx->nghost = 0;
+    ctx->list_inum = 0;
+    return UCG_OK;
+  });
+}
+
+int ucg_border_count(ucg_ctx *ctx, long long *sendcounts)
+{
+  if (!ctx || !sendcounts) return UCG_ERR_INVALID;
+  if (int rc = need_domain(ctx)) return rc;
+  return guarded(ctx, [&]() -> int {
+    Domain &D = *ctx->dom;
+    const int n = ctx->nlocal;
+    setup_bins(D);
+    if ((long long) D.nbin[0] * D.nbin[1] * D.nbin[2] >= (1LL << 27)) throw InputError{"too many bins for the sort key"};
+    if (n > 0) sort_owned(ctx, true);
+    const DomainDev dd = make_dev(D);
+    UCG_HIP(hipMemsetAsync(D.counter.get(), 0, (size_t) D.world * sizeof(int), ctx->stream));
+    if (n > 0)
+      hipLaunchKernelGGL(k_border_candidates<false>, dim3(nblk(n)), dim3(NB), 0, ctx->stream, dd, D.cutneigh, n,
+                         ctx->pos4.get(), D.counter.get(), nullptr, nullptr, nullptr);
+    counts_to_host(ctx, D, sendcounts);
+    D.nsend = 0;
+    for (int r = 0; r < D.world; r++) {
+      D.send_counts[(size_t) r] = sendcounts[r];
+      D.nsend += sendcounts[r];
+    }
+    return UCG_OK;
+  });
+}
+
+int ucg_border_pack(ucg_ctx *ctx, void *sendbuf)
+{
+  if (!ctx) return UCG_ERR_INVALID;
+  if (int rc = need_domain(ctx)) return rc;
+  return guarded(ctx, [&]() -> int {
+    Domain &D = *ctx->dom;
+    const int n = ctx->nlocal;
+    if (D.nsend == 0) return UCG_OK;
+    if (!sendbuf) return UCG_ERR_INVALID;
+    const DomainDev dd = make_dev(D);
+    offsets_to_device(ctx, D, D.send_counts, D.offsets);
+    D.send_src.reserve((size_t) D.nsend);
+    D.send_code.reserve((size_t) D.nsend);
+    UCG_HIP(hipMemsetAsync(D.counter.get(), 0, (size_t) D.world * sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(k_border_candidates<true>, dim3(nblk(n)), dim3(NB), 0, ctx->stream, dd, D.cutneigh, n,
+                       ctx->pos4.get(), D.counter.get(), D.offsets.get(), D.send_src.get(), D.send_code.get());
+    hipLaunchKernelGGL(k_halo_pack, dim3(nblk(D.nsend)), dim3(NB), 0, ctx->stream, dd, (int) D.nsend, D.send_src.get(),
+                       D.send_code.get(), ctx->pos4.get(), ctx->ucgp.get(), ctx->meta.get(), ctx->tag.get(),
+                       (HaloRec *) sendbuf, 1);
+    UCG_HIP(hipGetLastError());
+    return UCG_OK;
+  });
+}
+
+int ucg_border_unpack(ucg_ctx *ctx, const void *recvbuf, long long nrecv)
+{
+  if (!ctx || nrecv < 0 || (nrecv > 0 && !recvbuf)) return UCG_ERR_INVALID;
+  if (int rc = need_domain(ctx)) return rc;
+  return guarded(ctx, [&]() -> int {
+    Domain &D = *ctx->dom;
+    hipStream_t st = ctx->stream;
+    const int n = ctx->nlocal, ng = (int) nrecv;
+    const size_t nall = (size_t) n + (size_t) ng;
+    if (nall >= (size_t) UCG_NEIGHMASK) throw InputError{"too many beads + ghosts for 29-bit neighbour indices"};
+    const DomainDev dd = make_dev(D);
+    ctx->pos4.reserve(nall, true, st);
+    ctx->meta.reserve(nall, true, st);
+    ctx->tag.reserve(nall, true, st);
+    ctx->ucgp.reserve(nall, true, st);
+    D.bin_of.reserve(nall, true, st);
+    D.ghost_perm.reserve((size_t) ng + 1);
+    if (ng > 0) {
+      D.keys_in.reserve((size_t) ng);
+      D.keys_out.reserve((size_t) ng);
+      D.vals_in.reserve((size_t) ng);
+      D.vals_out.reserve((size_t) ng);
+      hipLaunchKernelGGL(k_border_keys, dim3(nblk(ng)), dim3(NB), 0, st, dd, ng, (const HaloRec *) recvbuf,
+                         D.keys_in.get(), D.vals_in.get());
+      sort_pairs(ctx, D, ng);
+      hipLaunchKernelGGL(k_border_finalize, dim3(nblk(ng)), dim3(NB), 0, st, ng, n, D.vals_out.get(), D.keys_out.get(),
+                         D.ghost_perm.get(), D.bin_of.get());
+      hipLaunchKernelGGL(k_halo_unpack, dim3(nblk(ng)), dim3(NB), 0, st, ng, n, D.ghost_perm.get(),
+                         (const HaloRec *) recvbuf, ctx->pos4.get(), ctx->meta.get(), ctx->ucgp.get(), ctx->tag.get(), 1);
+    }
+    ctx->nghost = ng;
+    UCG_HIP(hipGetLastError());
+    build_bins_and_rows(ctx);
+    return UCG_OK;
+  });
+}
+
+int ucg_halo_pack(ucg_ctx *ctx, void *sendbuf)
+{
+  if (!ctx) return UCG_ERR_INVALID;
+  if (int rc = need_domain(ctx)) return rc;
+  return guarded(ctx, [&]() -> int {
+    Domain &D = *ctx->dom;
+    if (D.nsend == 0) return UCG_OK;
+    if (!sendbuf) return UCG_ERR_INVALID;
+    const DomainDev dd = make_dev(D);
+    hipLaunchKernelGGL(k_halo_pack, dim3(nblk(D.nsend)), dim3(NB), 0, ctx->stream, dd, (int) D.nsend, D.send_src.get(),
+                       D.send_code.get(), ctx->pos4.get(), ctx->ucgp.get(), ctx->meta.get(), ctx->tag.get(),
+                       (HaloRec *) sendbuf, 0);
+    UCG_HIP(hipGetLastError());
+    return UCG_OK;
+  });
+}
+
+int ucg_halo_unpack(ucg_ctx *ctx, const void *recvbuf)
+{
+  if (!ctx) return UCG_ERR_INVALID;
+  if (int rc = need_domain(ctx)) return rc;
+  return guarded(ctx, [&]() -> int {
+    Domain &D = *ctx->dom;
+    const int ng = ctx->nghost;
+    if (ng == 0) return UCG_OK;
+    if (!recvbuf) return UCG_ERR_INVALID;
+    hipLaunchKernelGGL(k_halo_unpack, dim3(nblk(ng)), dim3(NB), 0, ctx->stream, ng, ctx->nlocal, D.ghost_perm.get(),
+                       (const HaloRec *) recvbuf, ctx->pos4.get(), ctx->meta.get(), ctx->ucgp.get(), ctx->tag.get(), 0);
+    UCG_HIP(hipGetLastError());
+    return UCG_OK;
+  });
+}
+
+int ucg_decide_local(ucg_ctx *ctx, int *due, int *flag)
+{
+  if (!ctx || !due || !flag) return UCG_ERR_INVALID;
+  if (int rc = need_domain(ctx)) return rc;
+  return guarded(ctx, [&]() -> int {
+    // Neighbor::decide(): the caller combines `flag` over ranks (MPI_Allreduce in upstream)
+    Domain &D = *ctx->dom;
+    D.ago++;
+    *due = 0;
+    *flag = 0;
+    if (D.ago >= D.delay && D.ago % D.every == 0) {
+      *due = 1;
+      if (D.check == 0) {
+        *flag = 1;
+        return UCG_OK;
+      }
+      const DomainDev dd = make_dev(D);
+      UCG_HIP(hipMemsetAsync(D.counter.get(), 0, sizeof(int), ctx->stream));
+      if (ctx->nlocal > 0)
+        hipLaunchKernelGGL(k_check_distance, dim3(nblk(ctx->nlocal)), dim3(NB), 0, ctx->stream, dd, ctx->nlocal,
+                           ctx->pos4.get(), D.xhold.get(), D.counter.get());
+      int f = 0;
+      UCG_HIP(hipMemcpyAsync(&f, D.counter.get(), sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+      UCG_HIP(hipStreamSynchronize(ctx->stream));
+      *flag = f != 0;
+    }
+    return UCG_OK;
+  });
+}
+
+int ucg_record_bytes(int *atom_rec, int *halo_rec)
+{
+  if (atom_rec) *atom_rec = (int) sizeof(AtomRec);
+  if (halo_rec) *halo_rec = (int) sizeof(HaloRec);
   return UCG_OK;
 }
 

@@ -1,0 +1,254 @@
+"""Spatial decomposition across the GPUs of one node: one process per GPU.
+
+Replaces, for the resident path, what upstream LAMMPS' CommBrick does with the field lists of
+``UCG/atom_vec_ucg.cpp:66-82``: bead migration (``exchange``), ghost construction
+(``borders``) and the per-step forward halo (``forward_comm``: x, ucgstate, ucgl, ucgp).
+The gather kernels accumulate nothing on ghosts, so there is NO reverse halo.
+
+Device work (count / pack / unpack, sorting, binning, lists, forces, fixes) is the C ABI's;
+this module only sequences it and moves the packed buffers with ``torch.distributed``:
+backend ``nccl`` (= RCCL over xGMI) on a multi-GPU node -- one ``all_to_all_single`` per halo,
+i.e. direct neighbour exchange on the point-to-point links, not LAMMPS' staged x/y/z
+forwarding -- or, for tests on a single GPU shared by the ranks, ``gloo`` with host staging.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def choose_procgrid(world: int):
+    """2x1x1, 2x2x1, 2x2x2, ... : factor the rank count over x, y, z as evenly as possible"""
+    grid = [1, 1, 1]
+    n, d, f = world, 0, 2
+    factors = []
+    while n > 1:
+        while n % f == 0:
+            factors.append(f)
+            n //= f
+        f += 1
+    for f in sorted(factors, reverse=True):
+        i = int(np.argmin(grid))
+        grid[i] *= f
+    grid.sort(reverse=True)
+    return grid
+
+
+def rank_loc(me: int, grid):
+    return me % grid[0], (me // grid[0]) % grid[1], me // (grid[0] * grid[1])
+
+
+def sub_box(boxlo, boxhi, grid, me):
+    """the brick of rank ``me`` -- same expression as the library / LAMMPS (boxlo + prd*i/p)"""
+    lo, hi = np.zeros(3), np.zeros(3)
+    loc = rank_loc(me, grid)
+    for d in range(3):
+        prd = boxhi[d] - boxlo[d]
+        lo[d] = boxlo[d] + prd * loc[d] / grid[d]
+        hi[d] = boxhi[d] if loc[d] + 1 >= grid[d] else boxlo[d] + prd * (loc[d] + 1) / grid[d]
+    return lo, hi
+
+
+def owner_rank(x, boxlo, boxhi, grid):
+    """rank owning each (wrapped) position, vectorised"""
+    x = np.asarray(x)
+    loc = []
+    for d in range(3):
+        prd = boxhi[d] - boxlo[d]
+        l = np.zeros(len(x), dtype=np.int64)
+        for i in range(1, grid[d]):
+            l[x[:, d] >= boxlo[d] + prd * i / grid[d]] = i
+        loc.append(l)
+    return loc[0] + grid[0] * (loc[1] + grid[1] * loc[2])
+
+
+class Transport:
+    """all_to_all of packed device buffers + small reductions over torch.distributed"""
+
+    def __init__(self, dist, device, staged: bool):
+        import torch
+
+        self.torch = torch
+        self.dist = dist
+        self.device = device
+        self.staged = staged  # gloo: stage through the host
+        self.world = dist.get_world_size()
+        self.rank = dist.get_rank()
+
+    def alltoall_counts(self, counts):
+        t = self.torch
+        send = t.tensor(np.asarray(counts, dtype=np.int64), device="cpu" if self.staged else self.device)
+        recv = t.empty_like(send)
+        self.dist.all_to_all_single(recv, send)
+        return recv.cpu().numpy()
+
+    def alltoall_bytes(self, sendbuf, send_counts, recv_counts, rec_bytes):
+        """sendbuf: uint8 device tensor grouped by destination; returns the uint8 device tensor received"""
+        t = self.torch
+        in_splits = [int(c) * rec_bytes for c in send_counts]
+        out_splits = [int(c) * rec_bytes for c in recv_counts]
+        nout = sum(out_splits)
+        if self.staged:
+            s = sendbuf[: sum(in_splits)].cpu()
+            r = t.empty(nout, dtype=t.uint8)
+            self.dist.all_to_all_single(r, s, out_splits, in_splits)
+            return r.to(self.device)
+        r = t.empty(max(nout, 1), dtype=t.uint8, device=self.device)
+        self.dist.all_to_all_single(r[:nout], sendbuf[: sum(in_splits)], out_splits, in_splits)
+        return r
+
+    def allreduce_max(self, value: int) -> int:
+        t = self.torch
+        x = t.tensor([int(value)], dtype=t.int64, device="cpu" if self.staged else self.device)
+        self.dist.all_reduce(x, op=self.dist.ReduceOp.MAX)
+        return int(x.item())
+
+    def allreduce_sum(self, values):
+        t = self.torch
+        x = t.tensor(np.asarray(values, dtype=np.float64), device="cpu" if self.staged else self.device)
+        self.dist.all_reduce(x, op=self.dist.ReduceOp.SUM)
+        return x.cpu().numpy()
+
+
+class RankSim:
+    """The Verlet step order of SURVEY.md section 3.1 on one rank of a decomposed run."""
+
+    def __init__(self, ctx, pair, transport: Transport, grid, use_langevin=True, use_ucgstate=True, groupbit=1):
+        self.ctx, self.pair, self.tr = ctx, pair, transport
+        self.grid = list(grid)
+        self.me = transport.rank
+        self.world = transport.world
+        self.use_langevin, self.use_ucgstate = use_langevin, use_ucgstate
+        self.groupbit = groupbit
+        self.atom_bytes, self.halo_bytes = ctx.record_bytes()
+        ctx.decomp_set(self.grid, self.me)
+        if transport.device.type == "cuda":
+            # run the library's kernels on torch's current stream so that they are ordered with the
+            # collectives (RCCL) and with torch's own copies (host-staged gloo)
+            ctx.set_stream(transport.torch.cuda.current_stream().cuda_stream)
+        self.ntimestep = self.beginstep = self.endstep = 0
+        self.nrebuild = 0
+        self.halo_send_counts = self.halo_recv_counts = None
+        self._halo_send = None
+
+    def _buf(self, nbytes):
+        t = self.tr.torch
+        return t.empty(max(int(nbytes), 16), dtype=t.uint8, device=self.tr.device)
+
+    def rebuild(self):
+        ctx, tr = self.ctx, self.tr
+        # exchange: every bead goes to the rank that owns its (wrapped) position
+        sc = ctx.exchange_count()
+        rc = tr.alltoall_counts(sc)
+        sb = self._buf(sc.sum() * self.atom_bytes)
+        ctx.exchange_pack(sb.data_ptr())
+        rb = tr.alltoall_bytes(sb, sc, rc, self.atom_bytes)
+        ctx.exchange_unpack(rb.data_ptr(), int(rc.sum()))
+        # borders: periodic / neighbour-rank images inside each rank's extended brick
+        sc = ctx.border_count()
+        rc = tr.alltoall_counts(sc)
+        sb = self._buf(sc.sum() * self.halo_bytes)
+        ctx.border_pack(sb.data_ptr())
+        rb = tr.alltoall_bytes(sb, sc, rc, self.halo_bytes)
+        ctx.border_unpack(rb.data_ptr(), int(rc.sum()))
+        self.halo_send_counts, self.halo_recv_counts = sc, rc
+        self._halo_send = sb  # reused every step: same counts until the next rebuild
+        self._keep = rb
+        self.nrebuild += 1
+
+    def halo_forward(self):
+        ctx, tr = self.ctx, self.tr
+        ctx.halo_pack(self._halo_send.data_ptr())
+        rb = tr.alltoall_bytes(self._halo_send, self.halo_send_counts, self.halo_recv_counts, self.halo_bytes)
+        ctx.halo_unpack(rb.data_ptr())
+        self._keep = rb
+
+    def _forces_and_post_force(self, ev):
+        out = self.pair.compute(ev, ev)
+        if self.use_langevin:
+            self.ctx.fix_ucgld_langevin_post_force(self.ntimestep, self.beginstep, self.endstep, self.groupbit)
+        if self.use_ucgstate:
+            self.ctx.fix_ucgstate_post_force()
+        return out
+
+    def setup(self, nsteps, ntypes=2):
+        self.beginstep = self.ntimestep
+        self.endstep = self.ntimestep + nsteps
+        self.rebuild()
+        if self.use_langevin:
+            # Fix_UCGLD_Langevin::init() reads atom->ucgml[1..ntypes] of the local bead order (App. B #5)
+            ml = self.ctx.atoms_download()["ucgml"]
+            pad = np.full(ntypes + 1, ml[0] if len(ml) else 1.0)
+            pad[: min(len(ml), ntypes + 1)] = ml[: ntypes + 1]
+            self.ctx.fix_ucgld_langevin_init(ntypes, pad)
+        return self._forces_and_post_force(1)
+
+    def run(self, nsteps, thermo_every=0):
+        ctx = self.ctx
+        last = None
+        for _ in range(nsteps):
+            self.ntimestep += 1
+            ev = 1 if (thermo_every > 0 and self.ntimestep % thermo_every == 0) else 0
+            ctx.fix_nve_ucgld_initial_integrate(self.groupbit)
+            due, flag = ctx.decide_local()
+            if due and self.tr.allreduce_max(flag):
+                self.rebuild()
+            else:
+                self.halo_forward()
+            out = self._forces_and_post_force(ev)
+            if ev:
+                last = out
+            ctx.fix_nve_ucgld_final_integrate(self.groupbit)
+        return last
+
+
+def run_bench(args, deck, rank, world, local_rank, dist):
+    """bench.py's N > 1 leg: the same 1 M beads split over `world` GPUs (strong scaling)"""
+    import time
+
+    import torch
+
+    from . import capi, synth
+
+    dt = 0.002
+    device = torch.device("cuda", local_rank)
+    beads = synth.make_beads(args.ncell, seed=12345)
+    grid = choose_procgrid(world)
+    # any initial split works: the first exchange sends every bead to its owner
+    sl = slice(rank * beads.n // world, (rank + 1) * beads.n // world)
+    ctx = capi.Context(local_rank, dt=dt)
+    n = sl.stop - sl.start
+    ctx.atoms_upload(n, 0, beads.ntypes, beads.x[sl], beads.v[sl], beads.type[sl], beads.tag[sl], beads.mask[sl],
+                     beads.ucgstate[sl], beads.ucgl[sl], beads.ucgvl[sl], beads.ucgml[sl], beads.ucgp[sl], beads.mass)
+    ctx.domain_set(beads.boxlo, beads.boxhi, 2.5, 0.3, every=10, delay=0, check=1)
+    pair = capi.Pair(ctx, "table_ucgld")
+    pair.settings(deck.pair_style_args())
+    pair.coeff(deck.pair_coeff_args())
+    pair.init(2, 1.0)
+    ctx.fix_ucgld_langevin(1.0, 1.0, 1.0, 48279, me=rank)
+    ctx.fix_ucgstate("ld", me=rank)
+    tr = Transport(dist, device, staged=False)
+    sim = RankSim(ctx, pair, tr, grid)
+    sim.setup(args.warmup + args.steps)
+    sim.run(args.warmup)
+    ctx.synchronize()
+    ctx.profile_enable(True)
+    ctx.profile_read(reset=True)
+    nre0 = sim.nrebuild
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sim.run(args.steps)
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    launches, pair_ms = ctx.profile_read(reset=True)
+    ctx.profile_enable(False)
+    pair.check_errors()
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    info = ctx.md_info()
+    tot = tr.allreduce_sum([info["list_entries"], info["nghost"], info["nlocal"]])
+    return dict(elapsed=float(t.item()), n=beads.n, pair_launches=launches, pair_ms=pair_ms, list_entries=int(tot[0]),
+                nghost=int(tot[1]), rebuilds=sim.nrebuild - nre0, maxrow=info["maxrow"], grid=grid,
+                nlocal_sum=int(tot[2]), rank0_list_entries=info["list_entries"], rank0_nlocal=info["nlocal"])

@@ -1,0 +1,79 @@
+"""worker for the world_size-2 tests (launched by test_multi_rank.py through subprocess)
+
+  python mp_worker.py cpu <port> <outdir>   -- gloo on CPU: decomposition + transport protocol
+  python mp_worker.py gpu <port> <outdir>   -- gloo (host-staged) with both ranks on ONE GPU
+"""
+import os
+import pickle
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import conftest  # noqa: E402
+import util  # noqa: E402
+
+
+def main():
+    mode, port, outdir = sys.argv[1], sys.argv[2], sys.argv[3]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = port
+    import torch
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = conftest.load_package()
+    multi, synth = pkg.multi, pkg.synth
+    beads = synth.make_beads(10, seed=5)
+    grid = multi.choose_procgrid(world)
+    result = {}
+    if mode == "cpu":
+        tr = multi.Transport(dist, torch.device("cpu"), staged=True)
+        sl = slice(rank * beads.n // world, (rank + 1) * beads.n // world)
+        x, tag = beads.x[sl], beads.tag[sl]
+        dest = multi.owner_rank(x, beads.boxlo, beads.boxhi, grid)
+        order = np.argsort(dest, kind="stable")
+        counts = np.bincount(dest, minlength=world).astype(np.int64)
+        rec = np.zeros((len(x), 4))
+        rec[:, :3], rec[:, 3] = x[order], tag[order]
+        rc = tr.alltoall_counts(counts)
+        sb = torch.from_numpy(rec.view(np.uint8).reshape(-1).copy())
+        rb = tr.alltoall_bytes(sb, counts, rc, 32)
+        got = rb.numpy()[: int(rc.sum()) * 32].view(np.float64).reshape(-1, 4)
+        lo, hi = multi.sub_box(beads.boxlo, beads.boxhi, grid, rank)
+        result = dict(n=len(got), inside=bool(np.all((got[:, :3] >= lo) & (got[:, :3] < hi))), tags=got[:, 3].astype(np.int64),
+                      counts=counts, rc=rc, maxflag=tr.allreduce_max(rank), total=tr.allreduce_sum([len(got)])[0])
+    else:
+        capi = pkg.capi
+        dt = 0.004
+        deck = util.make_deck("spline", 1024)
+        ctx = capi.Context(0, dt=dt)
+        sl = slice(rank * beads.n // world, (rank + 1) * beads.n // world)
+        n = sl.stop - sl.start
+        ctx.atoms_upload(n, 0, beads.ntypes, beads.x[sl], beads.v[sl], beads.type[sl], beads.tag[sl], beads.mask[sl],
+                         beads.ucgstate[sl], beads.ucgl[sl], beads.ucgvl[sl], beads.ucgml[sl], beads.ucgp[sl], beads.mass)
+        ctx.domain_set(beads.boxlo, beads.boxhi, 2.5, 0.3, every=2, delay=0, check=1)
+        pair = util.gpu_pair(ctx, "table_ucgld", deck)
+        tr = multi.Transport(dist, torch.device("cuda", 0), staged=True)
+        sim = multi.RankSim(ctx, pair, tr, grid, use_langevin=False, use_ucgstate=False)
+        e0, v0 = sim.setup(40)
+        A0 = ctx.atoms_download()
+        lo, hi = multi.sub_box(beads.boxlo, beads.boxhi, grid, rank)
+        inside = bool(np.all((A0["x"] >= lo) & (A0["x"] < hi)))
+        last = sim.run(40, thermo_every=40)
+        pair.check_errors()
+        A1 = ctx.atoms_download()
+        etot = tr.allreduce_sum([e0, last[0]])
+        result = dict(tag0=A0["tag"], f0=A0["f"], uf0=A0["ucgforce"], s0=A0["scores"], inside=inside, tag1=A1["tag"],
+                      x1=A1["x"], l1=A1["ucgl"], e0=etot[0], e1=etot[1], nrebuild=sim.nrebuild, nghost=A1["nghost"])
+        pair.close()
+        ctx.close()
+    with open(os.path.join(outdir, f"rank{rank}.pkl"), "wb") as fh:
+        pickle.dump(result, fh)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,116 @@
+"""N > 1 path: world_size-2 runs.  CPU tier: gloo, decomposition + transport protocol.
+GPU tier: both ranks share the one GPU of the box (gloo, host-staged buffers) and the
+decomposed run is compared with the single-rank GPU run of the same beads."""
+import os
+import pickle
+import socket
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+import util
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return str(p)
+
+
+def _launch(mode, world=2, timeout=300):
+    out = tempfile.mkdtemp(prefix="ucgmp_")
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "mp_worker.py"), mode, port, out], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o.decode(errors="replace"))
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {r} failed:\n{logs[r][-3000:]}"
+    return [pickle.load(open(os.path.join(out, f"rank{r}.pkl"), "rb")) for r in range(world)]
+
+
+def test_decomposition_helpers(pkg):
+    m = pkg.multi
+    assert m.choose_procgrid(1) == [1, 1, 1] and m.choose_procgrid(2) == [2, 1, 1]
+    assert m.choose_procgrid(4) == [2, 2, 1] and m.choose_procgrid(8) == [2, 2, 2]
+    lo, hi = np.zeros(3), np.array([10.0, 12.0, 14.0])
+    vol = 0.0
+    for me in range(8):
+        a, b = m.sub_box(lo, hi, [2, 2, 2], me)
+        vol += np.prod(b - a)
+        c = 0.5 * (a + b)
+        assert m.owner_rank(c[None, :], lo, hi, [2, 2, 2])[0] == me
+    assert abs(vol - np.prod(hi)) < 1e-9
+    # boundary points belong to the upper brick, the box top to the last one
+    assert m.owner_rank(np.array([[5.0, 0.0, 0.0]]), lo, hi, [2, 1, 1])[0] == 1
+    assert m.owner_rank(np.array([[4.999999, 0.0, 0.0]]), lo, hi, [2, 1, 1])[0] == 0
+
+
+def test_world2_gloo_exchange_protocol():
+    res = _launch("cpu")
+    tags = np.concatenate([r["tags"] for r in res])
+    assert sorted(tags.tolist()) == list(range(1, 1001))        # every bead exactly once
+    assert all(r["inside"] for r in res)                         # and inside its owner's brick
+    assert res[0]["rc"][1] == res[1]["counts"][0] and res[1]["rc"][0] == res[0]["counts"][1]
+    assert all(r["maxflag"] == 1 for r in res) and all(r["total"] == 1000 for r in res)
+
+
+@pytest.mark.gpu
+def test_world2_decomposed_run_matches_single_rank(fresh_ctx, pkg):
+    res = _launch("gpu")
+    assert all(r["inside"] for r in res)
+    assert all(r["nrebuild"] >= 2 and r["nghost"] > 0 for r in res)
+    # single-rank GPU run of the same beads, same settings
+    ctx = fresh_ctx
+    beads = pkg.synth.make_beads(10, seed=5)
+    deck = util.make_deck("spline", 1024)
+    ctx.set_units(1.0, 1.0, 1.0, 0.004)
+    ctx.upload_beads(beads)
+    ctx.domain_set(beads.boxlo, beads.boxhi, 2.5, 0.3, every=2, delay=0, check=1)
+    gp = util.gpu_pair(ctx, "table_ucgld", deck)
+    ctx.md_attach(gp, nve=True, langevin=False, ucgstate=False)
+    ctx.md_setup(40)
+    S0 = ctx.atoms_download()
+    e_single0 = ctx.md_thermo()["eng_vdwl"]
+    ctx.md_run(40, 40)
+    S1 = ctx.atoms_download()
+    e_single1 = ctx.md_thermo()["eng_vdwl"]
+
+    def by_tag(tag, arr):
+        out = np.zeros((beads.n,) + arr.shape[1:])
+        out[tag - 1] = arr
+        return out
+
+    tag0 = np.concatenate([r["tag0"] for r in res])
+    assert sorted(tag0.tolist()) == list(range(1, beads.n + 1))
+    for key, skey in (("f0", "f"), ("uf0", "ucgforce"), ("s0", "scores")):
+        multi = by_tag(tag0, np.concatenate([r[key] for r in res]))
+        single = by_tag(S0["tag"], S0[skey])
+        assert np.max(np.abs(multi - single)) <= 1e-11 * np.max(np.abs(single)), key
+    assert abs(res[0]["e0"] - e_single0) <= 1e-11 * abs(e_single0)
+    tag1 = np.concatenate([r["tag1"] for r in res])
+    x_multi = by_tag(tag1, np.concatenate([r["x1"] for r in res]))
+    x_single = by_tag(S1["tag"], S1["x"])
+    d = x_multi - x_single
+    d -= np.round(d / beads.boxhi) * beads.boxhi
+    assert np.max(np.abs(d)) < 1e-9
+    l_multi = by_tag(tag1, np.concatenate([r["l1"] for r in res]))
+    assert np.max(np.abs(l_multi - by_tag(S1["tag"], S1["ucgl"]))) < 1e-9
+    assert abs(res[0]["e1"] - e_single1) <= 1e-9 * abs(e_single1)
