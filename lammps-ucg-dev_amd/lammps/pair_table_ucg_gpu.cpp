@@ -1,0 +1,183 @@
+// USER-UCG/GPU pair styles: LAMMPS-side binding of libucg_hip.so -- see pair_table_ucg_gpu.h.
+//
+// Data flow per force evaluation (drop-in mode: LAMMPS keeps ownership of the host arrays):
+//   re-neighbour step : ucg_atoms_upload(all per-atom fields) + ucg_neigh_upload_full(full list
+//                       with the orientation bit tag[i] <= tag[j] set on every entry)
+//   every step        : ucg_atoms_upload_comm(x, ucgstate, ucgl, ucgp of owned + ghost atoms)
+//                       ucg_pair_compute  ->  ucg_atoms_download(f, ucgforce, scores [, ucgp])
+//                       results are ADDED to LAMMPS' arrays (force_clear has zeroed them)
+// The device kernels gather over a FULL list and leave nothing on ghosts, so newton_pair may
+// stay on (the reverse communication then adds zeros) and no fdotr virial is computed.
+#include "pair_table_ucg_gpu.h"
+
+#include "atom.h"
+#include "atom_vec_ucg_gpu.h"
+#include "comm.h"
+#include "error.h"
+#include "fix.h"
+#include "force.h"
+#include "memory.h"
+#include "modify.h"
+#include "neigh_list.h"
+#include "neighbor.h"
+#include "update.h"
+
+#include "ucg_hip.h"
+
+#include <vector>
+
+using namespace LAMMPS_NS;
+
+PairTableUCGGPU::PairTableUCGGPU(LAMMPS *lmp, int style) : Pair(lmp), ucg_style(style)
+{
+  no_virial_fdotr_compute = 1;    // the pair virial is returned by the kernel (reference: silently 0)
+  if (ucg_ctx_create(-1, &ctx) != UCG_OK)
+    error->all(FLERR, "USER-UCG/GPU: no usable HIP device (there is no CPU fallback in this package)");
+  check(ucg_pair_create(ctx, style, &gpair), true);
+}
+
+PairTableUCGGPU::~PairTableUCGGPU()
+{
+  if (copymode) return;
+  ucg_pair_destroy(gpair);
+  ucg_ctx_destroy(ctx);
+  if (allocated) {
+    memory->destroy(setflag);
+    memory->destroy(cutsq);
+  }
+}
+
+void PairTableUCGGPU::check(int rc, bool all)
+{
+  if (rc == UCG_OK) return;
+  if (all) error->all(FLERR, ucg_last_error(ctx));
+  else error->one(FLERR, ucg_last_error(ctx));
+}
+
+void PairTableUCGGPU::settings(int narg, char **arg)
+{
+  AtomVecUCG::get(lmp);    // "This pair style requires atom style ucg."
+  check(ucg_ctx_set_units(ctx, force->boltz, force->ftm2v, force->mvv2e, update->dt, force->special_lj), true);
+  check(ucg_pair_settings(gpair, narg, arg), true);
+}
+
+void PairTableUCGGPU::coeff(int narg, char **arg)
+{
+  if (!allocated) {
+    allocated = 1;
+    const int n = atom->ntypes + 1;
+    memory->create(setflag, n, n, "pair:setflag");
+    memory->create(cutsq, n, n, "pair:cutsq");
+    for (int i = 0; i < n; i++)
+      for (int j = 0; j < n; j++) setflag[i][j] = 0;
+  }
+  check(ucg_pair_coeff(gpair, atom->ntypes, narg, arg), true);
+  // the reference sets setflag for the FORMAL types it touched (UCG/pair_table_ucgld.cpp:844-845);
+  // formal types span 1..atom->ntypes, and init_one() below reports any pair still missing
+  for (int i = 1; i <= atom->ntypes; i++)
+    for (int j = i; j <= atom->ntypes; j++) setflag[i][j] = 1;
+}
+
+void PairTableUCGGPU::init_style()
+{
+  // full list, ghosts included as neighbours (they are never row owners)
+  neighbor->add_request(this, NeighConst::REQ_FULL);
+  // thermostat temperature, found like the reference does (UCG/pair_table_ucgld.cpp:873-881)
+  double *pT = nullptr;
+  int pdim;
+  for (int ifix = 0; ifix < modify->nfix; ifix++) {
+    pT = (double *) modify->fix[ifix]->extract("t_target", pdim);
+    if (pT) { T = *pT; break; }
+  }
+  if (!pT) error->all(FLERR, "USER-UCG/GPU pair styles need a fix that exports t_target (e.g. fix ucgld/langevin)");
+  check(ucg_ctx_set_units(ctx, force->boltz, force->ftm2v, force->mvv2e, update->dt, force->special_lj), true);
+  check(ucg_pair_init(gpair, atom->ntypes, T), true);
+}
+
+double PairTableUCGGPU::init_one(int i, int j)
+{
+  const double cut = ucg_pair_cut(gpair, i, j);
+  if (cut < 0.0) error->all(FLERR, "All pair coeffs are not set");
+  return cut;
+}
+
+void PairTableUCGGPU::upload_list()
+{
+  auto avec = AtomVecUCG::get(lmp);
+  const int nlocal = atom->nlocal, nghost = atom->nghost;
+  check(ucg_atoms_upload(ctx, nlocal, nghost, atom->ntypes, &atom->x[0][0], atom->v ? &atom->v[0][0] : nullptr, atom->type,
+                         atom->tag, atom->mask, avec->ucgstate, avec->ucgl, avec->ucgvl, avec->ucgml, avec->ucgp,
+                         atom->mass), false);
+  const int inum = list->inum;
+  if (inum != nlocal) error->one(FLERR, "USER-UCG/GPU: full neighbour list must have one row per owned atom");
+  std::vector<int> numneigh((size_t) inum);
+  std::vector<long long> first((size_t) inum);
+  long long total = 0;
+  for (int ii = 0; ii < inum; ii++) {
+    const int i = list->ilist[ii];
+    first[(size_t) i] = total;
+    numneigh[(size_t) i] = list->numneigh[i];
+    total += list->numneigh[i];
+  }
+  std::vector<int> flat((size_t) total + 1);
+  const tagint *tag = atom->tag;
+  for (int ii = 0; ii < inum; ii++) {
+    const int i = list->ilist[ii];
+    const int *jlist = list->firstneigh[i];
+    int *dst = &flat[(size_t) first[(size_t) i]];
+    for (int jj = 0; jj < list->numneigh[i]; jj++) {
+      const int j = jlist[jj] & NEIGHMASK;
+      const int sb = (jlist[jj] >> SBBITS) & 3;
+      const int orient = (tag[i] <= tag[j]) ? 1 : 0;    // the row owner plays the reference's "i"
+      dst[jj] = j | (orient << UCG_ORIENT_BIT) | (sb << UCG_SBBITS);
+    }
+  }
+  check(ucg_neigh_upload_full(ctx, inum, numneigh.data(), first.data(), flat.data()), false);
+  last_list_build = neighbor->lastcall;
+}
+
+void PairTableUCGGPU::compute(int eflag, int vflag)
+{
+  ev_init(eflag, vflag);
+  auto avec = AtomVecUCG::get(lmp);
+  const int nlocal = atom->nlocal;
+  if (neighbor->lastcall != last_list_build) upload_list();
+  else check(ucg_atoms_upload_comm(ctx, &atom->x[0][0], avec->ucgstate, avec->ucgl, avec->ucgp), false);
+
+  double eng = 0.0, vir[6] = {0, 0, 0, 0, 0, 0};
+  check(ucg_pair_compute(gpair, eflag_global, vflag_global, &eng, vir), false);
+  check(ucg_pair_check_errors(gpair), false);    // "Pair distance < table inner cutoff" etc.
+
+  std::vector<double> f((size_t) nlocal * 3), uf((size_t) nlocal), sc((size_t) nlocal * 2), up;
+  std::vector<int> ns((size_t) nlocal);
+  if (ucg_style == 2) up.resize((size_t) nlocal);
+  check(ucg_atoms_download(ctx, 0, nullptr, nullptr, f.data(), nullptr, nullptr, nullptr, ns.data(), nullptr, nullptr,
+                           nullptr, up.empty() ? nullptr : up.data(), uf.data(), sc.data()), false);
+  double **af = atom->f;
+  for (int i = 0; i < nlocal; i++) {
+    af[i][0] += f[3 * (size_t) i];
+    af[i][1] += f[3 * (size_t) i + 1];
+    af[i][2] += f[3 * (size_t) i + 2];
+    avec->num_ucgstates[i] = ns[(size_t) i];
+    if (ucg_style == 0) avec->ucgforce[i] += uf[(size_t) i];
+    if (ucg_style == 1) {
+      // table_ucg_bethe ASSIGNS the chemical-potential term (UCG/pair_table_ucg_bethe.cpp:155-162)
+      avec->ucgsoftmaxscores[i][0] = sc[2 * (size_t) i];
+      avec->ucgsoftmaxscores[i][1] = sc[2 * (size_t) i + 1];
+    } else if (ucg_style == 0) {
+      avec->ucgsoftmaxscores[i][0] += sc[2 * (size_t) i];
+      avec->ucgsoftmaxscores[i][1] += sc[2 * (size_t) i + 1];
+    }
+    if (ucg_style == 2) avec->ucgp[i] = up[(size_t) i];
+  }
+  if (eflag_global) eng_vdwl += eng;
+  if (vflag_global)
+    for (int k = 0; k < 6; k++) virial[k] += vir[k];
+}
+
+double PairTableUCGGPU::single(int, int, int itype, int jtype, double rsq, double, double factor_lj, double &fforce)
+{
+  double e = 0.0;
+  check(ucg_pair_single(gpair, itype, jtype, rsq, factor_lj, &fforce, &e), false);
+  return e;
+}

@@ -1,0 +1,64 @@
+/* -*- c++ -*- ----------------------------------------------------------
+   USER-UCG/GPU: pair styles table_ucgld, table_ucg_bethe, table_ucg_bethe_density
+   backed by libucg_hip.so (include/ucg_hip.h).  Same style names and the same
+   pair_style / pair_coeff syntax as the reference (UCG/pair_table_ucgld.h:1-3,
+   UCG/pair_table_ucg_bethe.h:31-33, UCG/pair_table_ucg_bethe_density.h:27-29).
+
+   Compiles only inside a LAMMPS source tree (needs pair.h); see INTEGRATION.md.
+------------------------------------------------------------------------- */
+#ifdef PAIR_CLASS
+// clang-format off
+PairStyle(table_ucgld,PairTableUCGLDGPU);
+PairStyle(table_ucg_bethe,PairTableUCGBetheGPU);
+PairStyle(table_ucg_bethe_density,PairTableUCGBetheDensityGPU);
+// clang-format on
+#else
+#ifndef LMP_PAIR_TABLE_UCG_GPU_H
+#define LMP_PAIR_TABLE_UCG_GPU_H
+
+#include "pair.h"
+
+struct ucg_ctx;
+struct ucg_pair;
+
+namespace LAMMPS_NS {
+
+class PairTableUCGGPU : public Pair {
+ public:
+  PairTableUCGGPU(class LAMMPS *, int style);
+  ~PairTableUCGGPU() override;
+  void compute(int, int) override;
+  void settings(int, char **) override;
+  void coeff(int, char **) override;
+  void init_style() override;
+  double init_one(int, int) override;
+  double single(int, int, int, int, double, double, double, double &) override;
+  void write_restart(FILE *) override {}
+  void read_restart(FILE *) override {}
+
+ protected:
+  int ucg_style;
+  ucg_ctx *ctx = nullptr;
+  ucg_pair *gpair = nullptr;
+  bigint last_list_build = -1;
+  double T = 0.0;
+  void check(int rc, bool all);
+  void upload_list();
+};
+
+class PairTableUCGLDGPU : public PairTableUCGGPU {
+ public:
+  PairTableUCGLDGPU(class LAMMPS *lmp) : PairTableUCGGPU(lmp, 0) {}
+};
+class PairTableUCGBetheGPU : public PairTableUCGGPU {
+ public:
+  PairTableUCGBetheGPU(class LAMMPS *lmp) : PairTableUCGGPU(lmp, 1) {}
+};
+class PairTableUCGBetheDensityGPU : public PairTableUCGGPU {
+ public:
+  PairTableUCGBetheDensityGPU(class LAMMPS *lmp) : PairTableUCGGPU(lmp, 2) {}
+};
+
+}    // namespace LAMMPS_NS
+#endif
+#endif
