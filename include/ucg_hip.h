@@ -69,7 +69,9 @@ int ucg_ctx_set_units(ucg_ctx *ctx, double boltz, double ftm2v, double mvv2e, do
 
 /* options: "generic_kernels" = 1 keeps the pair kernels on their general code path (per-table
  * grid lookup, IEEE division) even when the faster equivalent variants apply; takes effect
- * at the next ucg_pair_init.  Used by the tests to check that both give the same bits. */
+ * at the next ucg_pair_init.  Used by the tests to check that both give the same bits.
+ * "density_proximity_as_shipped" = 1 makes table_ucg_bethe_density use the proximity function
+ * itself in the CV back-force, as shipped (:719), instead of its derivative. */
 int ucg_ctx_set_option(ucg_ctx *ctx, const char *name, int value);
 /* device self-test: n random operands, counts a / b != div_by_const(a, b) (must be 0) */
 int ucg_selftest_div(ucg_ctx *ctx, double b, long long seed, int n, long long *mismatches);
@@ -137,6 +139,11 @@ int ucg_atoms_download(ucg_ctx *ctx, int with_ghosts, double *x, double *v, doub
                        int *tag, int *ucgstate, int *num_ucgstates, double *ucgl, double *ucgvl,
                        double *ucgml, double *ucgp, double *ucgforce, double *ucgsoftmaxscores);
 int ucg_atoms_counts(const ucg_ctx *ctx, int *nlocal, int *nghost);
+/* which owned atom each ghost is a periodic image of (host-built ghosts only; the device
+ * builder records it itself).  table_ucg_bethe_density needs it to give ghosts their owner's
+ * prior and CV force -- the forward_comm the reference declares but never performs
+ * (UCG/pair_table_ucg_bethe_density.cpp:280 vs ...density.h:107-110). */
+int ucg_ghosts_upload(ucg_ctx *ctx, const int *src, int nghost);
 /* AtomVecUCG::force_clear (UCG/atom_vec_ucg.cpp:131-135) + Verlet::force_clear */
 int ucg_force_clear(ucg_ctx *ctx);
 

@@ -36,7 +36,7 @@ SYMBOLS = [
     "ucg_pair_cut", "ucg_pair_cutforce", "ucg_pair_single", "ucg_pair_table_count",
     "ucg_pair_table_params", "ucg_pair_table_array", "ucg_pair_tabindex", "ucg_pair_compute",
     "ucg_pair_check_errors",
-    "ucg_atoms_upload", "ucg_atoms_upload_comm", "ucg_atoms_download", "ucg_atoms_counts", "ucg_force_clear",
+    "ucg_atoms_upload", "ucg_atoms_upload_comm", "ucg_atoms_download", "ucg_atoms_counts", "ucg_ghosts_upload", "ucg_force_clear",
     "ucg_neigh_upload_full", "ucg_domain_set", "ucg_neigh_rebuild", "ucg_halo_forward", "ucg_neigh_download",
     "ucg_ghosts_download",
     "ucg_fix_nve_initial", "ucg_fix_nve_final",
@@ -105,6 +105,7 @@ def lib():
     L.ucg_atoms_download.argtypes = [vp, C.c_int, c_double_p, c_double_p, c_double_p, c_int_p, c_int_p, c_int_p,
                                      c_int_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]
     L.ucg_atoms_counts.argtypes = [vp, c_int_p, c_int_p]
+    L.ucg_ghosts_upload.argtypes = [vp, c_int_p, C.c_int]
     L.ucg_force_clear.argtypes = [vp]
     L.ucg_neigh_upload_full.argtypes = [vp, C.c_int, c_int_p, c_ll_p, c_int_p]
     L.ucg_domain_set.argtypes = [vp, c_double_p, c_double_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int]
@@ -247,6 +248,10 @@ class Context:
             _dp(out["ucgml"]), _dp(out["ucgp"]), _dp(out["ucgforce"]), _dp(out["scores"])))
         out["nlocal"], out["nghost"] = nl, ng
         return out
+
+    def ghosts_upload(self, src):
+        s = _i32(src)
+        self.chk(self.L.ucg_ghosts_upload(self.h, _ip(s), len(s)))
 
     def force_clear(self):
         self.chk(self.L.ucg_force_clear(self.h))

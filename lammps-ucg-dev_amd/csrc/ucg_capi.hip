@@ -313,12 +313,24 @@ int ucg_pair_init(ucg_pair *p, int ntypes, double T)
         prior[(size_t) ti * 2 + s] = M.prior_prob_from_type[(size_t) ti * ms + s];
       }
     }
+    std::vector<int> dflags((size_t) na1 * 2, 0);
+    std::vector<double> dpar((size_t) na1 * 2, 0.0);
+    for (int ti = 1; ti <= M.n_actual; ti++) {
+      dflags[(size_t) ti * 2 + 0] = M.use_density[(size_t) ti];
+      dflags[(size_t) ti * 2 + 1] = M.use_state_entropy[(size_t) ti];
+      dpar[(size_t) ti * 2 + 0] = M.cv_thresholds[(size_t) ti];
+      dpar[(size_t) ti * 2 + 1] = M.threshold_radii[(size_t) ti];
+    }
+    p->d_densflags.reserve(dflags.size());
+    p->d_denspar.reserve(dpar.size());
+    h2d(ctx, p->d_densflags.get(), dflags.data(), dflags.size());
+    h2d(ctx, p->d_denspar.get(), dpar.data(), dpar.size());
     p->d_tab.reserve(tab.size());
     p->d_tabpar.reserve(par.size());
     p->d_pairtab.reserve(pairtab.size());
     p->d_cutsq.reserve(cutsq.size());
     p->d_mu.reserve(mu.size());
-    p->d_prior.reserve(prior.size());
+    p->d_prior_type.reserve(prior.size());
     p->d_err.reserve(4);
     p->d_evout.reserve(8);
     h2d(ctx, p->d_tab.get(), tab.data(), tab.size());
@@ -326,7 +338,7 @@ int ucg_pair_init(ucg_pair *p, int ntypes, double T)
     h2d(ctx, p->d_pairtab.get(), pairtab.data(), pairtab.size());
     h2d(ctx, p->d_cutsq.get(), cutsq.data(), cutsq.size());
     h2d(ctx, p->d_mu.get(), mu.data(), mu.size());
-    h2d(ctx, p->d_prior.get(), prior.data(), prior.size());
+    h2d(ctx, p->d_prior_type.get(), prior.data(), prior.size());
     UCG_HIP(hipMemsetAsync(p->d_err.get(), 0, 4 * sizeof(int), ctx->stream));
     sync(ctx);
 
@@ -347,7 +359,10 @@ int ucg_pair_init(ucg_pair *p, int ntypes, double T)
     D.pairtab = p->d_pairtab.get();
     D.cutsq = p->d_cutsq.get();
     D.mu = p->d_mu.get();
-    D.prior_type = p->d_prior.get();
+    D.prior_type = p->d_prior_type.get();
+    D.dens_flags = p->d_densflags.get();
+    D.dens_par = p->d_denspar.get();
+    D.dens_as_shipped = ctx->density_proximity_as_shipped ? 1 : 0;
     D.kT = M.kT;
     D.rkT = 1.0 / M.kT;
     for (int i = 0; i < 4; i++) D.special_lj[i] = ctx->special_lj[i];
@@ -463,7 +478,6 @@ int ucg_pair_compute(ucg_pair *p, int eflag, int vflag, double *eng_vdwl, double
   ucg_ctx *ctx = p->ctx;
   return guarded(ctx, [&]() -> int {
     if (!p->uploaded) return fail(ctx, UCG_ERR_INVALID, "ucg_pair_compute before ucg_pair_init");
-    if (p->model.style == STYLE_BETHE_DENSITY) return fail(ctx, UCG_ERR_UNSUPPORTED, "table_ucg_bethe_density kernels are not built yet");
     if (ctx->list_inum != ctx->nlocal) return fail(ctx, UCG_ERR_INVALID, "neighbour list does not match the resident atoms");
     const bool ev = (eflag || vflag);
     const int nb = pair_gather_blocks(ctx->nlocal);
@@ -474,8 +488,23 @@ int ucg_pair_compute(ucg_pair *p, int eflag, int vflag, double *eng_vdwl, double
       UCG_HIP(hipEventCreate(&e1));
       UCG_HIP(hipEventRecord(e0, ctx->stream));
     }
-    UCG_HIP(launch_pair_gather(p->dev, ctx->atoms_dev(), ctx->list_dev(), ev, p->d_evpart.get(), p->d_evout.get(),
-                               p->d_err.get(), ctx->stream));
+    if (p->model.style == STYLE_BETHE_DENSITY) {
+      if (ctx->nghost > 0 && !ctx->ghost_src_valid)
+        return fail(ctx, UCG_ERR_UNSUPPORTED,
+                    "table_ucg_bethe_density needs the ghost -> owner map (ucg_ghosts_upload or the device builder); "
+                    "decomposed runs are not covered yet");
+      const size_t nall = (size_t) ctx->nlocal + ctx->nghost;
+      p->d_prior.reserve(nall + 1);
+      p->d_cv.reserve(nall + 1);
+      p->d_partial.reserve((size_t) ctx->nlocal + 1);
+      p->d_evpart.reserve((size_t) density_evpart_doubles(ctx->nlocal));
+      UCG_HIP(launch_density(p->dev, ctx->atoms_dev(), ctx->list_dev(), ctx->ghost_src.get(), ev, p->d_prior.get(),
+                             p->d_partial.get(), p->d_cv.get(), p->d_evpart.get(), p->d_evout.get(), p->d_err.get(),
+                             ctx->stream));
+    } else {
+      UCG_HIP(launch_pair_gather(p->dev, ctx->atoms_dev(), ctx->list_dev(), ev, p->d_evpart.get(), p->d_evout.get(),
+                                 p->d_err.get(), ctx->stream));
+    }
     if (ctx->prof_on) {
       UCG_HIP(hipEventRecord(e1, ctx->stream));
       ctx->prof_ev.push_back(e0);
@@ -568,6 +597,7 @@ int ucg_atoms_upload(ucg_ctx *ctx, int nlocal, int nghost, int ntypes, const dou
     ctx->nghost = nghost;
     ctx->ntypes = ntypes;
     ctx->list_inum = 0;
+    ctx->ghost_src_valid = (nghost == 0);
     return UCG_OK;
   });
 }
@@ -636,6 +666,21 @@ int ucg_atoms_download(ucg_ctx *ctx, int with_ghosts, double *x, double *v, doub
       if (f) { f[3 * i] = f4[i].x; f[3 * i + 1] = f4[i].y; f[3 * i + 2] = f4[i].z; }
       if (ucgforce) ucgforce[i] = f4[i].w;
     }
+    return UCG_OK;
+  });
+}
+
+int ucg_ghosts_upload(ucg_ctx *ctx, const int *src, int nghost)
+{
+  if (!ctx || nghost < 0 || (nghost > 0 && !src)) return UCG_ERR_INVALID;
+  return guarded(ctx, [&]() -> int {
+    if (nghost != ctx->nghost) return fail(ctx, UCG_ERR_INVALID, "ghost map length differs from the resident ghost count");
+    for (int g = 0; g < nghost; g++)
+      if (src[g] < 0 || src[g] >= ctx->nlocal) return fail(ctx, UCG_ERR_INVALID, "ghost source index out of range");
+    ctx->ghost_src.reserve((size_t) nghost + 1);
+    h2d(ctx, ctx->ghost_src.get(), src, (size_t) nghost);
+    sync(ctx);
+    ctx->ghost_src_valid = true;
     return UCG_OK;
   });
 }
@@ -948,6 +993,10 @@ int ucg_ctx_set_option(ucg_ctx *ctx, const char *name, int value)
   if (!ctx || !name) return UCG_ERR_INVALID;
   if (std::strcmp(name, "generic_kernels") == 0) {
     ctx->force_generic_kernels = value != 0;
+    return UCG_OK;
+  }
+  if (std::strcmp(name, "density_proximity_as_shipped") == 0) {
+    ctx->density_proximity_as_shipped = value != 0;
     return UCG_OK;
   }
   ctx->err = std::string("unknown option ") + name;

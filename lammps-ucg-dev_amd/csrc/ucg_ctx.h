@@ -92,6 +92,7 @@ struct ucg_ctx {
   std::string err;
   double boltz = 1, ftm2v = 1, mvv2e = 1, dt = 0.005;
   double special_lj[4] = {1, 1, 1, 1};
+  bool density_proximity_as_shipped = false;  // option of the same name (App. B #12)
   bool force_generic_kernels = false;  // option "generic_kernels": never pick the FAST variants
 
   // atoms
@@ -102,6 +103,8 @@ struct ucg_ctx {
   ucg::DevBuf<double> ucgp, ucgml, mass;
   // neighbour list
   ucg::DevBuf<int> neigh, numneigh;
+  ucg::DevBuf<int> ghost_src;  // owned bead each ghost images (single-rank periodic images)
+  bool ghost_src_valid = false;
   int list_pitch = 0, list_maxrow = 0, list_inum = 0;
   long long list_entries = 0;
   // shared RanMars jump table
@@ -139,9 +142,13 @@ struct ucg_pair {
   bool uploaded = false;
   ucg::DevBuf<double4> d_tab, d_tabpar, d_tab_fast;
   ucg::DevBuf<int> d_pairtab;
-  ucg::DevBuf<double> d_cutsq, d_mu, d_prior;
+  ucg::DevBuf<double> d_cutsq, d_mu, d_prior_type;
   ucg::DevBuf<int> d_err;
   ucg::DevBuf<double> d_evpart, d_evout;
+  // table_ucg_bethe_density
+  ucg::DevBuf<double2> d_prior, d_cv;
+  ucg::DevBuf<double> d_partial, d_denspar;
+  ucg::DevBuf<int> d_densflags;
   std::vector<int> tabmap;  // host table id -> device table id (or -1)
   std::string err;
   double host_boltz = 1.0;  // used by host-only pairs (no context)

@@ -1,0 +1,381 @@
+// ucg_density.hip -- table_ucg_bethe_density on gfx950: the three passes of
+// PairTable_UCG_Bethe_Density::compute (UCG/pair_table_ucg_bethe_density.cpp:133-758,
+// helpers :107-127), Scenario 4 (:529-658), as gathers over the FULL neighbour list.
+//
+//   k_density_pass1   :219-274   rho_k = sum_m w(r) -> prior p_k0 = 1/2 + 1/2 tanh((rho-rho_th)/(0.1 rho_th))
+//   (halo)                       ghosts take their owner's prior   (the reference's forward_comm moves
+//                                0 bytes, App. B #7: ghost priors = 0 -> log(0/0) = NaN back-forces)
+//   k_density_pass2   :284-696   tables, pseudo-likelihood scores, Bethe closure (as shipped, unguarded),
+//                                pair forces (x 1/2 when the neighbour is owned: newton off, full list),
+//                                entropic accumulators G, posterior -> ucgp, CV forces G * dp/drho
+//   (halo)                       ghosts take their owner's CV forces
+//   k_density_pass3   :698-733   back-force of the density CV over the neighbours
+//
+// The reference scatters to owned neighbours (f[j] -= ...); here a bead also evaluates what
+// each neighbour's own visit of the pair would send it (the closure with the roles swapped,
+// the neighbour's CV force), so nothing is scattered and the sums are formed in row order.
+// Decisions where the shipped text is undefined are listed in DESIGN.md (App. B #7-#12).
+// Same arithmetic contract as ucg_pair.hip (-ffp-contract=off, ucg_math.h for exp/log/tanh).
+#include "ucg_pair_dev.h"
+
+namespace ucg {
+
+namespace {
+
+constexpr int DENS_BLOCK = 256;
+
+__device__ __forceinline__ double prox_fn(const double rth, const double r)
+{
+  const double t = ucg_tanh((r - rth) / (0.1 * rth));
+  return 0.5 * (1.0 - t);
+}
+
+__device__ __forceinline__ double prox_der(const double rth, const double r)
+{
+  const double t = ucg_tanh((r - rth) / (0.1 * rth));
+  return 0.5 * (1.0 - t * t) / (0.1 * rth);
+}
+
+__global__ __launch_bounds__(DENS_BLOCK) void k_density_pass1(const PairDev P, const AtomsDev A, const ListDev Lst,
+                                                             double2 *prior, double *partial0)
+{
+  const int k = blockIdx.x * DENS_BLOCK + threadIdx.x;
+  if (k >= A.nlocal) return;
+  const double4 pk = A.pos4[k];
+  const int tk = UCG_META_TYPE(A.meta[k]);
+  const int na1 = P.n_actual + 1;
+  if (P.dens_flags[tk * 2 + 0] == 1) {
+    const double rth = P.dens_par[tk * 2 + 1];
+    const int n = Lst.numneigh[k];
+    const int *rp = Lst.neigh + k;
+    double rho = 0.0;
+    for (int e = 0; e < n; e++, rp += Lst.pitch) {
+      const int m = rp[0] & 0x1FFFFFFF;
+      const double4 pm = A.pos4[m];
+      const int tm = UCG_META_TYPE(A.meta[m]);
+      const double dx = pk.x - pm.x, dy = pk.y - pm.y, dz = pk.z - pm.z;
+      const double rsq = dx * dx + dy * dy + dz * dz;
+      if (rsq < P.cutsq[tk * na1 + tm]) rho += prox_fn(rth, sqrt(rsq));
+    }
+    const double cth = P.dens_par[tk * 2 + 0];
+    const double th = ucg_tanh((rho - cth) / (0.1 * cth));
+    const double p0 = 0.5 + 0.5 * th;
+    prior[k] = make_double2(p0, 1.0 - p0);
+    partial0[k] = 0.5 * (1.0 - th * th) / (0.1 * cth);
+  } else {
+    const double e0 = ucg_exp(-P.mu[tk * 2 + 0] / P.kT);
+    const double e1 = ucg_exp(-P.mu[tk * 2 + 1] / P.kT);
+    double den = 0.0;
+    den += e0;
+    den += e1;
+    prior[k] = make_double2(e0 / den, e1 / den);
+    partial0[k] = 0.0;
+  }
+}
+
+__global__ __launch_bounds__(DENS_BLOCK) void k_ghost_copy2(int ng, int nlocal, const int *ghost_src, double2 *arr)
+{
+  const int g = blockIdx.x * DENS_BLOCK + threadIdx.x;
+  if (g < ng) arr[nlocal + g] = arr[ghost_src[g]];
+}
+
+// closure as shipped (:608-622): a = b - 1, no guards
+__device__ __forceinline__ void closure_shipped(const double kT, const double u00, const double u01, const double u10,
+                                                const double u11, const double pi1, const double pj1, double &p00,
+                                                double &p01, double &p10, double &p11)
+{
+  const double Jij = u11 + u00 - u01 - u10;
+  const double bij = ucg_exp(-Jij / kT);
+  const double aij = bij - 1.;
+  const double Qij = (pi1 + pj1) * aij + 1.;
+  const double Dij = sqrt(Qij * Qij - 4. * aij * bij * pi1 * pj1);
+  p11 = (Qij - Dij) / 2. / aij;
+  p00 = 1. + p11 - pi1 - pj1;
+  p10 = pi1 - p11;
+  p01 = pj1 - p11;
+}
+
+template <int TS, bool EV, bool LDS_TAB, bool FAST>
+__global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass2(const PairDev P, const AtomsDev A, const ListDev Lst,
+                                                             const double2 *prior, const double *partial0, double2 *cv,
+                                                             double *evpart, int *errflag)
+{
+  extern __shared__ double4 s_tab[];
+  __shared__ double s_red[(PAIR_BLOCK / 64) * 8];
+  __shared__ double4 s_par[UCG_MAX_TABLES];
+  __shared__ int s_pairtab[(UCG_MAX_ACTUAL + 1) * (UCG_MAX_ACTUAL + 1) * 4];
+  __shared__ double s_cutsq[(UCG_MAX_ACTUAL + 1) * (UCG_MAX_ACTUAL + 1)];
+
+  const int ntabent = FAST ? (P.tablength * P.fast_stride + 1) / 2 : P.ntab * P.tablength;
+  {
+    const int na1sq = (P.n_actual + 1) * (P.n_actual + 1);
+    for (int t = threadIdx.x; t < P.ntab; t += blockDim.x) s_par[t] = P.tabpar[t];
+    for (int t = threadIdx.x; t < na1sq * 4; t += blockDim.x) s_pairtab[t] = P.pairtab[t];
+    for (int t = threadIdx.x; t < na1sq; t += blockDim.x) s_cutsq[t] = P.cutsq[t];
+    if (LDS_TAB)
+      for (int t = threadIdx.x; t < ntabent; t += blockDim.x) s_tab[t] = (FAST ? P.tab_fast : P.tab)[t];
+    __syncthreads();
+  }
+
+  const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
+  const int k = chunk * PAIR_BLOCK + threadIdx.x;
+  const int nlocal = A.nlocal;
+  const int na1 = P.n_actual + 1;
+  const double kT = P.kT;
+  double ev[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int err = 0;
+
+  if (k < nlocal) {
+    const double4 pk = A.pos4[k];
+    const int tk = UCG_META_TYPE(A.meta[k]);
+    const int n = Lst.numneigh[k];
+    const int *rp = Lst.neigh + k;
+    const size_t pitch = (size_t) Lst.pitch;
+    const double2 prk = prior[k];
+    const bool dens_k = P.dens_flags[tk * 2 + 0] == 1;
+
+    double fx = 0.0, fy = 0.0, fz = 0.0, s0 = 0.0, s1 = 0.0, G0 = 0.0, G1 = 0.0;
+    if (dens_k) {
+      // one-body terms (:302-314); jnum is the whole row, skin included, as shipped
+      const double jnum_f = 1. - n;
+      const double mu0 = P.mu[tk * 2 + 0], mu1 = P.mu[tk * 2 + 1];
+      if (P.dens_flags[tk * 2 + 1]) {
+        G0 -= kT * ucg_log(prk.x) * jnum_f;
+        G1 -= kT * ucg_log(prk.y) * jnum_f;
+      }
+      G0 -= mu0;
+      s0 -= mu0 / kT;
+      G1 -= mu1;
+      s1 -= mu1 / kT;
+    }
+
+    for (int e = 0; e < n; e++, rp += pitch) {
+      const int ent = rp[0];
+      const int m = ent & 0x1FFFFFFF;
+      double factor_lj = 1.0;
+      if (!FAST) {
+        const int sb = (ent >> 30) & 3;
+        factor_lj = sb == 0 ? P.special_lj[0] : sb == 1 ? P.special_lj[1] : sb == 2 ? P.special_lj[2] : P.special_lj[3];
+      }
+      const double4 pm = A.pos4[m];
+      const int mm = A.meta[m];
+      const int tm = UCG_META_TYPE(mm);
+      const int sm = UCG_META_STATE(mm);
+      const double dx = pk.x - pm.x, dy = pk.y - pm.y, dz = pk.z - pm.z;
+      const double rsq = dx * dx + dy * dy + dz * dz;
+      if (rsq < s_cutsq[tk * na1 + tm]) {
+        const int *pt = s_pairtab + (tk * na1 + tm) * 4;
+        Quad q;
+        if (LDS_TAB) eval_quad<TS, FAST>(s_tab, s_par, pt, P.tablength, P.tlm1, P.fast_stride, rsq, factor_lj, q, err);
+        else eval_quad<TS, FAST>(FAST ? P.tab_fast : P.tab, s_par, pt, P.tablength, P.tlm1, P.fast_stride, rsq, factor_lj, q, err);
+        // scores: only the row owner's (:597-603)
+        s0 -= (sm ? q.u01 : q.u00) / kT;
+        s1 -= (sm ? q.u11 : q.u10) / kT;
+        const double pm1 = prior[m].y;
+        double p00, p01, p10, p11;
+        closure_shipped(kT, q.u00, q.u01, q.u10, q.u11, prk.y, pm1, p00, p01, p10, p11);
+        double evdwl = p00 * q.u00 + p01 * q.u01 + p10 * q.u10 + p11 * q.u11;
+        double fpair = p00 * q.f00 + p01 * q.f01 + p10 * q.f10 + p11 * q.f11;
+        const bool m_owned = m < nlocal;
+        if (m_owned) {
+          evdwl = evdwl * 0.5;
+          fpair = fpair * 0.5;
+        }
+        fx += dx * fpair;
+        fy += dy * fpair;
+        fz += dz * fpair;
+        if (m_owned) {
+          // what m's own visit of this pair sends to k: roles swapped (its u[a][b] is our u[b][a])
+          double t00, t01, t10, t11;
+          closure_shipped(kT, q.u00, q.u10, q.u01, q.u11, pm1, prk.y, t00, t01, t10, t11);
+          double fpj = t00 * q.f00 + t01 * q.f10 + t10 * q.f01 + t11 * q.f11;
+          fpj = fpj * 0.5;
+          const double djx = pm.x - pk.x, djy = pm.y - pk.y, djz = pm.z - pk.z;
+          fx -= djx * fpj;
+          fy -= djy * fpj;
+          fz -= djz * fpj;
+        }
+        if (EV) {
+          const double sc = m_owned ? 1.0 : 0.5;
+          ev[0] += m_owned ? evdwl : 0.5 * evdwl;
+          ev[1] += sc * (dx * dx * fpair);
+          ev[2] += sc * (dy * dy * fpair);
+          ev[3] += sc * (dz * dz * fpair);
+          ev[4] += sc * (dx * dy * fpair);
+          ev[5] += sc * (dx * dz * fpair);
+          ev[6] += sc * (dy * dz * fpair);
+        }
+        if (dens_k) {
+          G0 -= (q.u10 - q.u00 + kT * ucg_log(p10 / p00));
+          G1 -= (q.u11 - q.u01 + kT * ucg_log(p11 / p01));
+        }
+      }
+    }
+    A.frc4[k] = make_double4(fx, fy, fz, 0.0);
+    A.scores[k] = make_double2(s0, s1);
+    A.num_ucgstates[k] = 2;
+    // posterior (:678-689), index fixed to the bead's type (App. B #8)
+    {
+      const double e0 = ucg_exp(s0), e1 = ucg_exp(s1);
+      double den = 0.0;
+      den += e0;
+      den += e1;
+      A.ucgp[k] = e1 / den;
+    }
+    double2 c = make_double2(0.0, 0.0);
+    if (dens_k) {
+      const double pa = partial0[k];
+      c.x = G0 * pa;
+      c.y = G1 * (-pa);
+    }
+    cv[k] = c;
+  }
+  if (err) atomicOr(errflag, err);
+  if (EV) block_sum_store<8>(ev, s_red, evpart);
+}
+
+template <bool EV>
+__global__ __launch_bounds__(DENS_BLOCK) void k_density_pass3(const PairDev P, const AtomsDev A, const ListDev Lst,
+                                                             const double2 *cv, double *evpart)
+{
+  __shared__ double s_red[(DENS_BLOCK / 64) * 8];
+  const int k = blockIdx.x * DENS_BLOCK + threadIdx.x;
+  const int na1 = P.n_actual + 1;
+  double ev[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (k < A.nlocal) {
+    const double4 pk = A.pos4[k];
+    const int tk = UCG_META_TYPE(A.meta[k]);
+    const bool dens_k = P.dens_flags[tk * 2 + 0] == 1;
+    const double rth_k = P.dens_par[tk * 2 + 1];
+    const double2 cvk = cv[k];
+    double4 f = A.frc4[k];
+    const int n = Lst.numneigh[k];
+    const int *rp = Lst.neigh + k;
+    for (int e = 0; e < n; e++, rp += Lst.pitch) {
+      const int m = rp[0] & 0x1FFFFFFF;
+      const double4 pm = A.pos4[m];
+      const int tm = UCG_META_TYPE(A.meta[m]);
+      const double dx = pk.x - pm.x, dy = pk.y - pm.y, dz = pk.z - pm.z;
+      const double rsq = dx * dx + dy * dy + dz * dz;
+      const bool in_k = dens_k && rsq < P.cutsq[tk * na1 + tm];
+      const bool dens_m = P.dens_flags[tm * 2 + 0] == 1;
+      const bool in_m = dens_m && rsq < P.cutsq[tm * na1 + tk];
+      if (!(in_k || in_m)) continue;
+      const double distance = sqrt(rsq);
+      if (in_k) {
+        const double w = P.dens_as_shipped ? prox_fn(rth_k, distance) : prox_der(rth_k, distance);
+        for (int s = 0; s < 2; s++) {
+          const double fpair = (s ? cvk.y : cvk.x) * w / distance;
+          f.x += fpair * dx;
+          f.y += fpair * dy;
+          f.z += fpair * dz;
+          if (EV) {
+            ev[1] += dx * dx * fpair;
+            ev[2] += dy * dy * fpair;
+            ev[3] += dz * dz * fpair;
+            ev[4] += dx * dy * fpair;
+            ev[5] += dx * dz * fpair;
+            ev[6] += dy * dz * fpair;
+          }
+        }
+      }
+      if (in_m) {
+        const double rth_m = P.dens_par[tm * 2 + 1];
+        const double w = P.dens_as_shipped ? prox_fn(rth_m, distance) : prox_der(rth_m, distance);
+        const double2 cvm = cv[m];
+        const double djx = pm.x - pk.x, djy = pm.y - pk.y, djz = pm.z - pk.z;
+        for (int s = 0; s < 2; s++) {
+          const double fpair = (s ? cvm.y : cvm.x) * w / distance;
+          f.x -= fpair * djx;
+          f.y -= fpair * djy;
+          f.z -= fpair * djz;
+        }
+      }
+    }
+    A.frc4[k] = f;
+  }
+  if (EV) block_sum_store<8>(ev, s_red, evpart);
+}
+
+__global__ void k_ev_final2(const double *part, int nb1, const double *part3, int nb3, double *out)
+{
+  const int c = threadIdx.x;
+  if (c < 8) {
+    double s = 0.0;
+    for (int b = 0; b < nb1; b++) s += part[(size_t) b * 8 + c];
+    for (int b = 0; b < nb3; b++) s += part3[(size_t) b * 8 + c];
+    out[c] = s;
+  }
+}
+
+template <int TS>
+hipError_t launch_pass2(const PairDev &P, const AtomsDev &A, const ListDev &L, bool ev, const double2 *prior,
+                        const double *partial0, double2 *cv, double *evpart, int *errflag, hipStream_t st, int nblocks)
+{
+  const size_t tabbytes = P.fast ? ((size_t) (P.tablength * P.fast_stride + 1) / 2) * sizeof(double4)
+                                 : (size_t) P.ntab * P.tablength * sizeof(double4);
+  const size_t ldsbytes = P.tab_in_lds ? tabbytes : 0;
+#define UCG_LAUNCH(EVF, LDSF, FASTF)                                                                     \
+  do {                                                                                                   \
+    auto kern = k_density_pass2<TS, EVF, LDSF, FASTF>;                                                   \
+    if (ldsbytes > 48 * 1024) {                                                                          \
+      hipError_t e = hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                         (int) ldsbytes);                                                \
+      if (e != hipSuccess) return e;                                                                     \
+    }                                                                                                    \
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(PAIR_BLOCK), ldsbytes, st, P, A, L, prior, partial0, cv, evpart, \
+                       errflag);                                                                         \
+  } while (0)
+  const int sel = (P.tab_in_lds ? 4 : 0) | (ev ? 2 : 0) | (P.fast ? 1 : 0);
+  switch (sel) {
+    case 0: UCG_LAUNCH(false, false, false); break;
+    case 1: UCG_LAUNCH(false, false, true); break;
+    case 2: UCG_LAUNCH(true, false, false); break;
+    case 3: UCG_LAUNCH(true, false, true); break;
+    case 4: UCG_LAUNCH(false, true, false); break;
+    case 5: UCG_LAUNCH(false, true, true); break;
+    case 6: UCG_LAUNCH(true, true, false); break;
+    default: UCG_LAUNCH(true, true, true); break;
+  }
+#undef UCG_LAUNCH
+  return hipGetLastError();
+}
+
+}  // namespace
+
+// prior / cv: [nlocal + nghost] double2; partial0: [nlocal]; evpart: 8 * (blocks2 + blocks3) doubles
+hipError_t launch_density(const PairDev &P, const AtomsDev &A, const ListDev &L, const int *ghost_src, bool ev,
+                          double2 *prior, double *partial0, double2 *cv, double *evpart, double *evout, int *errflag,
+                          hipStream_t st)
+{
+  const int n = A.nlocal;
+  if (n == 0) return hipSuccess;
+  const int nb = (n + DENS_BLOCK - 1) / DENS_BLOCK;
+  const int nb2 = (n + PAIR_BLOCK - 1) / PAIR_BLOCK;
+  const int ngb = (A.nghost + DENS_BLOCK - 1) / DENS_BLOCK;
+  hipLaunchKernelGGL(k_density_pass1, dim3(nb), dim3(DENS_BLOCK), 0, st, P, A, L, prior, partial0);
+  if (A.nghost > 0) hipLaunchKernelGGL(k_ghost_copy2, dim3(ngb), dim3(DENS_BLOCK), 0, st, A.nghost, n, ghost_src, prior);
+  hipError_t e;
+  switch (P.tabstyle) {
+    case 0: e = launch_pass2<0>(P, A, L, ev, prior, partial0, cv, evpart, errflag, st, nb2); break;
+    case 1: e = launch_pass2<1>(P, A, L, ev, prior, partial0, cv, evpart, errflag, st, nb2); break;
+    default: e = launch_pass2<2>(P, A, L, ev, prior, partial0, cv, evpart, errflag, st, nb2); break;
+  }
+  if (e != hipSuccess) return e;
+  if (A.nghost > 0) hipLaunchKernelGGL(k_ghost_copy2, dim3(ngb), dim3(DENS_BLOCK), 0, st, A.nghost, n, ghost_src, cv);
+  double *evpart3 = evpart + (size_t) nb2 * 8;
+  if (ev) {
+    hipLaunchKernelGGL(k_density_pass3<true>, dim3(nb), dim3(DENS_BLOCK), 0, st, P, A, L, cv, evpart3);
+    hipLaunchKernelGGL(k_ev_final2, dim3(1), dim3(64), 0, st, evpart, nb2, evpart3, nb, evout);
+  } else {
+    hipLaunchKernelGGL(k_density_pass3<false>, dim3(nb), dim3(DENS_BLOCK), 0, st, P, A, L, cv, evpart3);
+  }
+  return hipGetLastError();
+}
+
+int density_evpart_doubles(int nlocal)
+{
+  return 8 * ((nlocal + DENS_BLOCK - 1) / DENS_BLOCK + (nlocal + PAIR_BLOCK - 1) / PAIR_BLOCK) + 16;
+}
+
+}  // namespace ucg

@@ -35,6 +35,10 @@ struct PairDev {
   const double *cutsq;    // [(n_actual+1)^2]  cutsq[itype][jtype] as the reference indexes it
   const double *mu;       // [(n_actual+1)*2]  chemical potential of state s of actual type t
   const double *prior_type;  // [(n_actual+1)*2]
+  // table_ucg_bethe_density, per actual type
+  const int *dens_flags;    // [(n_actual+1)*2] {use_density, use_state_entropy}
+  const double *dens_par;   // [(n_actual+1)*2] {cv_threshold, threshold_radius}
+  int dens_as_shipped;      // 1: back-force uses the proximity function itself (App. B #12)
   double kT;
   double rkT;          // RN(1/kT), used by the FAST kernels' exact division
   int fast;            // 1: one shared r^2 grid, all special_lj == 1, kT usable for div_by_const

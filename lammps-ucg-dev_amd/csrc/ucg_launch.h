@@ -17,6 +17,12 @@ hipError_t launch_pair_gather(const PairDev &P, const AtomsDev &A, const ListDev
 
 hipError_t launch_selftest_div(double b, unsigned long long seed, int n, unsigned long long *d_mismatches, hipStream_t st);
 
+// ---- ucg_density.hip
+hipError_t launch_density(const PairDev &P, const AtomsDev &A, const ListDev &L, const int *ghost_src, bool ev,
+                          double2 *prior, double *partial0, double2 *cv, double *evpart, double *evout, int *errflag,
+                          hipStream_t st);
+int density_evpart_doubles(int nlocal);
+
 // ---- ucg_fix.hip
 struct LangevinDev {
   const double *gfactor1, *gfactor2;  // [ntypes+1]

@@ -39,7 +39,7 @@ struct Domain {
   int nbin[3] = {1, 1, 1}, sten[3] = {0, 0, 0}, nbins = 1;
   double bboxlo[3], bboxhi[3], binsize[3], bininv[3];
   int ago = 0;
-  DevBuf<int> bin_of, cell_o0, cell_o1, cell_g0, cell_g1, ghost_src, ghost_code, counter, rowclass;
+  DevBuf<int> bin_of, cell_o0, cell_o1, cell_g0, cell_g1, ghost_code, counter, rowclass;
   DevBuf<double4> xhold, tmp4;
   DevBuf<unsigned long long> keys_in, keys_out;
   DevBuf<int> vals_in, vals_out, tmpi, cand_src, cand_code;
@@ -400,7 +400,7 @@ void rebuild(ucg_ctx *ctx)
   ctx->tag.reserve(nall, true, st);
   ctx->ucgp.reserve(nall, true, st);
   D.bin_of.reserve(nall, true, st);
-  D.ghost_src.reserve((size_t) ng + 1);
+  ctx->ghost_src.reserve((size_t) ng + 1);
   D.ghost_code.reserve((size_t) ng + 1);
   if (ng > 0) {
     D.keys_in.reserve((size_t) ng);
@@ -414,12 +414,13 @@ void rebuild(ucg_ctx *ctx)
                        D.counter.get(), D.keys_in.get(), D.vals_in.get(), D.cand_src.get(), D.cand_code.get());
     sort_pairs(ctx, D, ng);
     hipLaunchKernelGGL(k_ghost_finalize, dim3(nblk(ng)), dim3(NB), 0, st, ng, n, D.vals_out.get(), D.keys_out.get(),
-                       D.cand_src.get(), D.cand_code.get(), D.ghost_src.get(), D.ghost_code.get(), D.bin_of.get(),
+                       D.cand_src.get(), D.cand_code.get(), ctx->ghost_src.get(), D.ghost_code.get(), D.bin_of.get(),
                        ctx->tag.get(), ctx->meta.get());
-    hipLaunchKernelGGL(k_halo_forward, dim3(nblk(ng)), dim3(NB), 0, st, dd, ng, n, D.ghost_src.get(), D.ghost_code.get(),
+    hipLaunchKernelGGL(k_halo_forward, dim3(nblk(ng)), dim3(NB), 0, st, dd, ng, n, ctx->ghost_src.get(), D.ghost_code.get(),
                        ctx->pos4.get(), ctx->meta.get(), ctx->ucgp.get());
   }
   ctx->nghost = ng;
+  ctx->ghost_src_valid = true;
 
   build_bins_and_rows(ctx);
 }
@@ -488,7 +489,7 @@ void halo_forward(ucg_ctx *ctx)
   if (ctx->nghost <= 0) return;
   const DomainDev dd = make_dev(D);
   hipLaunchKernelGGL(k_halo_forward, dim3(nblk(ctx->nghost)), dim3(NB), 0, ctx->stream, dd, ctx->nghost, ctx->nlocal,
-                     D.ghost_src.get(), D.ghost_code.get(), ctx->pos4.get(), ctx->meta.get(), ctx->ucgp.get());
+                     ctx->ghost_src.get(), D.ghost_code.get(), ctx->pos4.get(), ctx->meta.get(), ctx->ucgp.get());
   UCG_HIP(hipGetLastError());
 }
 
@@ -826,7 +827,7 @@ int ucg_ghosts_download(ucg_ctx *ctx, int *src, int *shift3, int cap)
     }
     std::vector<int> s((size_t) ng), c((size_t) ng);
     if (ng) {
-      UCG_HIP(hipMemcpyAsync(s.data(), ctx->dom->ghost_src.get(), (size_t) ng * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+      UCG_HIP(hipMemcpyAsync(s.data(), ctx->ghost_src.get(), (size_t) ng * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
       UCG_HIP(hipMemcpyAsync(c.data(), ctx->dom->ghost_code.get(), (size_t) ng * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
       UCG_HIP(hipStreamSynchronize(ctx->stream));
     }
@@ -1112,6 +1113,7 @@ int ucg_border_unpack(ucg_ctx *ctx, const void *recvbuf, long long nrecv)
                          (const HaloRec *) recvbuf, ctx->pos4.get(), ctx->meta.get(), ctx->ucgp.get(), ctx->tag.get(), 1);
     }
     ctx->nghost = ng;
+    ctx->ghost_src_valid = false;  // ghosts of a decomposed run belong to other ranks
     UCG_HIP(hipGetLastError());
     build_bins_and_rows(ctx);
     return UCG_OK;

@@ -26,194 +26,11 @@
 //
 // Compiled with -ffp-contract=off: every product and sum below rounds exactly
 // where the reference's scalar x86-64 code rounds.
-#include "ucg_dev.h"
-#include "ucg_math.h"
-#include "ucg_launch.h"
+#include "ucg_pair_dev.h"
 
 namespace ucg {
 
 namespace {
-
-constexpr int PAIR_BLOCK = 1024;
-
-struct Quad {
-  double u00, u01, u10, u11;
-  double f00, f01, f10, f11;
-};
-
-// correctly rounded a / b from y = RN(1/b): q0 = RN(a*y), then two FMA residual steps.
-// Exact for normal-range operands when b's significand is not all ones (checked on the host).
-__device__ __forceinline__ double div_by_const(const double a, const double b, const double y)
-{
-  if (!(fabs(a) > 1.0e-280 && fabs(a) < 1.0e280)) return a / b;
-  double q = a * y;
-  double r = fma(-b, q, a);
-  q = fma(r, y, q);
-  r = fma(-b, q, a);
-  return fma(r, y, q);
-}
-
-// knot index of rsq on one table's r^2 grid (the shared part of UCG/pair_table_ucgld.cpp:436-459)
-__device__ __forceinline__ int grid_locate(const double4 par, const int tlm1, const double rsq, int &err)
-{
-  if (rsq < par.x) err |= 1;
-  int it = static_cast<int>((rsq - par.x) * par.z);
-  if (it >= tlm1) {
-    err |= 2;
-    it = tlm1 - 1;
-  }
-  if (it < 0) it = 0;
-  return it;
-}
-
-struct Basis {
-  double a, b, a3, b3;  // SPLINE: a, b, a^3-a, b^3-b ; LINEAR: b = fraction
-};
-
-template <int TS>
-__device__ __forceinline__ Basis grid_basis(const double4 par, const int it, const double rsq)
-{
-  Basis B;
-  B.a = B.b = B.a3 = B.b3 = 0.0;
-  if (TS != 0) {
-    const double rsq_it = par.x + it * par.y;  // == tb->rsq[it] bit for bit (:1159,:1196)
-    B.b = (rsq - rsq_it) * par.z;
-    if (TS == 2) {
-      B.a = 1.0 - B.b;
-      B.a3 = B.a * B.a * B.a - B.a;
-      B.b3 = B.b * B.b * B.b - B.b;
-    }
-  }
-  return B;
-}
-
-// (f/r, e) of one table at a located knot; UCG/pair_table_ucgld.cpp:440-481
-template <int TS, typename TabPtr>
-__device__ __forceinline__ void knot_eval(TabPtr tab, const double deltasq6, const int it, const Basis &B,
-                                          double &fval, double &eval)
-{
-  if (TS == 0) {  // LOOKUP {e, f, -, -}
-    const double4 k = tab[it];
-    eval = k.x;
-    fval = k.y;
-  } else if (TS == 1) {  // LINEAR {e, de, f, df}
-    const double4 k = tab[it];
-    fval = k.z + B.b * k.w;
-    eval = k.x + B.b * k.y;
-  } else {  // SPLINE {e, f, e2, f2}
-    const double4 k0 = tab[it];
-    const double4 k1 = tab[it + 1];
-    fval = B.a * k0.y + B.b * k1.y + (B.a3 * k0.w + B.b3 * k1.w) * deltasq6;
-    eval = B.a * k0.x + B.b * k1.x + (B.a3 * k0.z + B.b3 * k1.z) * deltasq6;
-  }
-}
-
-// FAST layout: knot-major, the tables of one knot side by side, each {e,f | e2,f2} (or the
-// LINEAR / LOOKUP quartet) as two 16-byte slots, plus ONE padding slot per knot so that the
-// knot stride (2*ntab+1 slots) is odd: a random knot index then lands on any of the 16
-// ds_read_b128 bank slots, instead of only 8 of them with a 32-byte stride.
-template <int TS>
-__device__ __forceinline__ void knot_eval_fast(const double2 *rec, const int stride, const double deltasq6,
-                                               const Basis &B, double &fval, double &eval)
-{
-  if (TS == 0) {
-    const double2 k = rec[0];
-    eval = k.x;
-    fval = k.y;
-  } else if (TS == 1) {
-    const double2 ka = rec[0], kb = rec[1];  // {e, de}, {f, df}
-    fval = kb.x + B.b * kb.y;
-    eval = ka.x + B.b * ka.y;
-  } else {
-    const double2 k0a = rec[0], k0b = rec[1];            // {e, f}, {e2, f2} at knot it
-    const double2 k1a = rec[stride], k1b = rec[stride + 1];  // ... at knot it+1
-    fval = B.a * k0a.y + B.b * k1a.y + (B.a3 * k0b.y + B.b3 * k1b.y) * deltasq6;
-    eval = B.a * k0a.x + B.b * k1a.x + (B.a3 * k0b.x + B.b3 * k1b.x) * deltasq6;
-  }
-}
-
-// own-frame quad: u[a][b] = table(F(tk,a), F(tm,b)); equals the reference's u[b][a] when the
-// row owner is the pair's "j" (tabindex is symmetric after init_one)
-template <int TS, bool FAST, typename TabPtr>
-__device__ __forceinline__ void eval_quad(TabPtr tab, const double4 *s_par, const int *pt, const int tablength,
-                                          const int tlm1, const int fast_stride, const double rsq,
-                                          const double factor_lj, Quad &q, int &err)
-{
-  const int t00 = pt[0], t01 = pt[1], t10 = pt[2], t11 = pt[3];
-  if (FAST) {
-    const double4 par = s_par[0];
-    const int it = grid_locate(par, tlm1, rsq, err);
-    const Basis B = grid_basis<TS>(par, it, rsq);
-    const double2 *rec = reinterpret_cast<const double2 *>(tab) + it * fast_stride;
-    knot_eval_fast<TS>(rec + 2 * t00, fast_stride, par.w, B, q.f00, q.u00);
-    knot_eval_fast<TS>(rec + 2 * t01, fast_stride, par.w, B, q.f01, q.u01);
-    if (t10 == t01) {
-      q.f10 = q.f01;
-      q.u10 = q.u01;
-    } else {
-      knot_eval_fast<TS>(rec + 2 * t10, fast_stride, par.w, B, q.f10, q.u10);
-    }
-    knot_eval_fast<TS>(rec + 2 * t11, fast_stride, par.w, B, q.f11, q.u11);
-  } else {
-    {
-      const double4 par = s_par[t00];
-      const int it = grid_locate(par, tlm1, rsq, err);
-      knot_eval<TS>(tab + t00 * tablength, par.w, it, grid_basis<TS>(par, it, rsq), q.f00, q.u00);
-    }
-    {
-      const double4 par = s_par[t01];
-      const int it = grid_locate(par, tlm1, rsq, err);
-      knot_eval<TS>(tab + t01 * tablength, par.w, it, grid_basis<TS>(par, it, rsq), q.f01, q.u01);
-    }
-    if (t10 == t01) {
-      q.f10 = q.f01;
-      q.u10 = q.u01;
-    } else {
-      const double4 par = s_par[t10];
-      const int it = grid_locate(par, tlm1, rsq, err);
-      knot_eval<TS>(tab + t10 * tablength, par.w, it, grid_basis<TS>(par, it, rsq), q.f10, q.u10);
-    }
-    {
-      const double4 par = s_par[t11];
-      const int it = grid_locate(par, tlm1, rsq, err);
-      knot_eval<TS>(tab + t11 * tablength, par.w, it, grid_basis<TS>(par, it, rsq), q.f11, q.u11);
-    }
-    q.f00 = factor_lj * q.f00; q.u00 *= factor_lj;
-    q.f01 = factor_lj * q.f01; q.u01 *= factor_lj;
-    q.f10 = factor_lj * q.f10; q.u10 *= factor_lj;
-    q.f11 = factor_lj * q.f11; q.u11 *= factor_lj;
-  }
-}
-
-// deterministic block sum of NV doubles per lane -> out[blockIdx.x*NV + c]
-template <int NV>
-__device__ __forceinline__ void block_sum_store(double (&v)[NV], double *red, double *out)
-{
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-#pragma unroll
-  for (int c = 0; c < NV; c++) {
-    double s = v[c];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if (lane == 0) red[wave * NV + c] = s;
-  }
-  __syncthreads();
-  if (threadIdx.x < NV) {
-    double s = 0.0;
-    for (int w = 0; w < nw; w++) s += red[w * NV + threadIdx.x];
-    out[(size_t) blockIdx.x * NV + threadIdx.x] = s;
-  }
-}
-
-// XCD-aware chunk order: blocks b and b+8 share an XCD (observed round-robin), so give
-// each XCD one contiguous range of bead chunks; beads are bin-sorted, so a range is a
-// spatial slab whose neighbour gathers stay in that XCD's L2.  Speed only, never correctness.
-__device__ __forceinline__ int xcd_chunk(int b, int nb)
-{
-  const int per = nb >> 3;
-  if (per == 0 || b >= per * 8) return b;
-  return (b & 7) * per + (b >> 3);
-}
 
 template <int STYLE, int TS, bool EV, bool LDS_TAB, bool FAST>
 __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, const AtomsDev A,

@@ -162,6 +162,11 @@ int orc_pair_compute_half(orc_pair *p, orc_atoms *a, const orc_list *l, int newt
 int orc_pair_compute_gather(orc_pair *p, orc_atoms *a, const orc_list *l, int eflag, int vflag,
                             orc_ev *ev);
 
+/* table_ucg_bethe_density (orc_density.c): mode 0 = sequential sweep with scatter (the
+ * reference's loop shape), 1 = canonical gather; ghost_src[g] = owned index ghost g images */
+int orc_pair_density_compute(orc_pair *p, orc_atoms *a, const orc_list *l, int mode, int eflag,
+                             int vflag, const int *ghost_src, orc_ev *ev);
+
 /* --------------------------------------------------------------- fixes */
 
 /* AtomVecUCG::force_clear + Verlet::force_clear (UCG/atom_vec_ucg.cpp:131-135) */

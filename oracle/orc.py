@@ -100,8 +100,8 @@ def lib():
     L.orc_pair_dbl_array.argtypes = [C.c_void_p, C.c_char_p, c_int_p]
     L.orc_pair_dbl_array.restype = c_double_p
     L.orc_pair_set_compat.argtypes = [C.c_void_p, C.c_int]
-    L.orc_pair_density_compute.argtypes = [C.c_void_p, C.POINTER(Atoms), C.POINTER(NList), C.c_int,
-                                           C.c_int, C.POINTER(Ev)]
+    L.orc_pair_density_compute.argtypes = [C.c_void_p, C.POINTER(Atoms), C.POINTER(NList), C.c_int, C.c_int,
+                                           C.c_int, c_int_p, C.POINTER(Ev)]
     L.orc_force_clear.argtypes = [C.POINTER(Atoms), C.c_int]
     L.orc_fix_nve_initial.argtypes = [C.POINTER(Atoms), C.c_double, C.c_double, C.c_int]
     L.orc_fix_nve_final.argtypes = [C.POINTER(Atoms), C.c_double, C.c_double, C.c_int]

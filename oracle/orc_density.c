@@ -6,8 +6,6 @@
 #include <stdlib.h>
 #include <string.h>
 
-int orc_pair_density_compute(orc_pair *p, orc_atoms *a, const orc_list *l, int eflag, int vflag,
-                             orc_ev *ev);
 
 /* ---- accessors used by the tests to compare the product's tables bit for bit ---- */
 
@@ -98,11 +96,311 @@ orc_fix_ucgstate *orc_fix_ucgstate_create(int ld_flag, int mc_flag, int mc_seed,
 
 void orc_fix_ucgstate_destroy(orc_fix_ucgstate *fx) { free(fx); }
 
-int orc_pair_density_compute(orc_pair *p, orc_atoms *a, const orc_list *l, int eflag, int vflag,
-                             orc_ev *ev)
+/* ------------------------------------------------------------------------------------------
+ * table_ucg_bethe_density: PairTable_UCG_Bethe_Density::compute,
+ * UCG/pair_table_ucg_bethe_density.cpp:133-758 (helpers :107-127), Scenario 4 (:529-658).
+ * FULL list, newton off.  Three passes:
+ *   1 (:219-274)  local density rho_i = sum_j w(r_ij) -> prior p_i0 = 1/2 + 1/2 tanh((rho-rho_th)/(0.1 rho_th))
+ *   2 (:284-664)  tables, scores, Bethe closure, pair forces (x 1/2 when j is owned), entropic accumulators G
+ *   3 (:669-734)  posterior -> ucgp, back-force of the density CV over the neighbours
+ * Decisions where the shipped text is inconsistent or undefined, all flagged:
+ *   #7  ghost priors: the reference's forward_comm moves 0 bytes (ghost priors = 0 -> NaN); here ghosts
+ *       carry their owner's prior and CV force (what the legacy style does, rleucg_interface.cpp:131-160)
+ *   #8  ucgp uses n_states_per_type[itype] (the shipped [i] indexes by atom)
+ *   #9  closure kept as shipped: a = b - 1, D = sqrt(Q^2 - 4ab pi pj), p11 = (Q - D)/2/a, unguarded
+ *   #11 neighbour indices are masked in all passes
+ *   #12 back-force uses the DERIVATIVE of the proximity function (legacy :480); compat flag
+ *       density_proximity_as_shipped = 1 uses the function itself as shipped (:719)
+ *   back-force on / from ghost neighbours: as shipped a ghost j receives nothing and nothing comes
+ *       back from it (momentum is lost across boundaries); here every neighbour m, owned or ghost,
+ *       pushes back on k with its own CV force (legacy reverse_comm design, :104-129,:494)
+ * mode 0 = sequential sweep with scatter (the reference's loop shape), mode 1 = canonical gather.
+ */
+#include <stdio.h>
+
+static double prox(const orc_pair *p, int type, double r)
 {
-  (void) a; (void) l; (void) eflag; (void) vflag;
+  double t = orc_tanh((r - p->threshold_radii[type]) / (0.1 * p->threshold_radii[type]));
+  return 0.5 * (1.0 - t);
+}
+
+static double prox_der(const orc_pair *p, int type, double r)
+{
+  double t = orc_tanh((r - p->threshold_radii[type]) / (0.1 * p->threshold_radii[type]));
+  return 0.5 * (1.0 - t * t) / (0.1 * p->threshold_radii[type]);
+}
+
+typedef struct { double u[2][2], fp[2][2]; } dquad;
+
+static int deval4(const orc_pair *p, int itype, int jtype, double rsq, double factor_lj, dquad *q)
+{
+  const int nt = p->n_formal + 1, ms = p->max_states;
+  for (int si = 0; si < 2; si++) {
+    int fi = p->formal_from_actual[itype * ms + si];
+    for (int sj = 0; sj < 2; sj++) {
+      int fj = p->formal_from_actual[jtype * ms + sj];
+      const orc_table *tb = &p->tables[p->tabindex[fi * nt + fj]];
+      double value, evdwl;
+      int rc = orc_table_eval(tb, p->tabstyle, p->tablength, rsq, &value, &evdwl);
+      if (rc) return rc;
+      q->fp[si][sj] = factor_lj * value;
+      evdwl *= factor_lj;
+      q->u[si][sj] = evdwl;
+    }
+  }
+  return 0;
+}
+
+/* closure as shipped (:608-622) for the pair seen with "i" holding prior pi1 */
+static void dclosure(const orc_pair *p, const dquad *q, double pi1, double pj1, double *p00, double *p01,
+                     double *p10, double *p11)
+{
+  const double kT = p->kT;
+  double Jij = q->u[1][1] + q->u[0][0] - q->u[0][1] - q->u[1][0];
+  double bij = orc_exp(-Jij / kT);
+  double aij = bij - 1.;
+  double Qij = (pi1 + pj1) * aij + 1.;
+  double Dij = sqrt(Qij * Qij - 4. * aij * bij * pi1 * pj1);
+  *p11 = (Qij - Dij) / 2. / aij;
+  *p00 = 1. + *p11 - pi1 - pj1;
+  *p10 = pi1 - *p11;
+  *p01 = pj1 - *p11;
+}
+
+int orc_pair_density_compute(orc_pair *p, orc_atoms *a, const orc_list *l, int mode, int eflag, int vflag,
+                             const int *ghost_src, orc_ev *ev)
+{
+  const int nt = p->n_formal + 1, ms = p->max_states;
+  const int nlocal = a->nlocal, nall = a->nlocal + a->nghost;
+  const double kT = p->kT;
+  const double *x = a->x;
+  double *f = a->f;
   memset(ev, 0, sizeof(*ev));
-  strcpy(p->errmsg, "table_ucg_bethe_density oracle not built yet");
-  return 1;
+  if (p->style != ORC_STYLE_BETHE_DENSITY) {
+    strcpy(p->errmsg, "orc_pair_density_compute needs style table_ucg_bethe_density");
+    return 1;
+  }
+  for (int i = 0; i < nall; i++) {
+    int t = a->type[i];
+    if (t < 1 || t > p->n_actual || p->n_states_per_type[t] != 2) {
+      strcpy(p->errmsg, "only 2-state types are live (Scenario 4)");
+      return 1;
+    }
+  }
+  double *prior = (double *) calloc((size_t) nall * 2, sizeof(double));
+  double *partial = (double *) calloc((size_t) nall * 2, sizeof(double));
+  double *G = (double *) calloc((size_t) nall * 2, sizeof(double));
+  double *S = (double *) calloc((size_t) nall * 2, sizeof(double));
+  double *cv = (double *) calloc((size_t) nall * 2, sizeof(double));
+
+  /* ---- pass 1 */
+  for (int ii = 0; ii < l->inum; ii++) {
+    const int i = l->ilist[ii];
+    const int itype = a->type[i];
+    if (p->use_density[itype] == 1) {
+      double rho = 0.0;
+      const int *row = l->neigh + l->first[ii];
+      for (int jj = 0; jj < l->numneigh[ii]; jj++) {
+        const int j = row[jj] & ORC_NEIGHMASK;
+        const int jtype = a->type[j];
+        const double delx = x[3 * i] - x[3 * j], dely = x[3 * i + 1] - x[3 * j + 1], delz = x[3 * i + 2] - x[3 * j + 2];
+        const double rsq = delx * delx + dely * dely + delz * delz;
+        if (rsq < p->cutsq[itype * nt + jtype]) rho += prox(p, itype, sqrt(rsq));
+      }
+      /* threshold_prob_and_partial_from_cv :107-113 */
+      double th = orc_tanh((rho - p->cv_thresholds[itype]) / (0.1 * p->cv_thresholds[itype]));
+      prior[2 * i] = 0.5 + 0.5 * th;
+      partial[2 * i] = 0.5 * (1.0 - th * th) / (0.1 * p->cv_thresholds[itype]);
+      prior[2 * i + 1] = 1.0 - prior[2 * i];
+      partial[2 * i + 1] = -partial[2 * i];
+    } else {
+      double den = 0.0;
+      for (int si = 0; si < 2; si++) {
+        prior[2 * i + si] = orc_exp(-p->chem_pot[p->formal_from_actual[itype * ms + si]] / kT);
+        den += prior[2 * i + si];
+      }
+      for (int si = 0; si < 2; si++) prior[2 * i + si] /= den;
+    }
+  }
+  /* forward communication of the priors (fix of App. B #7) */
+  for (int g = 0; g < a->nghost; g++) {
+    const int src = ghost_src[g];
+    prior[2 * (nlocal + g)] = prior[2 * src];
+    prior[2 * (nlocal + g) + 1] = prior[2 * src + 1];
+    partial[2 * (nlocal + g)] = partial[2 * src];
+    partial[2 * (nlocal + g) + 1] = partial[2 * src + 1];
+  }
+
+  /* ---- pass 2 */
+  double *fpart = (double *) calloc((size_t) nall * 3, sizeof(double)); /* mode 0 scatter target incl. ghosts */
+  for (int ii = 0; ii < l->inum; ii++) {
+    const int i = l->ilist[ii];
+    const int itype = a->type[i];
+    const int *row = l->neigh + l->first[ii];
+    const int jnum = l->numneigh[ii];
+    const double jnum_f = 1. - jnum;
+    a->num_ucgstates[i] = p->n_states_per_type[itype];
+    if (p->use_density[itype]) {
+      for (int si = 0; si < 2; si++) {
+        if (p->use_state_entropy[itype]) G[2 * i + si] -= kT * orc_log(prior[2 * i + si]) * jnum_f;
+        G[2 * i + si] -= p->chem_pot[p->formal_from_actual[itype * ms + si]];
+        S[2 * i + si] -= p->chem_pot[p->formal_from_actual[itype * ms + si]] / kT;
+      }
+    }
+    double fx = 0.0, fy = 0.0, fz = 0.0;
+    for (int jj = 0; jj < jnum; jj++) {
+      int j = row[jj];
+      const double factor_lj = p->special_lj[(j >> ORC_SBBITS) & 3];
+      j &= ORC_NEIGHMASK;
+      const int jtype = a->type[j];
+      const int jstate = a->ucgstate[j];
+      const double delx = x[3 * i] - x[3 * j], dely = x[3 * i + 1] - x[3 * j + 1], delz = x[3 * i + 2] - x[3 * j + 2];
+      const double rsq = delx * delx + dely * dely + delz * delz;
+      if (!(rsq < p->cutsq[itype * nt + jtype])) continue;
+      dquad q;
+      int rc = deval4(p, itype, jtype, rsq, factor_lj, &q);
+      if (rc) {
+        if (!ev->err) { ev->err = rc; ev->err_i = i; ev->err_j = j; }
+        continue;
+      }
+      for (int si = 0; si < 2; si++) S[2 * i + si] -= q.u[si][jstate] / kT;
+      double p00, p01, p10, p11;
+      dclosure(p, &q, prior[2 * i + 1], prior[2 * j + 1], &p00, &p01, &p10, &p11);
+      double evdwl = p00 * q.u[0][0] + p01 * q.u[0][1] + p10 * q.u[1][0] + p11 * q.u[1][1];
+      double fpair = p00 * q.fp[0][0] + p01 * q.fp[0][1] + p10 * q.fp[1][0] + p11 * q.fp[1][1];
+      if (j < nlocal) {
+        evdwl = evdwl * 0.5;
+        fpair = fpair * 0.5;
+      }
+      if (mode == 0) {
+        fpart[3 * i] += delx * fpair; fpart[3 * i + 1] += dely * fpair; fpart[3 * i + 2] += delz * fpair;
+        if (j < nlocal) { fpart[3 * j] -= delx * fpair; fpart[3 * j + 1] -= dely * fpair; fpart[3 * j + 2] -= delz * fpair; }
+      } else {
+        fx += delx * fpair; fy += dely * fpair; fz += delz * fpair;
+        if (j < nlocal) {
+          /* what j's own visit of this pair sends to i: the closure with the roles swapped */
+          dquad qt;
+          for (int sa = 0; sa < 2; sa++)
+            for (int sb = 0; sb < 2; sb++) { qt.u[sa][sb] = q.u[sb][sa]; qt.fp[sa][sb] = q.fp[sb][sa]; }
+          double t00, t01, t10, t11;
+          dclosure(p, &qt, prior[2 * j + 1], prior[2 * i + 1], &t00, &t01, &t10, &t11);
+          double fpj = t00 * qt.fp[0][0] + t01 * qt.fp[0][1] + t10 * qt.fp[1][0] + t11 * qt.fp[1][1];
+          fpj = fpj * 0.5;
+          const double djx = x[3 * j] - x[3 * i], djy = x[3 * j + 1] - x[3 * i + 1], djz = x[3 * j + 2] - x[3 * i + 2];
+          fx -= djx * fpj; fy -= djy * fpj; fz -= djz * fpj;
+        }
+      }
+      /* ev_tally with newton off: half per owned end */
+      if (eflag) ev->eng_vdwl += (j < nlocal) ? evdwl : 0.5 * evdwl;
+      if (vflag) {
+        const double sc = (j < nlocal) ? 1.0 : 0.5;
+        ev->virial[0] += sc * (delx * delx * fpair); ev->virial[1] += sc * (dely * dely * fpair);
+        ev->virial[2] += sc * (delz * delz * fpair); ev->virial[3] += sc * (delx * dely * fpair);
+        ev->virial[4] += sc * (delx * delz * fpair); ev->virial[5] += sc * (dely * delz * fpair);
+      }
+      if (p->use_density[itype] == 1) {
+        G[2 * i] -= (q.u[1][0] - q.u[0][0] + kT * orc_log(p10 / p00));
+        G[2 * i + 1] -= (q.u[1][1] - q.u[0][1] + kT * orc_log(p11 / p01));
+      }
+    }
+    if (mode == 1) { f[3 * i] = fx; f[3 * i + 1] = fy; f[3 * i + 2] = fz; }
+  }
+  if (mode == 0)
+    for (int i = 0; i < nlocal; i++) { f[3 * i] = fpart[3 * i]; f[3 * i + 1] = fpart[3 * i + 1]; f[3 * i + 2] = fpart[3 * i + 2]; }
+
+  /* posterior (:678-696) and CV forces of the owned beads */
+  for (int ii = 0; ii < l->inum; ii++) {
+    const int i = l->ilist[ii];
+    const int itype = a->type[i];
+    double e0 = orc_exp(S[2 * i]), e1 = orc_exp(S[2 * i + 1]);
+    double den = 0.0;
+    den += e0;
+    den += e1;
+    a->ucgp[i] = e1 / den;
+    a->scores[2 * i] = S[2 * i];
+    a->scores[2 * i + 1] = S[2 * i + 1];
+    if (p->use_density[itype] == 1) {
+      cv[2 * i] = G[2 * i] * partial[2 * i];
+      cv[2 * i + 1] = G[2 * i + 1] * partial[2 * i + 1];
+    }
+  }
+  for (int g = 0; g < a->nghost; g++) {
+    cv[2 * (nlocal + g)] = cv[2 * ghost_src[g]];
+    cv[2 * (nlocal + g) + 1] = cv[2 * ghost_src[g] + 1];
+  }
+
+  /* ---- pass 3: back-force of the density CV (:698-733) */
+  memset(fpart, 0, sizeof(double) * 3 * (size_t) nall);
+  for (int ii = 0; ii < l->inum; ii++) {
+    const int i = l->ilist[ii];
+    const int itype = a->type[i];
+    const int *row = l->neigh + l->first[ii];
+    const int jnum = l->numneigh[ii];
+    if (mode == 0) {
+      /* the reference's loop shape: state outer, neighbours inner, scatter to j */
+      if (p->use_density[itype] == 1) {
+        for (int si = 0; si < 2; si++) {
+          const double cv_force = cv[2 * i + si];
+          for (int jj = 0; jj < jnum; jj++) {
+            const int j = row[jj] & ORC_NEIGHMASK;
+            const int jtype = a->type[j];
+            const double delx = x[3 * i] - x[3 * j], dely = x[3 * i + 1] - x[3 * j + 1], delz = x[3 * i + 2] - x[3 * j + 2];
+            const double rsq = delx * delx + dely * dely + delz * delz;
+            if (rsq < p->cutsq[itype * nt + jtype]) {
+              const double distance = sqrt(rsq);
+              const double w = p->density_proximity_as_shipped ? prox(p, itype, distance) : prox_der(p, itype, distance);
+              const double fpair = cv_force * w / distance;
+              f[3 * i] += fpair * delx; f[3 * i + 1] += fpair * dely; f[3 * i + 2] += fpair * delz;
+              fpart[3 * j] -= fpair * delx; fpart[3 * j + 1] -= fpair * dely; fpart[3 * j + 2] -= fpair * delz;
+              if (vflag) {
+                ev->virial[0] += delx * delx * fpair; ev->virial[1] += dely * dely * fpair; ev->virial[2] += delz * delz * fpair;
+                ev->virial[3] += delx * dely * fpair; ev->virial[4] += delx * delz * fpair; ev->virial[5] += dely * delz * fpair;
+              }
+            }
+          }
+        }
+      }
+    } else {
+      /* canonical: one sweep of the row; per neighbour first i's own CV force (state 0, 1), then
+         what the neighbour's CV force (state 0, 1) sends back to i -- owned or ghost neighbour alike */
+      double fx = f[3 * i], fy = f[3 * i + 1], fz = f[3 * i + 2];
+      for (int jj = 0; jj < jnum; jj++) {
+        const int j = row[jj] & ORC_NEIGHMASK;
+        const int jtype = a->type[j];
+        const double delx = x[3 * i] - x[3 * j], dely = x[3 * i + 1] - x[3 * j + 1], delz = x[3 * i + 2] - x[3 * j + 2];
+        const double rsq = delx * delx + dely * dely + delz * delz;
+        const double distance = sqrt(rsq);
+        if (p->use_density[itype] == 1 && rsq < p->cutsq[itype * nt + jtype]) {
+          const double w = p->density_proximity_as_shipped ? prox(p, itype, distance) : prox_der(p, itype, distance);
+          for (int si = 0; si < 2; si++) {
+            const double fpair = cv[2 * i + si] * w / distance;
+            fx += fpair * delx; fy += fpair * dely; fz += fpair * delz;
+            if (vflag) {
+              ev->virial[0] += delx * delx * fpair; ev->virial[1] += dely * dely * fpair; ev->virial[2] += delz * delz * fpair;
+              ev->virial[3] += delx * dely * fpair; ev->virial[4] += delx * delz * fpair; ev->virial[5] += dely * delz * fpair;
+            }
+          }
+        }
+        if (p->use_density[jtype] == 1 && rsq < p->cutsq[jtype * nt + itype]) {
+          const double djx = x[3 * j] - x[3 * i], djy = x[3 * j + 1] - x[3 * i + 1], djz = x[3 * j + 2] - x[3 * i + 2];
+          const double w = p->density_proximity_as_shipped ? prox(p, jtype, distance) : prox_der(p, jtype, distance);
+          for (int sj = 0; sj < 2; sj++) {
+            const double fpair = cv[2 * j + sj] * w / distance;
+            fx -= fpair * djx; fy -= fpair * djy; fz -= fpair * djz;
+          }
+        }
+      }
+      f[3 * i] = fx; f[3 * i + 1] = fy; f[3 * i + 2] = fz;
+    }
+  }
+  if (mode == 0) {
+    /* scatter targets: owned j directly, ghost j through the reverse sum into its owner */
+    for (int i = 0; i < nlocal; i++) { f[3 * i] += fpart[3 * i]; f[3 * i + 1] += fpart[3 * i + 1]; f[3 * i + 2] += fpart[3 * i + 2]; }
+    for (int g = 0; g < a->nghost; g++) {
+      const int src = ghost_src[g];
+      for (int d = 0; d < 3; d++) f[3 * src + d] += fpart[3 * (nlocal + g) + d];
+    }
+  }
+  free(prior); free(partial); free(G); free(S); free(cv); free(fpart);
+  return ev->err ? 2 : 0;
 }

@@ -474,7 +474,10 @@ static int decide(orc_sim *s)
 static int compute_forces(orc_sim *s, int eflag, int vflag)
 {
   int rc;
-  if (s->mode == 0) {
+  if (s->pair->style == ORC_STYLE_BETHE_DENSITY) {
+    orc_force_clear(&s->a, 0);
+    rc = orc_pair_density_compute(s->pair, &s->a, &s->full, s->mode, eflag, vflag, s->ghost_src, &s->ev);
+  } else if (s->mode == 0) {
     orc_force_clear(&s->a, 1);
     rc = orc_pair_compute_half(s->pair, &s->a, &s->half, 1, eflag, vflag, &s->ev);
     orc_sim_reverse_comm(s);

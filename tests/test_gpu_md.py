@@ -58,12 +58,15 @@ CASES = [
     ("table_ucg_bethe", (), None, "plain", 0.004, 80, 1),
     ("table_ucg_bethe", ("pseudo", "no"), None, ("mc", 9127, 0.2), 0.004, 80, 2),
     ("table_ucgld", (), None, None, 0.004, 60, 1),
+    ("table_ucg_bethe_density", (), None, ("mc", 4242, 0.3), 0.002, 60, 1),
+    ("table_ucg_bethe_density", (), None, None, 0.002, 40, 2),
 ]
 
 
 @pytest.mark.parametrize("style,extra,langevin,ucgstate,dt,steps,every", CASES)
 def test_md_trajectory_bitwise(fresh_ctx, pkg, orc, style, extra, langevin, ucgstate, dt, steps, every):
-    deck = util.make_deck("spline", 1024, extra_keywords=extra)
+    dens = dict(density=(11.3, 1.5), extra11=0.05) if style.endswith("density") else {}
+    deck = util.make_deck("spline", 1024, extra_keywords=extra, **dens)
     beads = pkg.synth.make_beads(8, seed=31)
     op = util.oracle_pair(style, deck)
     sim = util.oracle_sim(beads, op, mode=1, dt=dt, langevin=langevin, nve=True, ucgstate=ucgstate, every=every)

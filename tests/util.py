@@ -45,6 +45,8 @@ def upload_from_oracle(ctx, sim, beads):
                      A["ucgl"], A["ucgvl"], A["ucgml"], A["ucgp"], beads.mass)
     il, nn, fi, ne = sim.full_list()
     ctx.neigh_upload_full(nn, fi, ne)
+    if ng:
+        ctx.ghosts_upload(sim.ghost_map()[0])
     return A
 
 
