@@ -179,6 +179,13 @@ def main():
             "launches": int(result["pair_launches"]),
         },
     }
+    # HBM traffic of the pair kernel: measured in separate rocprofv3 --pmc passes of this same
+    # command (tools/profile_pmc.sh) and committed under profiles/; valid for the default workload
+    tfile = os.path.join(ROOT, "profiles", "r01_pair_traffic.json")
+    if world == 1 and args.ncell == 100 and args.tabstyle == "spline" and args.tablength == 1024 and os.path.exists(tfile):
+        with open(tfile) as fh:
+            out["roofline"]["traffic"] = json.load(fh)["traffic_bytes_per_launch"]
+        out["roofline"]["traffic_note"] = "HBM bytes per launch from rocprofv3 PMC (FETCH_SIZE x2 per the gfx950 calibration + WRITE_SIZE), profiles/r01_pair_traffic.json"
     if not args.no_cpu_baseline:
         cb = cpu_baseline(pkg, deck, args.cpu_ncell, args.cpu_steps, dt)
         out["cpu_baseline"] = {

@@ -73,6 +73,10 @@ int ucg_ctx_set_units(ucg_ctx *ctx, double boltz, double ftm2v, double mvv2e, do
  * "density_proximity_as_shipped" = 1 makes table_ucg_bethe_density use the proximity function
  * itself in the CV back-force, as shipped (:719), instead of its derivative. */
 int ucg_ctx_set_option(ucg_ctx *ctx, const char *name, int value);
+/* PMC calibration aid: stream a fresh buffer of nbytes with 4-byte (wide=0) or 16-byte (wide=1)
+ * loads per lane, `repeats` launches of k_stream; lets FETCH_SIZE be calibrated on a known
+ * byte count in this library's own access widths (MI355X_MICROARCH.md, HBM section). */
+int ucg_selftest_stream(ucg_ctx *ctx, long long nbytes, int wide, int repeats);
 /* device self-test: n random operands, counts a / b != div_by_const(a, b) (must be 0) */
 int ucg_selftest_div(ucg_ctx *ctx, double b, long long seed, int n, long long *mismatches);
 

@@ -31,7 +31,7 @@ NEIGHMASK = 0x1FFFFFFF
 # every symbol include/ucg_hip.h declares (checked by the CPU test-suite against the .so)
 SYMBOLS = [
     "ucg_abi_version", "ucg_ctx_create", "ucg_ctx_destroy", "ucg_last_error", "ucg_ctx_set_stream",
-    "ucg_ctx_synchronize", "ucg_ctx_set_units", "ucg_ctx_set_option", "ucg_selftest_div",
+    "ucg_ctx_synchronize", "ucg_ctx_set_units", "ucg_ctx_set_option", "ucg_selftest_div", "ucg_selftest_stream",
     "ucg_pair_create", "ucg_pair_create_host", "ucg_pair_last_error", "ucg_pair_destroy", "ucg_pair_settings", "ucg_pair_coeff", "ucg_pair_init",
     "ucg_pair_cut", "ucg_pair_cutforce", "ucg_pair_single", "ucg_pair_table_count",
     "ucg_pair_table_params", "ucg_pair_table_array", "ucg_pair_tabindex", "ucg_pair_compute",
@@ -79,6 +79,7 @@ def lib():
     L.ucg_ctx_set_units.argtypes = [vp, C.c_double, C.c_double, C.c_double, C.c_double, c_double_p]
     L.ucg_ctx_set_option.argtypes = [vp, C.c_char_p, C.c_int]
     L.ucg_selftest_div.argtypes = [vp, C.c_double, C.c_longlong, C.c_int, c_ll_p]
+    L.ucg_selftest_stream.argtypes = [vp, C.c_longlong, C.c_int, C.c_int]
     L.ucg_pair_create.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.ucg_pair_create_host.argtypes = [C.c_int, C.c_double, C.POINTER(vp)]
     L.ucg_pair_last_error.argtypes = [vp]
@@ -205,6 +206,9 @@ class Context:
         m = C.c_longlong(0)
         self.chk(self.L.ucg_selftest_div(self.h, float(b), int(seed), int(n), C.byref(m)))
         return m.value
+
+    def selftest_stream(self, nbytes, wide, repeats=1):
+        self.chk(self.L.ucg_selftest_stream(self.h, int(nbytes), int(wide), int(repeats)))
 
     def set_stream(self, stream_ptr):
         self.chk(self.L.ucg_ctx_set_stream(self.h, C.c_void_p(stream_ptr or 0)))

@@ -988,6 +988,21 @@ int ucg_selftest_div(ucg_ctx *ctx, double b, long long seed, int n, long long *m
   });
 }
 
+int ucg_selftest_stream(ucg_ctx *ctx, long long nbytes, int wide, int repeats)
+{
+  if (!ctx || nbytes < 16 || repeats < 1) return UCG_ERR_INVALID;
+  return guarded(ctx, [&]() -> int {
+    DevBuf<char> buf;
+    DevBuf<int> sink;
+    buf.reserve((size_t) nbytes);
+    sink.reserve(4);
+    UCG_HIP(hipMemsetAsync(buf.get(), 1, (size_t) nbytes, ctx->stream));
+    for (int r = 0; r < repeats; r++) UCG_HIP(launch_stream(buf.get(), (size_t) nbytes, wide, sink.get(), ctx->stream));
+    sync(ctx);
+    return UCG_OK;
+  });
+}
+
 int ucg_ctx_set_option(ucg_ctx *ctx, const char *name, int value)
 {
   if (!ctx || !name) return UCG_ERR_INVALID;

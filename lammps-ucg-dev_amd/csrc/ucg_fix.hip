@@ -181,9 +181,35 @@ __global__ void k_thermo_final(const double *part, int nblocks, double *out)
   }
 }
 
+// PMC calibration: stream `n` elements of width 4 B (WIDE=false) or 16 B (WIDE=true) per lane
+template <bool WIDE>
+__global__ __launch_bounds__(FIX_BLOCK) void k_stream(const int4 *p, size_t n, int *sink)
+{
+  size_t i = (size_t) blockIdx.x * FIX_BLOCK + threadIdx.x;
+  const size_t stride = (size_t) gridDim.x * FIX_BLOCK;
+  int acc = 0;
+  if (WIDE) {
+    for (; i < n; i += stride) {
+      const int4 v = p[i];
+      acc += v.x ^ v.y ^ v.z ^ v.w;
+    }
+  } else {
+    const int *q = reinterpret_cast<const int *>(p);
+    for (; i < n; i += stride) acc += q[i];
+  }
+  if (acc == 0x7fffffff) *sink = acc;
+}
+
 inline int nblk(int n) { return (n + FIX_BLOCK - 1) / FIX_BLOCK; }
 
 }  // namespace
+
+hipError_t launch_stream(const void *buf, size_t nbytes, int wide, int *sink, hipStream_t st)
+{
+  if (wide) hipLaunchKernelGGL(k_stream<true>, dim3(2048), dim3(FIX_BLOCK), 0, st, (const int4 *) buf, nbytes / 16, sink);
+  else hipLaunchKernelGGL(k_stream<false>, dim3(2048), dim3(FIX_BLOCK), 0, st, (const int4 *) buf, nbytes / 4, sink);
+  return hipGetLastError();
+}
 
 hipError_t launch_nve_initial(const AtomsDev &A, double dtv, double dtf, int groupbit, hipStream_t st)
 {

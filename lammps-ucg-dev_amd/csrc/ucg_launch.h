@@ -37,6 +37,7 @@ hipError_t launch_lambda_ke(const AtomsDev &A, int groupbit, double mvv2e, doubl
 hipError_t launch_ucgstate(const AtomsDev &A, int ld_flag, int mc_flag, double mc_rate,
                            const unsigned int *draws, hipStream_t st);
 hipError_t launch_force_clear(const AtomsDev &A, hipStream_t st);
+hipError_t launch_stream(const void *buf, size_t nbytes, int wide, int *sink, hipStream_t st);
 
 // ---- ucg_ranmars.hip : exact block-parallel RANMAR
 struct RanMarsDev {
