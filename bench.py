@@ -97,6 +97,10 @@ def main():
     else:
         beads = synth.make_beads(args.ncell, seed=12345)
         ctx = capi.Context(local_rank, dt=dt)
+        if os.environ.get("UCG_GATHER_SLOTS"):
+            ctx.set_option("gather_slots", int(os.environ["UCG_GATHER_SLOTS"]))
+        if os.environ.get("UCG_STAGE_OWN"):
+            ctx.set_option("stage_own", int(os.environ["UCG_STAGE_OWN"]))
         ctx.upload_beads(beads)
         ctx.domain_set(beads.boxlo, beads.boxhi, 2.5, 0.3, every=10, delay=0, check=1)
         pair = capi.Pair(ctx, "table_ucgld")

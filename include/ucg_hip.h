@@ -110,6 +110,10 @@ double ucg_pair_cutforce(const ucg_pair *p);
 /* Pair::single(): UCG/pair_table_ucgld.cpp:1474-1520, evaluated on the host */
 int ucg_pair_single(const ucg_pair *p, int itype, int jtype, double rsq, double factor_lj,
                     double *fforce, double *energy);
+/* lanes per bead of the table_ucgld / table_ucg_bethe kernels (option "gather_slots": 1, 4, 8, 16;
+ * default 1).  It is part of the canonical summation order: entry e of a row is added into partial
+ * sum e % slots, and the partial sums are combined by the tree s[l] += s[l + slots/2], ..., s[l] += s[l+1]. */
+int ucg_pair_gather_slots(const ucg_pair *p);
 /* host copies of the built tables, for inspection: which in
  * {"rsq","e","f","de","df","e2","f2"}; returns the length or <0 */
 int ucg_pair_table_count(const ucg_pair *p);

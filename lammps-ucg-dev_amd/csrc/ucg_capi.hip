@@ -365,6 +365,7 @@ int ucg_pair_init(ucg_pair *p, int ntypes, double T)
     D.dens_as_shipped = ctx->density_proximity_as_shipped ? 1 : 0;
     D.kT = M.kT;
     D.rkT = 1.0 / M.kT;
+    D.gather_slots = ctx->gather_slots;
     for (int i = 0; i < 4; i++) D.special_lj[i] = ctx->special_lj[i];
     {
       // FAST kernels: same arithmetic, less work (see ucg_pair.hip).  Conditions checked here.
@@ -394,6 +395,10 @@ int ucg_pair_init(ucg_pair *p, int ntypes, double T)
       D.tab_fast = p->d_tab_fast.get();
       const size_t bytes = fast ? ((nslots + 1) / 2) * sizeof(double4) : (size_t) ntab * tl * sizeof(double4);
       D.tab_in_lds = (bytes <= 152 * 1024) ? 1 : 0;
+      // own-bead staging: 36 bytes per bead of the workgroup behind the tables, if the 160 KB allow it
+      const size_t own = (size_t) (1024 / ctx->gather_slots) * 36;
+      const size_t used = (D.tab_in_lds ? bytes : 0) + own + 6 * 1024;  // + the static model arrays
+      D.stage_own = (ctx->stage_own && used <= 160 * 1024) ? 1 : 0;
     }
     if (M.style == STYLE_BETHE && M.prior_flag == PRIOR_CHEMPOT_NOISE)
       return fail(ctx, UCG_ERR_UNSUPPORTED,
@@ -425,6 +430,8 @@ int ucg_pair_single(const ucg_pair *p, int itype, int jtype, double rsq, double 
     return UCG_OK;
   });
 }
+
+int ucg_pair_gather_slots(const ucg_pair *p) { return (p && p->uploaded) ? p->dev.gather_slots : 1; }
 
 int ucg_pair_table_count(const ucg_pair *p) { return p ? (int) p->model.tables.size() : -1; }
 
@@ -480,7 +487,7 @@ int ucg_pair_compute(ucg_pair *p, int eflag, int vflag, double *eng_vdwl, double
     if (!p->uploaded) return fail(ctx, UCG_ERR_INVALID, "ucg_pair_compute before ucg_pair_init");
     if (ctx->list_inum != ctx->nlocal) return fail(ctx, UCG_ERR_INVALID, "neighbour list does not match the resident atoms");
     const bool ev = (eflag || vflag);
-    const int nb = pair_gather_blocks(ctx->nlocal);
+    const int nb = pair_gather_blocks(ctx->nlocal, p->dev.gather_slots);
     if (ev) p->d_evpart.reserve((size_t) nb * 8 + 8);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->prof_on) {
@@ -1008,6 +1015,18 @@ int ucg_ctx_set_option(ucg_ctx *ctx, const char *name, int value)
   if (!ctx || !name) return UCG_ERR_INVALID;
   if (std::strcmp(name, "generic_kernels") == 0) {
     ctx->force_generic_kernels = value != 0;
+    return UCG_OK;
+  }
+  if (std::strcmp(name, "stage_own") == 0) {
+    ctx->stage_own = value != 0;
+    return UCG_OK;
+  }
+  if (std::strcmp(name, "gather_slots") == 0) {
+    if (value != 1 && value != 4 && value != 8 && value != 16) {
+      ctx->err = "gather_slots must be 1, 4, 8 or 16";
+      return UCG_ERR_INVALID;
+    }
+    ctx->gather_slots = value;
     return UCG_OK;
   }
   if (std::strcmp(name, "density_proximity_as_shipped") == 0) {

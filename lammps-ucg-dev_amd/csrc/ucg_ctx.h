@@ -93,6 +93,8 @@ struct ucg_ctx {
   double boltz = 1, ftm2v = 1, mvv2e = 1, dt = 0.005;
   double special_lj[4] = {1, 1, 1, 1};
   bool density_proximity_as_shipped = false;  // option of the same name (App. B #12)
+  bool stage_own = true;  // option "stage_own": LDS staging of the workgroup's own beads in k_pair_gather
+  int gather_slots = 1;  // option "gather_slots": lanes per bead of the ucgld / bethe gather kernels
   bool force_generic_kernels = false;  // option "generic_kernels": never pick the FAST variants
 
   // atoms

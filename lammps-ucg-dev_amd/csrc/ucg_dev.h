@@ -41,6 +41,8 @@ struct PairDev {
   int dens_as_shipped;      // 1: back-force uses the proximity function itself (App. B #12)
   double kT;
   double rkT;          // RN(1/kT), used by the FAST kernels' exact division
+  int gather_slots;    // lanes per bead in k_pair_gather (1, 4, 8 or 16): part of the canonical order
+  int stage_own;       // 1: k_pair_gather keeps its workgroup's own beads in LDS behind the tables
   int fast;            // 1: one shared r^2 grid, all special_lj == 1, kT usable for div_by_const
   double special_lj[4];
 };

@@ -11,7 +11,7 @@
 namespace ucg {
 
 // ---- ucg_pair.hip
-int pair_gather_blocks(int nlocal);
+int pair_gather_blocks(int nlocal, int slots);
 hipError_t launch_pair_gather(const PairDev &P, const AtomsDev &A, const ListDev &L, bool ev,
                               double *evpart, double *evout, int *errflag, hipStream_t st);
 

@@ -8,8 +8,8 @@
 // management follows the "ucg-rebuild-v1" specification, which the CPU
 // oracle implements independently so that whole trajectories can be compared bit for bit:
 //   (1) wrap owned beads into the box; (2) bins of ~cutneigh/2 over the box extended by
-//   cutneigh; (3) sort owned beads by (bin, tag); (4) ghosts = periodic images that fall in
-//   the extended box, sorted by (bin, tag, shift code); (5) full-list rows in stencil order
+//   cutneigh; (3) sort owned beads by (Morton code of the bin, tag); (4) ghosts = periodic images
+//   that fall in the extended box, sorted by (Morton code of the bin, tag, shift code); (5) full-list rows in stencil order
 //   (dz, dy, dx ascending), owned beads of a bin before its ghosts, kept when
 //   rsq < cutneigh^2, bit 29 = (tag_row <= tag_neighbour); each row stably partitioned into
 //   four build-time distance classes (inside the force cutoff, then thirds of the skin).
@@ -39,12 +39,17 @@ struct Domain {
   int nbin[3] = {1, 1, 1}, sten[3] = {0, 0, 0}, nbins = 1;
   double bboxlo[3], bboxhi[3], binsize[3], bininv[3];
   int ago = 0;
-  DevBuf<int> bin_of, cell_o0, cell_o1, cell_g0, cell_g1, ghost_code, counter, rowclass;
+  DevBuf<int> bin_of, ghost_code, counter, rowclass;
+  DevBuf<int4> cells;     // per bin {owned start, owned end, ghost start, ghost end}
+  DevBuf<double4> bpos;   // builder records {x, y, z, (double) tag}
   DevBuf<double4> xhold, tmp4;
   DevBuf<unsigned long long> keys_in, keys_out;
   DevBuf<int> vals_in, vals_out, tmpi, cand_src, cand_code;
   DevBuf<double> tmpd;
   DevBuf<char> cub_tmp;
+  DevBuf<int> scratch;                 // discovery-order rows before the class partition
+  DevBuf<unsigned long long> rowstat;  // [0] max row length, [1] total entries
+  int row_capacity = 0;
 };
 
 struct DomainDev {
@@ -102,6 +107,22 @@ __device__ __forceinline__ int coord2bin(const DomainDev &D, double x, double y,
   return (bz * D.nbin[1] + by) * D.nbin[0] + bx;
 }
 
+// Morton (Z-order) code of a bin, 9 bits per dimension: beads sorted along this curve form
+// compact blobs, so most neighbours of a workgroup's beads are the workgroup's own beads
+__device__ __forceinline__ unsigned long long morton_of_bin(const DomainDev &D, int b)
+{
+  const unsigned bx = (unsigned) (b % D.nbin[0]), by = (unsigned) ((b / D.nbin[0]) % D.nbin[1]);
+  const unsigned bz = (unsigned) (b / (D.nbin[0] * D.nbin[1]));
+  unsigned long long m = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    m |= (unsigned long long) ((bx >> i) & 1u) << (3 * i);
+    m |= (unsigned long long) ((by >> i) & 1u) << (3 * i + 1);
+    m |= (unsigned long long) ((bz >> i) & 1u) << (3 * i + 2);
+  }
+  return m;
+}
+
 __device__ __forceinline__ double wrap1(double x, double lo, double hi, double prd)
 {
   // Domain::pbc(), orthogonal periodic
@@ -123,7 +144,7 @@ __global__ __launch_bounds__(NB) void k_wrap_and_key(const DomainDev D, int n, d
   p.y = wrap1(p.y, D.boxlo[1], D.boxhi[1], D.prd[1]);
   p.z = wrap1(p.z, D.boxlo[2], D.boxhi[2], D.prd[2]);
   pos4[i] = p;
-  const unsigned long long b = (unsigned long long) coord2bin(D, p.x, p.y, p.z);
+  const unsigned long long b = morton_of_bin(D, coord2bin(D, p.x, p.y, p.z));
   keys[i] = (b << 37) | ((unsigned long long) (unsigned int) tag[i] << 5);
   vals[i] = i;
 }
@@ -135,10 +156,12 @@ __global__ __launch_bounds__(NB) void k_gather(int n, const int *perm, const T *
   if (i < n) dst[i] = src[perm[i]];
 }
 
-__global__ __launch_bounds__(NB) void k_bins_from_keys(int n, const unsigned long long *keys, int *bin_of)
+__global__ __launch_bounds__(NB) void k_bins_from_pos(const DomainDev D, int n, int offset, const double4 *pos4, int *bin_of)
 {
   const int i = blockIdx.x * NB + threadIdx.x;
-  if (i < n) bin_of[i] = (int) (keys[i] >> 37);
+  if (i >= n) return;
+  const double4 p = pos4[offset + i];
+  bin_of[offset + i] = coord2bin(D, p.x, p.y, p.z);
 }
 
 // periodic images of owned beads that fall inside the extended box; FILL=false counts only
@@ -163,7 +186,7 @@ __global__ __launch_bounds__(NB) void k_ghost_candidates(const DomainDev D, int 
         const int slot = atomicAdd(counter, 1);
         if (FILL) {
           const int code = (sz + 1) * 9 + (sy + 1) * 3 + (sx + 1);
-          const unsigned long long b = (unsigned long long) coord2bin(D, xs, ys, zs);
+          const unsigned long long b = morton_of_bin(D, coord2bin(D, xs, ys, zs));
           keys[slot] = (b << 37) | ((unsigned long long) (unsigned int) tag[i] << 5) | (unsigned long long) code;
           vals[slot] = slot;
           cand_src[slot] = i;
@@ -184,7 +207,6 @@ __global__ __launch_bounds__(NB) void k_ghost_finalize(int ng, int nlocal, const
   const int src = cand_src[c];
   ghost_src[g] = src;
   ghost_code[g] = cand_code[c];
-  bin_of[nlocal + g] = (int) (keys[g] >> 37);
   tag[nlocal + g] = tag[src];
   meta[nlocal + g] = meta[src];
 }
@@ -207,77 +229,142 @@ __global__ __launch_bounds__(NB) void k_halo_forward(const DomainDev D, int ng, 
   ucgp[nlocal + g] = ucgp[src];
 }
 
-__global__ __launch_bounds__(NB) void k_cell_ranges(int n, int offset, const int *bin_of, int *cell0, int *cell1)
+// per bin {owned start, owned end, ghost start, ghost end}; cls selects the pair to fill
+__global__ __launch_bounds__(NB) void k_cell_ranges(int n, int offset, const int *bin_of, int4 *cells, int cls)
 {
   const int i = blockIdx.x * NB + threadIdx.x;
   if (i >= n) return;
   const int b = bin_of[offset + i];
-  if (i == 0 || bin_of[offset + i - 1] != b) cell0[b] = offset + i;
-  if (i == n - 1 || bin_of[offset + i + 1] != b) cell1[b] = offset + i + 1;
+  int *c = reinterpret_cast<int *>(&cells[b]) + 2 * cls;
+  if (i == 0 || bin_of[offset + i - 1] != b) c[0] = offset + i;
+  if (i == n - 1 || bin_of[offset + i + 1] != b) c[1] = offset + i + 1;
 }
 
-// full-list rows.  FILL=false counts the row and its four build-time distance classes
-// (class 0: inside the force cutoff; 1..3: thirds of the skin shell); FILL=true writes the
-// entries, each class contiguous and in stencil-traversal order (stable partition).
-template <bool FILL>
-__global__ __launch_bounds__(NB) void k_build_rows(const DomainDev D, int nlocal, const double4 *pos4, const int *tag,
-                                                  const int *bin_of, const int *cell_o0, const int *cell_o1,
-                                                  const int *cell_g0, const int *cell_g1, int *rowcount, int *rowclass,
-                                                  int *neigh, int pitch)
+// builder records: position + tag in one 32-byte gather
+__global__ __launch_bounds__(NB) void k_builder_records(int nall, const double4 *pos4, const int *tag, double4 *bpos)
 {
+  const int i = blockIdx.x * NB + threadIdx.x;
+  if (i >= nall) return;
+  double4 p = pos4[i];
+  p.w = (double) tag[i];
+  bpos[i] = p;
+}
+
+// full-list rows, pass 1 ("discover"): one lane per owned bead walks the stencil bins in
+// (dz, dy, dx) ascending order -- bins farther than cutneigh from the bead itself are skipped --
+// and appends every neighbour within cutneigh to a scratch row in discovery order, tagged with
+// its build-time distance class in bits 30-31 (class 0: inside the force cutoff; 1..3: thirds of
+// the skin shell).  Rows longer than `cap` are counted but not stored (the host then grows the
+// buffers and repeats).  Per-class counts, row length, and block-reduced max / total are kept.
+__global__ __launch_bounds__(NB) void k_rows_discover(const DomainDev D, int nlocal, const double4 *pos4,
+                                                     const int *bin_of, const int4 *cells, int *rowcount, int *rowclass,
+                                                     int *scratch, int pitch, int cap, const double3 binsize,
+                                                     int *maxrow, unsigned long long *total)
+{
+  __shared__ int s_max[NB / 64];
+  __shared__ unsigned long long s_tot[NB / 64];
   const int k = blockIdx.x * NB + threadIdx.x;
-  if (k >= nlocal) return;
-  const double4 pk = pos4[k];
-  const int tk = tag[k];
-  const int b = bin_of[k];
-  const int bx = b % D.nbin[0], by = (b / D.nbin[0]) % D.nbin[1], bz = b / (D.nbin[0] * D.nbin[1]);
-  int p0 = 0, p1 = 0, p2 = 0, p3 = 0;
-  if (FILL) {
-    p1 = rowclass[k];
-    p2 = p1 + rowclass[pitch + k];
-    p3 = p2 + rowclass[2 * pitch + k];
-  }
-  for (int dz = -D.sten[2]; dz <= D.sten[2]; dz++) {
-    const int cz = bz + dz;
-    if (cz < 0 || cz >= D.nbin[2]) continue;
-    for (int dy = -D.sten[1]; dy <= D.sten[1]; dy++) {
-      const int cy = by + dy;
-      if (cy < 0 || cy >= D.nbin[1]) continue;
-      for (int dx = -D.sten[0]; dx <= D.sten[0]; dx++) {
-        const int cx = bx + dx;
-        if (cx < 0 || cx >= D.nbin[0]) continue;
-        const int c = (cz * D.nbin[1] + cy) * D.nbin[0] + cx;
-        for (int cls = 0; cls < 2; cls++) {
-          const int m0 = cls ? cell_g0[c] : cell_o0[c];
-          const int m1 = cls ? cell_g1[c] : cell_o1[c];
-          for (int m = m0; m < m1; m++) {
-            if (m == k) continue;
-            const double4 pm = pos4[m];
-            const double delx = pk.x - pm.x;
-            const double dely = pk.y - pm.y;
-            const double delz = pk.z - pm.z;
-            const double rsq = delx * delx + dely * dely + delz * delz;
-            if (rsq < D.cutneighsq) {
-              int slot;
-              if (rsq < D.cls_sq[0]) slot = p0++;
-              else if (rsq < D.cls_sq[1]) slot = p1++;
-              else if (rsq < D.cls_sq[2]) slot = p2++;
-              else slot = p3++;
-              if (FILL) {
-                const int orient = (tk <= tag[m]) ? 1 : 0;
-                neigh[(size_t) slot * pitch + k] = m | (orient << UCG_ORIENT_BIT);
+  int cnt = 0;
+  if (k < nlocal) {
+    const double4 pk = pos4[k];  // builder record: w = tag
+    const double tk = pk.w;
+    const int b = bin_of[k];
+    const int bx = b % D.nbin[0], by = (b / D.nbin[0]) % D.nbin[1], bz = b / (D.nbin[0] * D.nbin[1]);
+    const double prune = D.cutneighsq * (1.0 + 1.0e-9) + 1.0e-12;
+    int c0 = 0, c1 = 0, c2 = 0;
+    for (int dz = -D.sten[2]; dz <= D.sten[2]; dz++) {
+      const int cz = bz + dz;
+      if (cz < 0 || cz >= D.nbin[2]) continue;
+      const double zlo = D.bboxlo[2] + cz * binsize.z;
+      const double ez = pk.z < zlo ? zlo - pk.z : (pk.z > zlo + binsize.z ? pk.z - (zlo + binsize.z) : 0.0);
+      for (int dy = -D.sten[1]; dy <= D.sten[1]; dy++) {
+        const int cy = by + dy;
+        if (cy < 0 || cy >= D.nbin[1]) continue;
+        const double ylo = D.bboxlo[1] + cy * binsize.y;
+        const double ey = pk.y < ylo ? ylo - pk.y : (pk.y > ylo + binsize.y ? pk.y - (ylo + binsize.y) : 0.0);
+        if (ez * ez + ey * ey > prune) continue;
+        for (int dx = -D.sten[0]; dx <= D.sten[0]; dx++) {
+          const int cx = bx + dx;
+          if (cx < 0 || cx >= D.nbin[0]) continue;
+          const double xlo = D.bboxlo[0] + cx * binsize.x;
+          const double ex = pk.x < xlo ? xlo - pk.x : (pk.x > xlo + binsize.x ? pk.x - (xlo + binsize.x) : 0.0);
+          if (ez * ez + ey * ey + ex * ex > prune) continue;
+          const int c = (cz * D.nbin[1] + cy) * D.nbin[0] + cx;
+          const int4 cell = cells[c];
+          for (int cls = 0; cls < 2; cls++) {
+            const int m0 = cls ? cell.z : cell.x;
+            const int m1 = cls ? cell.w : cell.y;
+            for (int m = m0; m < m1; m++) {
+              if (m == k) continue;
+              const double4 pm = pos4[m];
+              const double delx = pk.x - pm.x;
+              const double dely = pk.y - pm.y;
+              const double delz = pk.z - pm.z;
+              const double rsq = delx * delx + dely * dely + delz * delz;
+              if (rsq < D.cutneighsq) {
+                int rc;
+                if (rsq < D.cls_sq[0]) { rc = 0; c0++; }
+                else if (rsq < D.cls_sq[1]) { rc = 1; c1++; }
+                else if (rsq < D.cls_sq[2]) { rc = 2; c2++; }
+                else rc = 3;
+                if (cnt < cap) {
+                  const int orient = (tk <= pm.w) ? 1 : 0;
+                  scratch[(size_t) cnt * pitch + k] = m | (orient << UCG_ORIENT_BIT) | (rc << 30);
+                }
+                cnt++;
               }
             }
           }
         }
       }
     }
+    rowcount[k] = cnt;
+    rowclass[k] = c0;
+    rowclass[pitch + k] = c1;
+    rowclass[2 * pitch + k] = c2;
   }
-  if (!FILL) {
-    rowcount[k] = p0 + p1 + p2 + p3;
-    rowclass[k] = p0;
-    rowclass[pitch + k] = p1;
-    rowclass[2 * pitch + k] = p2;
+  // block max / total -> one atomic each per block (integer: order-free)
+  int mx = cnt;
+  unsigned long long tot = (unsigned long long) cnt;
+  for (int off = 32; off > 0; off >>= 1) {
+    mx = max(mx, __shfl_down(mx, off, 64));
+    tot += __shfl_down(tot, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    s_max[threadIdx.x >> 6] = mx;
+    s_tot[threadIdx.x >> 6] = tot;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < NB / 64; w++) {
+      mx = max(mx, s_max[w]);
+      tot += s_tot[w];
+    }
+    atomicMax(maxrow, mx);
+    atomicAdd(total, tot);
+  }
+}
+
+// pass 2 ("partition"): stable partition of each scratch row into its four classes
+__global__ __launch_bounds__(NB) void k_rows_partition(int nlocal, const int *rowcount, const int *rowclass,
+                                                      const int *scratch, int *neigh, int pitch)
+{
+  const int k = blockIdx.x * NB + threadIdx.x;
+  if (k >= nlocal) return;
+  const int n = rowcount[k];
+  int p0 = 0;
+  int p1 = rowclass[k];
+  int p2 = p1 + rowclass[pitch + k];
+  int p3 = p2 + rowclass[2 * pitch + k];
+  for (int e = 0; e < n; e++) {
+    const int ent = scratch[(size_t) e * pitch + k];
+    const int rc = (ent >> 30) & 3;
+    int slot;
+    if (rc == 0) slot = p0++;
+    else if (rc == 1) slot = p1++;
+    else if (rc == 2) slot = p2++;
+    else slot = p3++;
+    neigh[(size_t) slot * pitch + k] = ent & 0x3FFFFFFF;
   }
 }
 
@@ -364,7 +451,7 @@ void sort_owned(ucg_ctx *ctx, bool wrap)
   permute(ctx, n, perm, ctx->ucgml, D.tmpd);
   permute(ctx, n, perm, ctx->ucgp, D.tmpd);
   D.bin_of.reserve((size_t) n);
-  hipLaunchKernelGGL(k_bins_from_keys, dim3(nblk(n)), dim3(NB), 0, st, n, D.keys_out.get(), D.bin_of.get());
+  hipLaunchKernelGGL(k_bins_from_pos, dim3(nblk(n)), dim3(NB), 0, st, dd, n, 0, ctx->pos4.get(), D.bin_of.get());
 
 }
 
@@ -380,7 +467,7 @@ void rebuild(ucg_ctx *ctx)
     if (D.prd[d] < 2.0 * D.cutneigh * 0.5)
       throw InputError{"periodic box shorter than the ghost cutoff: more than one image layer would be needed"};
   setup_bins(D);
-  if ((long long) D.nbin[0] * D.nbin[1] * D.nbin[2] >= (1LL << 27)) throw InputError{"too many bins for the sort key"};
+  if (D.nbin[0] > 512 || D.nbin[1] > 512 || D.nbin[2] > 512) throw InputError{"more than 512 bins per dimension: too many for the sort key"};
   const DomainDev dd = make_dev(D);
 
   sort_owned(ctx, true);
@@ -418,6 +505,7 @@ void rebuild(ucg_ctx *ctx)
                        ctx->tag.get(), ctx->meta.get());
     hipLaunchKernelGGL(k_halo_forward, dim3(nblk(ng)), dim3(NB), 0, st, dd, ng, n, ctx->ghost_src.get(), D.ghost_code.get(),
                        ctx->pos4.get(), ctx->meta.get(), ctx->ucgp.get());
+    hipLaunchKernelGGL(k_bins_from_pos, dim3(nblk(ng)), dim3(NB), 0, st, dd, ng, n, ctx->pos4.get(), D.bin_of.get());
   }
   ctx->nghost = ng;
   ctx->ghost_src_valid = true;
@@ -433,41 +521,42 @@ void build_bins_and_rows(ucg_ctx *ctx)
   const DomainDev dd = make_dev(D);
   // (2) bin ranges of both classes
   const size_t nb1 = (size_t) D.nbins + 1;
-  D.cell_o0.reserve(nb1);
-  D.cell_o1.reserve(nb1);
-  D.cell_g0.reserve(nb1);
-  D.cell_g1.reserve(nb1);
-  UCG_HIP(hipMemsetAsync(D.cell_o0.get(), 0, nb1 * sizeof(int), st));
-  UCG_HIP(hipMemsetAsync(D.cell_o1.get(), 0, nb1 * sizeof(int), st));
-  UCG_HIP(hipMemsetAsync(D.cell_g0.get(), 0, nb1 * sizeof(int), st));
-  UCG_HIP(hipMemsetAsync(D.cell_g1.get(), 0, nb1 * sizeof(int), st));
-  hipLaunchKernelGGL(k_cell_ranges, dim3(nblk(n)), dim3(NB), 0, st, n, 0, D.bin_of.get(), D.cell_o0.get(), D.cell_o1.get());
-  if (ng > 0)
-    hipLaunchKernelGGL(k_cell_ranges, dim3(nblk(ng)), dim3(NB), 0, st, ng, n, D.bin_of.get(), D.cell_g0.get(),
-                       D.cell_g1.get());
+  D.cells.reserve(nb1);
+  UCG_HIP(hipMemsetAsync(D.cells.get(), 0, nb1 * sizeof(int4), st));
+  hipLaunchKernelGGL(k_cell_ranges, dim3(nblk(n)), dim3(NB), 0, st, n, 0, D.bin_of.get(), D.cells.get(), 0);
+  if (ng > 0) hipLaunchKernelGGL(k_cell_ranges, dim3(nblk(ng)), dim3(NB), 0, st, ng, n, D.bin_of.get(), D.cells.get(), 1);
+  D.bpos.reserve((size_t) n + ng);
+  hipLaunchKernelGGL(k_builder_records, dim3(nblk((long long) n + ng)), dim3(NB), 0, st, n + ng, ctx->pos4.get(),
+                     ctx->tag.get(), D.bpos.get());
 
-  // (5) rows: count, size, fill
+  // (5) rows: discover into a scratch list (capacity from the previous build), then partition
   const int pitch = ((n + 63) / 64) * 64;
   ctx->numneigh.reserve((size_t) pitch);
   D.rowclass.reserve((size_t) pitch * 3);
-  hipLaunchKernelGGL(k_build_rows<false>, dim3(nblk(n)), dim3(NB), 0, st, dd, n, ctx->pos4.get(), ctx->tag.get(),
-                     D.bin_of.get(), D.cell_o0.get(), D.cell_o1.get(), D.cell_g0.get(), D.cell_g1.get(),
-                     ctx->numneigh.get(), D.rowclass.get(), nullptr, pitch);
-  // max and total row length (hipcub reductions into counter[0..1] would need two temp buffers; rows are
-  // rebuilt rarely, so a small host pass over the counts is acceptable here)
-  std::vector<int> counts((size_t) n);
-  UCG_HIP(hipMemcpyAsync(counts.data(), ctx->numneigh.get(), (size_t) n * sizeof(int), hipMemcpyDeviceToHost, st));
-  UCG_HIP(hipStreamSynchronize(st));
+  D.rowstat.reserve(4);
+  const double3 bs = make_double3(D.binsize[0], D.binsize[1], D.binsize[2]);
+  int cap = D.row_capacity > 0 ? D.row_capacity : 96;
   int maxrow = 0;
   long long total = 0;
-  for (int i = 0; i < n; i++) {
-    if (counts[(size_t) i] > maxrow) maxrow = counts[(size_t) i];
-    total += counts[(size_t) i];
+  for (int attempt = 0; attempt < 3; attempt++) {
+    D.scratch.reserve((size_t) pitch * (size_t) cap);
+    UCG_HIP(hipMemsetAsync(D.rowstat.get(), 0, 4 * sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(k_rows_discover, dim3(nblk(n)), dim3(NB), 0, st, dd, n, D.bpos.get(), D.bin_of.get(),
+                       D.cells.get(), ctx->numneigh.get(), D.rowclass.get(), D.scratch.get(), pitch, cap, bs,
+                       (int *) D.rowstat.get(), D.rowstat.get() + 1);
+    unsigned long long stat[2];
+    UCG_HIP(hipMemcpyAsync(stat, D.rowstat.get(), sizeof stat, hipMemcpyDeviceToHost, st));
+    UCG_HIP(hipStreamSynchronize(st));
+    maxrow = (int) (stat[0] & 0xFFFFFFFFull);
+    total = (long long) stat[1];
+    if (maxrow <= cap) break;
+    cap = maxrow + 16;  // a row did not fit: grow and rediscover
   }
+  if (maxrow > cap) throw InputError{"neighbour rows keep overflowing their buffers"};
+  D.row_capacity = maxrow + 16;
   ctx->neigh.reserve((size_t) pitch * (size_t) (maxrow > 0 ? maxrow : 1));
-  hipLaunchKernelGGL(k_build_rows<true>, dim3(nblk(n)), dim3(NB), 0, st, dd, n, ctx->pos4.get(), ctx->tag.get(),
-                     D.bin_of.get(), D.cell_o0.get(), D.cell_o1.get(), D.cell_g0.get(), D.cell_g1.get(), nullptr,
-                     D.rowclass.get(), ctx->neigh.get(), pitch);
+  hipLaunchKernelGGL(k_rows_partition, dim3(nblk(n)), dim3(NB), 0, st, n, ctx->numneigh.get(), D.rowclass.get(),
+                     D.scratch.get(), ctx->neigh.get(), pitch);
   ctx->list_inum = n;
   ctx->list_pitch = pitch;
   ctx->list_maxrow = maxrow;
@@ -668,19 +757,16 @@ __global__ __launch_bounds__(NB) void k_border_keys(const DomainDev D, int ng, c
   const int j = blockIdx.x * NB + threadIdx.x;
   if (j >= ng) return;
   const HaloRec r = in[j];
-  const unsigned long long b = (unsigned long long) coord2bin(D, r.x, r.y, r.z);
+  const unsigned long long b = morton_of_bin(D, coord2bin(D, r.x, r.y, r.z));
   const unsigned long long code = (unsigned long long) ((r.meta >> 24) & 31);
   keys[j] = (b << 37) | ((unsigned long long) (unsigned int) r.tag << 5) | code;
   vals[j] = j;
 }
 
-__global__ __launch_bounds__(NB) void k_border_finalize(int ng, int nlocal, const int *order, const unsigned long long *keys,
-                                                       int *perm, int *bin_of)
+__global__ __launch_bounds__(NB) void k_border_finalize(int ng, const int *order, int *perm)
 {
   const int g = blockIdx.x * NB + threadIdx.x;
-  if (g >= ng) return;
-  perm[g] = order[g];
-  bin_of[nlocal + g] = (int) (keys[g] >> 37);
+  if (g < ng) perm[g] = order[g];
 }
 
 __global__ __launch_bounds__(NB) void k_halo_unpack(int ng, int nlocal, const int *perm, const HaloRec *in, double4 *pos4,
@@ -1041,7 +1127,7 @@ int ucg_border_count(ucg_ctx *ctx, long long *sendcounts)
     Domain &D = *ctx->dom;
     const int n = ctx->nlocal;
     setup_bins(D);
-    if ((long long) D.nbin[0] * D.nbin[1] * D.nbin[2] >= (1LL << 27)) throw InputError{"too many bins for the sort key"};
+    if (D.nbin[0] > 512 || D.nbin[1] > 512 || D.nbin[2] > 512) throw InputError{"more than 512 bins per dimension: too many for the sort key"};
     if (n > 0) sort_owned(ctx, true);
     const DomainDev dd = make_dev(D);
     UCG_HIP(hipMemsetAsync(D.counter.get(), 0, (size_t) D.world * sizeof(int), ctx->stream));
@@ -1107,10 +1193,10 @@ int ucg_border_unpack(ucg_ctx *ctx, const void *recvbuf, long long nrecv)
       hipLaunchKernelGGL(k_border_keys, dim3(nblk(ng)), dim3(NB), 0, st, dd, ng, (const HaloRec *) recvbuf,
                          D.keys_in.get(), D.vals_in.get());
       sort_pairs(ctx, D, ng);
-      hipLaunchKernelGGL(k_border_finalize, dim3(nblk(ng)), dim3(NB), 0, st, ng, n, D.vals_out.get(), D.keys_out.get(),
-                         D.ghost_perm.get(), D.bin_of.get());
+      hipLaunchKernelGGL(k_border_finalize, dim3(nblk(ng)), dim3(NB), 0, st, ng, D.vals_out.get(), D.ghost_perm.get());
       hipLaunchKernelGGL(k_halo_unpack, dim3(nblk(ng)), dim3(NB), 0, st, ng, n, D.ghost_perm.get(),
                          (const HaloRec *) recvbuf, ctx->pos4.get(), ctx->meta.get(), ctx->ucgp.get(), ctx->tag.get(), 1);
+      hipLaunchKernelGGL(k_bins_from_pos, dim3(nblk(ng)), dim3(NB), 0, st, dd, ng, n, ctx->pos4.get(), D.bin_of.get());
     }
     ctx->nghost = ng;
     ctx->ghost_src_valid = false;  // ghosts of a decomposed run belong to other ranks

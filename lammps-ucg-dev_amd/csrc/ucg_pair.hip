@@ -32,7 +32,7 @@ namespace ucg {
 
 namespace {
 
-template <int STYLE, int TS, bool EV, bool LDS_TAB, bool FAST>
+template <int STYLE, int TS, bool EV, bool LDS_TAB, bool FAST, int SLOTS>
 __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, const AtomsDev A,
                                                            const ListDev Lst, double *evpart,
                                                            int *errflag)
@@ -46,6 +46,23 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
 
   // in double4 units; the FAST layout is tablength * (2*ntab+1) 16-byte slots
   const int ntabent = FAST ? (P.tablength * P.fast_stride + 1) / 2 : P.ntab * P.tablength;
+  // the workgroup's own beads, staged in LDS behind the tables (when they fit): beads are sorted
+  // along a Morton curve, so ~3/4 of a bead's neighbours are beads of its own workgroup and are then
+  // read from LDS instead of through the vector L1, whose tag rate (one line per lane per load) is
+  // what bounds this kernel otherwise.  Same values either way.
+  const bool stage_own = P.stage_own != 0;
+  double4 *s_ownpos = s_tab + (LDS_TAB ? ntabent : 0);
+  int *s_ownmeta = reinterpret_cast<int *>(s_ownpos + PAIR_BLOCK / SLOTS);
+  const int k0 = xcd_chunk(blockIdx.x, gridDim.x) * (PAIR_BLOCK / SLOTS);
+  if (stage_own) {
+    for (int t = threadIdx.x; t < PAIR_BLOCK / SLOTS; t += blockDim.x) {
+      if (k0 + t < A.nlocal) {
+        s_ownpos[t] = A.pos4[k0 + t];
+        s_ownmeta[t] = A.meta[k0 + t];
+      }
+    }
+  }
+  const unsigned nown = stage_own ? (unsigned) min(PAIR_BLOCK / SLOTS, A.nlocal - k0) : 0u;
   {
     const int na1sq = (P.n_actual + 1) * (P.n_actual + 1);
     for (int t = threadIdx.x; t < P.ntab; t += blockDim.x) s_par[t] = P.tabpar[t];
@@ -56,8 +73,13 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
     __syncthreads();
   }
 
+  // SLOTS lanes share one bead: lane `slot` takes the row entries e = slot, slot+SLOTS, ...;
+  // adjacent lanes then gather adjacent list entries (mostly adjacent beads: shared cache lines),
+  // and the SLOTS partial sums are combined by a fixed shuffle tree (the canonical order).
   const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
-  const int k = chunk * PAIR_BLOCK + threadIdx.x;
+  const int gtid = chunk * PAIR_BLOCK + threadIdx.x;
+  const int k = gtid / SLOTS;
+  const int slot = gtid % SLOTS;
   const int nlocal = A.nlocal;
   const int na1 = P.n_actual + 1;
   const double kT = P.kT, rkT = P.rkT;
@@ -70,18 +92,21 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
     const int tk = UCG_META_TYPE(mk);
     const double lk = pk.w;
     const int n = Lst.numneigh[k];
-    const int *rp = Lst.neigh + k;
     const size_t pitch = (size_t) Lst.pitch;
+    const size_t rstep = pitch * SLOTS;
+    const int *rp = Lst.neigh + k + (size_t) slot * pitch;
 
     double fx = 0.0, fy = 0.0, fz = 0.0, uf = 0.0, s0 = 0.0, s1 = 0.0;
     const double mu0 = P.mu[tk * 2 + 0], mu1 = P.mu[tk * 2 + 1];
-    if (STYLE == 0) {
-      const double mui = mu1 - mu0;
-      uf -= mui;
-      s1 -= mui / kT;
-    } else {
-      s0 = -mu0 / kT;
-      s1 = -mu1 / kT;
+    if (slot == 0) {  // the prologue values (:170-180 / bethe :155-162) start slot 0's sums
+      if (STYLE == 0) {
+        const double mui = mu1 - mu0;
+        uf -= mui;
+        s1 -= mui / kT;
+      } else {
+        s0 = -mu0 / kT;
+        s1 = -mu1 / kT;
+      }
     }
     // priors of k for the Bethe closure
     double pk_as_i1 = 0.0, pk_as_j1 = 0.0, pk_as_i0 = 0.0, pk_as_j0 = 0.0;
@@ -111,15 +136,46 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
       }
     }
 
-    // software pipeline: the gather of entry e+1 is in flight while entry e is evaluated
-    int ent = (n > 0) ? rp[0] : 0;
-    double4 pm = A.pos4[ent & 0x1FFFFFFF];
-    int mm = A.meta[ent & 0x1FFFFFFF];
-    for (int e = 0; e < n; e++) {
-      rp += pitch;
-      const int ent_n = (e + 1 < n) ? rp[0] : ent;
-      const double4 pm_n = A.pos4[ent_n & 0x1FFFFFFF];
-      const int mm_n = A.meta[ent_n & 0x1FFFFFFF];
+    // one actual type (the usual UCG deck): cutoff and table ids are the same for every pair
+    const bool onetype = (P.n_actual == 1);
+    const double cut11 = s_cutsq[na1 + 1];
+    const int pt11_0 = s_pairtab[(na1 + 1) * 4 + 0], pt11_1 = s_pairtab[(na1 + 1) * 4 + 1];
+    const int pt11_2 = s_pairtab[(na1 + 1) * 4 + 2], pt11_3 = s_pairtab[(na1 + 1) * 4 + 3];
+
+    // two-stage software pipeline: while entry e is evaluated, the gather of entry e+SLOTS is in
+    // flight and the list word of entry e+2*SLOTS is being fetched (no exposed index-load latency)
+    int ent = (slot < n) ? rp[0] : 0;
+    int ent_n = (slot + SLOTS < n) ? rp[rstep] : ent;
+    double4 pm;
+    int mm;
+    {
+      const int m0 = ent & 0x1FFFFFFF;
+      const unsigned ml = (unsigned) (m0 - k0);
+      if (ml < nown) {
+        pm = s_ownpos[ml];
+        mm = s_ownmeta[ml];
+      } else {
+        pm = A.pos4[m0];
+        mm = A.meta[m0];
+      }
+    }
+    rp += rstep;
+    for (int e = slot; e < n; e += SLOTS) {
+      rp += rstep;
+      const int ent_nn = (e + 2 * SLOTS < n) ? rp[0] : ent_n;
+      double4 pm_n;
+      int mm_n;
+      {
+        const int m1 = ent_n & 0x1FFFFFFF;
+        const unsigned ml = (unsigned) (m1 - k0);
+        if (ml < nown) {
+          pm_n = s_ownpos[ml];
+          mm_n = s_ownmeta[ml];
+        } else {
+          pm_n = A.pos4[m1];
+          mm_n = A.meta[m1];
+        }
+      }
 
       const int m = ent & 0x1FFFFFFF;
       const bool k_is_i = (ent >> 29) & 1;
@@ -135,8 +191,15 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
       const double dy = pk.y - pm.y;
       const double dz = pk.z - pm.z;
       const double rsq = dx * dx + dy * dy + dz * dz;
-      if (rsq < s_cutsq[tk * na1 + tm]) {
-        const int *pt = s_pairtab + (tk * na1 + tm) * 4;
+      const double cutv = onetype ? cut11 : s_cutsq[tk * na1 + tm];
+      if (rsq < cutv) {
+        int pt[4];
+        if (onetype) {
+          pt[0] = pt11_0; pt[1] = pt11_1; pt[2] = pt11_2; pt[3] = pt11_3;
+        } else {
+          const int *ps = s_pairtab + (tk * na1 + tm) * 4;
+          pt[0] = ps[0]; pt[1] = ps[1]; pt[2] = ps[2]; pt[3] = ps[3];
+        }
         Quad q;
         if (LDS_TAB) eval_quad<TS, FAST>(s_tab, s_par, pt, P.tablength, P.tlm1, P.fast_stride, rsq, factor_lj, q, err);
         else eval_quad<TS, FAST>(FAST ? P.tab_fast : P.tab, s_par, pt, P.tablength, P.tlm1, P.fast_stride, rsq, factor_lj, q, err);
@@ -252,17 +315,32 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
         }
       }
       ent = ent_n;
+      ent_n = ent_nn;
       pm = pm_n;
       mm = mm_n;
     }
-    if (STYLE == 0) {
-      A.frc4[k] = make_double4(fx, fy, fz, uf);
-    } else {
-      // table_ucg_bethe never touches ucgforce: it stays at its cleared value
-      A.frc4[k] = make_double4(fx, fy, fz, 0.0);
+    if (SLOTS > 1) {
+      // fixed tree over the bead's lanes: s[l] += s[l + off], off = SLOTS/2 ... 1
+#pragma unroll
+      for (int off = SLOTS / 2; off > 0; off >>= 1) {
+        fx += __shfl_down(fx, off, SLOTS);
+        fy += __shfl_down(fy, off, SLOTS);
+        fz += __shfl_down(fz, off, SLOTS);
+        if (STYLE == 0) uf += __shfl_down(uf, off, SLOTS);
+        s0 += __shfl_down(s0, off, SLOTS);
+        s1 += __shfl_down(s1, off, SLOTS);
+      }
     }
-    A.scores[k] = make_double2(s0, s1);
-    A.num_ucgstates[k] = 2;
+    if (slot == 0) {
+      if (STYLE == 0) {
+        A.frc4[k] = make_double4(fx, fy, fz, uf);
+      } else {
+        // table_ucg_bethe never touches ucgforce: it stays at its cleared value
+        A.frc4[k] = make_double4(fx, fy, fz, 0.0);
+      }
+      A.scores[k] = make_double2(s0, s1);
+      A.num_ucgstates[k] = 2;
+    }
   }
   if (err) atomicOr(errflag, err);
   if (EV) block_sum_store<8>(ev, s_red, evpart);
@@ -299,16 +377,17 @@ __global__ void k_selftest_div(const double b, const double y, const unsigned lo
   if (__builtin_bit_cast(unsigned long long, q1) != __builtin_bit_cast(unsigned long long, q2)) atomicAdd(mismatches, 1ull);
 }
 
-template <int STYLE, int TS>
+template <int STYLE, int TS, int SLOTS>
 hipError_t launch_style_ts(const PairDev &P, const AtomsDev &A, const ListDev &L, bool ev, double *evpart,
                            int *errflag, hipStream_t st, int nblocks)
 {
   const size_t tabbytes = P.fast ? ((size_t) (P.tablength * P.fast_stride + 1) / 2) * sizeof(double4)
                                  : (size_t) P.ntab * P.tablength * sizeof(double4);
-  const size_t ldsbytes = P.tab_in_lds ? tabbytes : 0;
+  const size_t ownbytes = P.stage_own ? (size_t) (PAIR_BLOCK / SLOTS) * (sizeof(double4) + sizeof(int)) : 0;
+  const size_t ldsbytes = (P.tab_in_lds ? tabbytes : 0) + ownbytes;
 #define UCG_LAUNCH(EVF, LDSF, FASTF)                                                                   \
   do {                                                                                                 \
-    auto kern = k_pair_gather<STYLE, TS, EVF, LDSF, FASTF>;                                            \
+    auto kern = k_pair_gather<STYLE, TS, EVF, LDSF, FASTF, SLOTS>;                                     \
     if (ldsbytes > 48 * 1024) {                                                                        \
       hipError_t e = hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                          (int) ldsbytes);                                              \
@@ -335,21 +414,32 @@ template <int STYLE>
 hipError_t launch_style(const PairDev &P, const AtomsDev &A, const ListDev &L, bool ev, double *evpart,
                         int *errflag, hipStream_t st, int nblocks)
 {
-  switch (P.tabstyle) {
-    case 0: return launch_style_ts<STYLE, 0>(P, A, L, ev, evpart, errflag, st, nblocks);
-    case 1: return launch_style_ts<STYLE, 1>(P, A, L, ev, evpart, errflag, st, nblocks);
-    default: return launch_style_ts<STYLE, 2>(P, A, L, ev, evpart, errflag, st, nblocks);
+#define UCG_TS(SL)                                                                                  \
+  switch (P.tabstyle) {                                                                             \
+    case 0: return launch_style_ts<STYLE, 0, SL>(P, A, L, ev, evpart, errflag, st, nblocks);       \
+    case 1: return launch_style_ts<STYLE, 1, SL>(P, A, L, ev, evpart, errflag, st, nblocks);       \
+    default: return launch_style_ts<STYLE, 2, SL>(P, A, L, ev, evpart, errflag, st, nblocks);      \
   }
+  switch (P.gather_slots) {
+    case 4: UCG_TS(4)
+    case 8: UCG_TS(8)
+    case 16: UCG_TS(16)
+    default: UCG_TS(1)
+  }
+#undef UCG_TS
 }
 
 }  // namespace
 
-int pair_gather_blocks(int nlocal) { return (nlocal + PAIR_BLOCK - 1) / PAIR_BLOCK; }
+int pair_gather_blocks(int nlocal, int slots)
+{
+  return (int) (((long long) nlocal * slots + PAIR_BLOCK - 1) / PAIR_BLOCK);
+}
 
 hipError_t launch_pair_gather(const PairDev &P, const AtomsDev &A, const ListDev &L, bool ev,
                               double *evpart, double *evout, int *errflag, hipStream_t st)
 {
-  const int nblocks = pair_gather_blocks(A.nlocal);
+  const int nblocks = pair_gather_blocks(A.nlocal, P.gather_slots);
   if (nblocks == 0) return hipSuccess;
   hipError_t e;
   if (P.style == 0) e = launch_style<0>(P, A, L, ev, evpart, errflag, st, nblocks);

@@ -108,9 +108,12 @@ typedef struct {
   double *cv_thresholds, *threshold_radii; /* [n_actual+1] */
   /* density-style compat switches; 0 = fixed, 1 = as shipped */
   int density_proximity_as_shipped;  /* #12 */
+  /* canonical gather order: number of interleaved slot accumulators per bead (power of two, <= ORC_MAX_SLOTS) */
+  int gather_slots;
   char errmsg[512];
 } orc_pair;
 
+#define ORC_MAX_SLOTS 64
 orc_pair *orc_pair_create(int style);
 void orc_pair_destroy(orc_pair *p);
 const char *orc_pair_error(const orc_pair *p);

@@ -100,6 +100,7 @@ def lib():
     L.orc_pair_dbl_array.argtypes = [C.c_void_p, C.c_char_p, c_int_p]
     L.orc_pair_dbl_array.restype = c_double_p
     L.orc_pair_set_compat.argtypes = [C.c_void_p, C.c_int]
+    L.orc_pair_set_gather_slots.argtypes = [C.c_void_p, C.c_int]
     L.orc_pair_density_compute.argtypes = [C.c_void_p, C.POINTER(Atoms), C.POINTER(NList), C.c_int, C.c_int,
                                            C.c_int, c_int_p, C.POINTER(Ev)]
     L.orc_force_clear.argtypes = [C.POINTER(Atoms), C.c_int]
@@ -196,6 +197,10 @@ class Pair:
 
     def init(self, ntypes=2, T=1.0, boltz=1.0):
         self._chk(self.L.orc_pair_init(self.h, ntypes, T, boltz))
+
+    def set_gather_slots(self, slots: int):
+        """canonical order: interleaved partial sums per bead (must equal the GPU kernel's lanes per bead)"""
+        self.L.orc_pair_set_gather_slots(self.h, int(slots))
 
     def set_compat(self, flags: int):
         self.L.orc_pair_set_compat(self.h, flags)

@@ -317,6 +317,12 @@ int orc_pair_compute_gather(orc_pair *p, orc_atoms *a, const orc_list *l, int ef
     const int *row = l->neigh + l->first[ii];
     const int n = l->numneigh[ii];
     const double xk = x[3 * k + 0], yk = x[3 * k + 1], zk = x[3 * k + 2];
+    /* slot accumulators: entry e of the row goes to slot e % S; slot 0 starts from the prologue
+       value, the others from 0; at the end slots are combined by the fixed tree
+       s[l] += s[l + S/2], ..., s[l] += s[l + 1] (what a group of S GPU lanes does) */
+    const int S = p->gather_slots > 0 ? p->gather_slots : 1;
+    double sfx[ORC_MAX_SLOTS] = {0}, sfy[ORC_MAX_SLOTS] = {0}, sfz[ORC_MAX_SLOTS] = {0};
+    double suf[ORC_MAX_SLOTS] = {0}, ss0[ORC_MAX_SLOTS] = {0}, ss1[ORC_MAX_SLOTS] = {0};
     double fx = 0.0, fy = 0.0, fz = 0.0, uf = 0.0, s0 = 0.0, s1 = 0.0;
     double e_acc = 0.0, v_acc[6] = {0, 0, 0, 0, 0, 0};
 
@@ -331,7 +337,10 @@ int orc_pair_compute_gather(orc_pair *p, orc_atoms *a, const orc_list *l, int ef
       s1 = -p->chem_pot[p->formal_from_actual[ktype * ms + 1]] / kT;
     }
 
+    sfx[0] = fx; sfy[0] = fy; sfz[0] = fz; suf[0] = uf; ss0[0] = s0; ss1[0] = s1;
     for (int e = 0; e < n; e++) {
+      const int slot = e % S;
+      fx = sfx[slot]; fy = sfy[slot]; fz = sfz[slot]; uf = suf[slot]; s0 = ss0[slot]; s1 = ss1[slot];
       int m = row[e];
       const int k_is_i = (m >> ORC_ORIENT_BIT) & 1;
       const double factor_lj = p->special_lj[(m >> ORC_SBBITS) & 3];
@@ -416,7 +425,14 @@ int orc_pair_compute_gather(orc_pair *p, orc_atoms *a, const orc_list *l, int ef
           v_acc[5] += 0.5 * (dely * delz * fpair);
         }
       }
+      sfx[slot] = fx; sfy[slot] = fy; sfz[slot] = fz; suf[slot] = uf; ss0[slot] = s0; ss1[slot] = s1;
     }
+    for (int off = S / 2; off > 0; off >>= 1)
+      for (int l = 0; l < off; l++) {
+        sfx[l] += sfx[l + off]; sfy[l] += sfy[l + off]; sfz[l] += sfz[l + off];
+        suf[l] += suf[l + off]; ss0[l] += ss0[l + off]; ss1[l] += ss1[l + off];
+      }
+    fx = sfx[0]; fy = sfy[0]; fz = sfz[0]; uf = suf[0]; s0 = ss0[0]; s1 = ss1[0];
     a->f[3 * k + 0] = fx;
     a->f[3 * k + 1] = fy;
     a->f[3 * k + 2] = fz;

@@ -74,6 +74,8 @@ void orc_pair_set_special_lj(orc_pair *p, const double *s)
   for (int i = 0; i < 4; i++) p->special_lj[i] = s[i];
 }
 
+void orc_pair_set_gather_slots(orc_pair *p, int slots) { p->gather_slots = slots; }
+
 void orc_pair_set_compat(orc_pair *p, int flags) { p->density_proximity_as_shipped = flags & 1; }
 
 void orc_fix_langevin_get(const orc_fix_langevin *fx, double *out)

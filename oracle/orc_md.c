@@ -11,9 +11,9 @@
  *
  *   rebuild: (1) wrap owned atoms into the box (Domain::pbc form);
  *            (2) bins of ~cutneigh/2 over the box extended by cutneigh;
- *            (3) sort owned atoms by (bin, tag);
+ *            (3) sort owned atoms by (Morton code of the bin, tag);
  *            (4) ghosts = every periodic image x + s*prd (s in {-1,0,1}^3 \ 0) that
- *                falls in the extended box, sorted by (bin, tag, shift code);
+ *                falls in the extended box, sorted by (Morton code of the bin, tag, shift code);
  *            (5) full list rows: stencil bins in (dz,dy,dx) ascending order, owned
  *                atoms of the bin then ghost atoms of the bin, entry kept when
  *                rsq < cutneigh^2; bit 29 = (tag_k <= tag_m); the row is then stably
@@ -162,7 +162,23 @@ static int coord2bin(const orc_sim *s, const double *x)
   return (ib[2] * s->nbin[1] + ib[1]) * s->nbin[0] + ib[0];
 }
 
-typedef struct { long long key; int idx; int code; } sortrec;
+/* Morton (Z-order) code of a bin: bits of (bx, by, bz) interleaved, 9 bits per dimension.
+   Sorting beads along this curve makes every run of ~1000 consecutive beads a compact blob,
+   so most neighbours of a workgroup's beads are the workgroup's own beads. */
+static long long morton_of_bin(const orc_sim *s, int b)
+{
+  const unsigned bx = (unsigned) (b % s->nbin[0]), by = (unsigned) ((b / s->nbin[0]) % s->nbin[1]);
+  const unsigned bz = (unsigned) (b / (s->nbin[0] * s->nbin[1]));
+  long long m = 0;
+  for (int i = 0; i < 9; i++) {
+    m |= (long long) ((bx >> i) & 1u) << (3 * i);
+    m |= (long long) ((by >> i) & 1u) << (3 * i + 1);
+    m |= (long long) ((bz >> i) & 1u) << (3 * i + 2);
+  }
+  return m;
+}
+
+typedef struct { long long key; int idx; int code; int bin; } sortrec;
 
 static int cmp_sortrec(const void *pa, const void *pb)
 {
@@ -191,7 +207,8 @@ static void sort_owned(orc_sim *s)
   const int n = a->nlocal;
   sortrec *r = (sortrec *) malloc(sizeof(sortrec) * (size_t) n);
   for (int i = 0; i < n; i++) {
-    r[i].key = ((long long) coord2bin(s, &a->x[3 * i]) << 32) | (unsigned int) a->tag[i];
+    r[i].bin = coord2bin(s, &a->x[3 * i]);
+    r[i].key = (morton_of_bin(s, r[i].bin) << 32) | (unsigned int) a->tag[i];
     r[i].idx = i;
     r[i].code = 0;
   }
@@ -209,7 +226,7 @@ static void sort_owned(orc_sim *s)
   permute_i(a->mask, r, n, ti);
   permute_i(a->ucgstate, r, n, ti);
   permute_i(a->num_ucgstates, r, n, ti);
-  for (int i = 0; i < n; i++) s->bin_of[i] = (int) (r[i].key >> 32);
+  for (int i = 0; i < n; i++) s->bin_of[i] = r[i].bin;
   free(td);
   free(ti);
   free(r);
@@ -243,7 +260,8 @@ static void build_ghosts(orc_sim *s)
             cap *= 2;
             r = (sortrec *) xrealloc(r, sizeof(sortrec) * (size_t) cap);
           }
-          r[ng].key = ((long long) coord2bin(s, xs) << 32) | (unsigned int) a->tag[i];
+          r[ng].bin = coord2bin(s, xs);
+          r[ng].key = (morton_of_bin(s, r[ng].bin) << 32) | (unsigned int) a->tag[i];
           r[ng].idx = i;
           r[ng].code = code;
           ng++;
@@ -260,7 +278,7 @@ static void build_ghosts(orc_sim *s)
     s->ghost_shift[3 * g + 0] = sx;
     s->ghost_shift[3 * g + 1] = sy;
     s->ghost_shift[3 * g + 2] = sz;
-    s->bin_of[n + g] = (int) (r[g].key >> 32);
+    s->bin_of[n + g] = r[g].bin;
     a->tag[n + g] = a->tag[src];
     a->type[n + g] = a->type[src];
     a->mask[n + g] = a->mask[src];
@@ -302,20 +320,23 @@ void orc_sim_reverse_comm(orc_sim *s)
 
 static void build_bins(orc_sim *s)
 {
+  /* beads of one bin are contiguous in both classes (sorted by the bin's Morton code, then tag);
+     record [start, end) per bin by boundary detection */
   const orc_atoms *a = &s->a;
   const int n = a->nlocal, ng = a->nghost;
-  s->binstart_owned = (int *) xrealloc(s->binstart_owned, sizeof(int) * ((size_t) s->nbins + 1));
-  s->binstart_ghost = (int *) xrealloc(s->binstart_ghost, sizeof(int) * ((size_t) s->nbins + 1));
-  /* both classes are already sorted by bin */
-  int p = 0;
-  for (int b = 0; b <= s->nbins; b++) {
-    while (p < n && s->bin_of[p] < b) p++;
-    s->binstart_owned[b] = p;
+  s->binstart_owned = (int *) xrealloc(s->binstart_owned, sizeof(int) * 2 * ((size_t) s->nbins + 1));
+  s->binstart_ghost = (int *) xrealloc(s->binstart_ghost, sizeof(int) * 2 * ((size_t) s->nbins + 1));
+  memset(s->binstart_owned, 0, sizeof(int) * 2 * ((size_t) s->nbins + 1));
+  memset(s->binstart_ghost, 0, sizeof(int) * 2 * ((size_t) s->nbins + 1));
+  for (int i = 0; i < n; i++) {
+    const int b = s->bin_of[i];
+    if (i == 0 || s->bin_of[i - 1] != b) s->binstart_owned[2 * b] = i;
+    if (i == n - 1 || s->bin_of[i + 1] != b) s->binstart_owned[2 * b + 1] = i + 1;
   }
-  p = 0;
-  for (int b = 0; b <= s->nbins; b++) {
-    while (p < ng && s->bin_of[n + p] < b) p++;
-    s->binstart_ghost[b] = n + p;
+  for (int g = 0; g < ng; g++) {
+    const int b = s->bin_of[n + g];
+    if (g == 0 || s->bin_of[n + g - 1] != b) s->binstart_ghost[2 * b] = n + g;
+    if (g == ng - 1 || s->bin_of[n + g + 1] != b) s->binstart_ghost[2 * b + 1] = n + g + 1;
   }
 }
 
@@ -372,7 +393,7 @@ static void build_lists(orc_sim *s)
             const int c = (cz * s->nbin[1] + cy) * s->nbin[0] + cx;
             for (int cls = 0; cls < 2; cls++) {
               const int *bs = cls ? s->binstart_ghost : s->binstart_owned;
-              for (int m = bs[c]; m < bs[c + 1]; m++) {
+              for (int m = bs[2 * c]; m < bs[2 * c + 1]; m++) {
                 if (m == k) continue;
                 const double delx = x[3 * k + 0] - x[3 * m + 0];
                 const double dely = x[3 * k + 1] - x[3 * m + 1];

@@ -291,3 +291,28 @@ def test_pair_bethe_density_parity(fresh_ctx, pkg, orc, tabstyle, tablength, ent
     assert sim0.compute_forces(1, 1) == 0
     R = sim0.arrays()
     assert np.abs(G["f"] - R["f"]).max() <= 1e-10 * np.abs(R["f"]).max()
+
+
+@pytest.mark.parametrize("slots", [1, 4, 8, 16])
+@pytest.mark.parametrize("style", ["table_ucgld", "table_ucg_bethe"])
+def test_gather_slots_define_the_canonical_order(fresh_ctx, pkg, orc, slots, style):
+    """lanes per bead of the gather kernel = interleaved partial sums + fixed tree in the oracle"""
+    ctx = fresh_ctx
+    ctx.set_option("gather_slots", slots)
+    deck = util.make_deck("spline", 1024)
+    beads = pkg.synth.make_beads(9, seed=slots)
+    beads.ucgp = np.clip(np.random.default_rng(3).uniform(size=beads.n), 1e-6, 1 - 1e-6)
+    op = util.oracle_pair(style, deck, slots=slots)
+    sim = util.oracle_sim(beads, op, mode=1)
+    sim.rebuild()
+    util.upload_from_oracle(ctx, sim, beads)
+    gp = util.gpu_pair(ctx, style, deck)
+    assert gp.gather_slots == slots
+    eng, vir = gp.compute(1, 1)
+    gp.check_errors()
+    G = ctx.atoms_download()
+    assert sim.compute_forces(1, 1) == 0
+    O = sim.arrays()
+    for k in ("f", "ucgforce", "scores"):
+        assert util.bits_equal(G[k], O[k]), k
+    assert abs(eng - sim.ev()["eng_vdwl"]) <= 1e-12 * abs(eng)

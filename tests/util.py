@@ -11,12 +11,16 @@ def make_deck(tabstyle="spline", tablength=1024, **kw):
     return pkg.synth.make_deck(tempfile.mkdtemp(prefix="ucgdeck_"), tabstyle, tablength, **kw)
 
 
-def oracle_pair(style, deck, T=1.0, ntypes=2):
+GATHER_SLOTS = 1  # the library's default lanes per bead (ucg_pair_gather_slots); part of the canonical order
+
+
+def oracle_pair(style, deck, T=1.0, ntypes=2, slots=GATHER_SLOTS):
     orc = load_oracle()
     p = orc.Pair(style)
     p.settings(deck.pair_style_args())
     p.coeff(deck.pair_coeff_args(), ntypes)
     p.init(ntypes, T, 1.0)
+    p.set_gather_slots(slots)
     return p
 
 
