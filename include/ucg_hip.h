@@ -237,6 +237,11 @@ int ucg_ranmars_fill(ucg_ctx *ctx, int seed, long long skip, int n, double *out)
  * step order of upstream Verlet::setup()/run() with the
  * whole state resident in HBM; used by bench.py and the trajectory-parity tests */
 int ucg_md_attach(ucg_ctx *ctx, ucg_pair *pair, int use_nve, int use_langevin, int use_ucgstate);
+/* the per-bead hooks that follow the pair kernel as ONE launch, in the reference's order:
+ * ucgld/langevin post_force -> ucgstate post_force -> nve/ucgld final_integrate [-> the next
+ * step's initial_integrate].  Bit-identical to calling the hooks one by one. */
+int ucg_md_post_fused(ucg_ctx *ctx, int use_langevin, int use_ucgstate, int use_nve, int fuse_next_initial,
+                      int groupbit, long long ntimestep, long long beginstep, long long endstep);
 int ucg_md_setup(ucg_ctx *ctx, long long nsteps_planned);
 int ucg_md_run(ucg_ctx *ctx, long long nsteps, int thermo_every);
 /* out[0..15]: ntimestep, nrebuild, nlocal, nghost, list entries, pair errors, ... */

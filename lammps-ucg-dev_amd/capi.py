@@ -46,7 +46,7 @@ SYMBOLS = [
     "ucg_decomp_set", "ucg_record_bytes", "ucg_exchange_count", "ucg_exchange_pack", "ucg_exchange_unpack",
     "ucg_border_count", "ucg_border_pack", "ucg_border_unpack", "ucg_halo_pack", "ucg_halo_unpack", "ucg_decide_local",
     "ucg_ranmars_fill",
-    "ucg_md_attach", "ucg_md_setup", "ucg_md_run", "ucg_md_info", "ucg_md_thermo",
+    "ucg_md_attach", "ucg_md_post_fused", "ucg_md_setup", "ucg_md_run", "ucg_md_info", "ucg_md_thermo",
     "ucg_profile_enable", "ucg_profile_read",
 ]
 
@@ -139,6 +139,7 @@ def lib():
     L.ucg_decide_local.argtypes = [vp, c_int_p, c_int_p]
     L.ucg_ranmars_fill.argtypes = [vp, C.c_int, C.c_longlong, C.c_int, c_double_p]
     L.ucg_md_attach.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int]
+    L.ucg_md_post_fused.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_longlong, C.c_longlong]
     L.ucg_md_setup.argtypes = [vp, C.c_longlong]
     L.ucg_md_run.argtypes = [vp, C.c_longlong, C.c_int]
     L.ucg_md_info.argtypes = [vp, c_ll_p]
@@ -384,6 +385,10 @@ class Context:
     # ---- resident driver
     def md_attach(self, pair, nve=True, langevin=False, ucgstate=False):
         self.chk(self.L.ucg_md_attach(self.h, pair.h, int(nve), int(langevin), int(ucgstate)))
+
+    def md_post_fused(self, langevin, ucgstate, nve, fuse_next, ntimestep, beginstep, endstep, groupbit=1):
+        self.chk(self.L.ucg_md_post_fused(self.h, int(langevin), int(ucgstate), int(nve), int(fuse_next), groupbit,
+                                          ntimestep, beginstep, endstep))
 
     def md_setup(self, nsteps):
         self.chk(self.L.ucg_md_setup(self.h, nsteps))

@@ -953,6 +953,41 @@ int ucg_fix_ucgstate_post_force(ucg_ctx *ctx)
   });
 }
 
+int ucg_md_post_fused(ucg_ctx *ctx, int use_langevin, int use_ucgstate, int use_nve, int fuse_next_initial, int groupbit,
+                      long long ntimestep, long long beginstep, long long endstep)
+{
+  if (!ctx) return UCG_ERR_INVALID;
+  return guarded(ctx, [&]() -> int {
+    LangevinDev Lg{};
+    if (use_langevin) {
+      FixLangevin &L = ctx->lang;
+      if (!L.active || !L.inited) return fail(ctx, UCG_ERR_INVALID, "fix ucgld/langevin not initialised");
+      double delta = (double) (ntimestep - beginstep);
+      if (delta != 0.0) delta /= (double) (endstep - beginstep);
+      L.t_target = L.t_start + delta * (L.t_stop - L.t_start);
+      L.tsqrt = std::sqrt(L.t_target);
+      rng_draw(ctx, L.rng, L.draws, ctx->nlocal);
+      Lg.gfactor1 = L.gf1.get();
+      Lg.gfactor2 = L.gf2.get();
+      Lg.tsqrt = L.tsqrt;
+      Lg.draws = L.draws.get();
+    }
+    const unsigned int *mc_draws = nullptr;
+    FixUcgState &S = ctx->ucgst;
+    if (use_ucgstate) {
+      if (!S.active) return fail(ctx, UCG_ERR_INVALID, "fix ucgstate not created");
+      if (S.mc_flag && !S.ld_flag) {
+        rng_draw(ctx, S.rng, S.draws, ctx->nlocal);
+        mc_draws = S.draws.get();
+      }
+    }
+    UCG_HIP(launch_post_fused(ctx->atoms_dev(), use_langevin != 0, Lg, use_ucgstate != 0, S.ld_flag, S.mc_flag, S.mc_rate,
+                              mc_draws, use_nve != 0, fuse_next_initial != 0, ctx->dt, 0.5 * ctx->dt * ctx->ftm2v,
+                              groupbit, ctx->stream));
+    return UCG_OK;
+  });
+}
+
 int ucg_ranmars_fill(ucg_ctx *ctx, int seed, long long skip, int n, double *out)
 {
   if (!ctx || !out || n < 0 || skip < 0) return UCG_ERR_INVALID;
@@ -1015,6 +1050,10 @@ int ucg_ctx_set_option(ucg_ctx *ctx, const char *name, int value)
   if (!ctx || !name) return UCG_ERR_INVALID;
   if (std::strcmp(name, "generic_kernels") == 0) {
     ctx->force_generic_kernels = value != 0;
+    return UCG_OK;
+  }
+  if (std::strcmp(name, "md_no_fuse") == 0) {
+    ctx->md_no_fuse = value != 0;
     return UCG_OK;
   }
   if (std::strcmp(name, "stage_own") == 0) {

@@ -122,6 +122,7 @@ struct ucg_ctx {
   // resident driver
   ucg_pair *md_pair = nullptr;
   bool md_nve = false, md_lang = false, md_ucgst = false;
+  bool md_no_fuse = false;  // option "md_no_fuse": keep initial_integrate a separate launch
   long long ntimestep = 0, beginstep = 0, endstep = 0;
   int groupbit = 1;
   long long nrebuild = 0, pair_error_steps = 0;

@@ -124,6 +124,103 @@ __global__ __launch_bounds__(FIX_BLOCK) void k_ucgstate(const AtomsDev A, const 
   }
 }
 
+// Resident-loop fusion of the per-bead hooks that follow the pair kernel, in the reference's
+// order: fix ucgld/langevin post_force -> fix ucgstate post_force -> fix nve/ucgld final_integrate
+// [-> the NEXT step's initial_integrate when nothing has to look at the state in between].
+// Each bead is independent and every statement is the one of the stand-alone kernels above,
+// in the same order, so the results are bit-identical; only the HBM passes are merged.
+template <bool LANG, bool UCGST, bool NVE, bool NEXT>
+__global__ __launch_bounds__(FIX_BLOCK) void k_post_fused(const AtomsDev A, const LangevinDev Lg, const int ld_flag,
+                                                         const int mc_flag, const double mc_rate,
+                                                         const unsigned int *mc_draws, const double dtv, const double dtf,
+                                                         const int groupbit)
+{
+  const int i = blockIdx.x * FIX_BLOCK + threadIdx.x;
+  if (i >= A.nlocal) return;
+  const bool ingroup = (A.mask[i] & groupbit) != 0;
+  int meta = A.meta[i];
+  double4 f = A.frc4[i];
+  double4 v = A.vel4[i];
+  double4 x;
+  bool x_loaded = false, x_dirty = false;
+  if (LANG && ingroup) {
+    const int t = UCG_META_TYPE(meta);
+    const double gamma1 = Lg.gfactor1[t];
+    const double gamma2 = Lg.gfactor2[t] * Lg.tsqrt;
+    const double uni = (double) Lg.draws[i] * 5.9604644775390625e-08;
+    const double fran = gamma2 * (uni - 0.5);
+    const double fdrag = gamma1 * v.w;
+    f.w += fdrag + fran;
+    A.frc4[i] = f;
+  }
+  if (UCGST) {
+    double ucgp;
+    bool meta_dirty = false;
+    if (A.num_ucgstates[i] == 1) {
+      if (!ld_flag) { meta &= 0xFFFF; meta_dirty = true; }
+      ucgp = 1.0;
+    } else {
+      const double2 s = A.scores[i];
+      const double e0 = ucg_exp((700.0 < s.x) ? 700.0 : s.x);
+      const double e1 = ucg_exp((700.0 < s.y) ? 700.0 : s.y);
+      double softmax_denom = 0.0;
+      softmax_denom += e0;
+      softmax_denom += e1;
+      const double r = e1 / softmax_denom;
+      const double lo = (1e-6 < r) ? r : 1e-6;
+      ucgp = (lo < 1.0 - 1e-6) ? lo : 1.0 - 1e-6;
+      if (!ld_flag) {
+        int state;
+        if (mc_flag) {
+          const int cur = UCG_META_STATE(meta);
+          double mc_factor;
+          if (cur == 0) mc_factor = ucgp / (1.0 - ucgp);
+          else mc_factor = (1.0 - ucgp) / ucgp;
+          mc_factor = ((1.0 < mc_factor) ? 1.0 : mc_factor) * mc_rate;
+          const double mc_rand = (double) mc_draws[i] * 5.9604644775390625e-08;
+          state = (mc_rand < mc_factor) ? 0 : 1;
+        } else {
+          state = (int) round(ucgp);
+        }
+        meta = (meta & 0xFFFF) | (state << 16);
+        meta_dirty = true;
+      }
+    }
+    A.ucgp[i] = ucgp;
+    if (!ld_flag) {
+      if (meta_dirty) A.meta[i] = meta;
+      x = A.pos4[i];
+      x_loaded = true;
+      x.w = ucgp;
+      x_dirty = true;
+    }
+  }
+  if (NVE && ingroup) {
+    const double dtfm = dtf / A.mass[UCG_META_TYPE(meta)];
+    const double dtflm = dtf / A.ucgml[i];
+    // final_integrate of this step
+    v.x += dtfm * f.x;
+    v.y += dtfm * f.y;
+    v.z += dtfm * f.z;
+    v.w += dtflm * f.w;
+    if (NEXT) {
+      // initial_integrate of the next step (same forces)
+      if (!x_loaded) x = A.pos4[i];
+      v.x += dtfm * f.x;
+      v.y += dtfm * f.y;
+      v.z += dtfm * f.z;
+      x.x += dtv * v.x;
+      x.y += dtv * v.y;
+      x.z += dtv * v.z;
+      v.w += dtflm * f.w;
+      x.w += dtv * v.w;
+      x_dirty = true;
+    }
+    A.vel4[i] = v;
+  }
+  if (x_dirty) A.pos4[i] = x;
+}
+
 __global__ __launch_bounds__(FIX_BLOCK) void k_force_clear(const AtomsDev A)
 {
   const int i = blockIdx.x * FIX_BLOCK + threadIdx.x;
@@ -237,6 +334,33 @@ hipError_t launch_ucgstate(const AtomsDev &A, int ld_flag, int mc_flag, double m
 {
   if (A.nlocal == 0) return hipSuccess;
   hipLaunchKernelGGL(k_ucgstate, dim3(nblk(A.nlocal)), dim3(FIX_BLOCK), 0, st, A, ld_flag, mc_flag, mc_rate, draws);
+  return hipGetLastError();
+}
+
+hipError_t launch_post_fused(const AtomsDev &A, bool lang, const LangevinDev &Lg, bool ucgst, int ld_flag, int mc_flag,
+                             double mc_rate, const unsigned int *mc_draws, bool nve, bool next, double dtv, double dtf,
+                             int groupbit, hipStream_t st)
+{
+  if (A.nlocal == 0) return hipSuccess;
+  const dim3 g(nblk(A.nlocal)), b(FIX_BLOCK);
+#define UCG_PF(L, U, N, X) \
+  hipLaunchKernelGGL((k_post_fused<L, U, N, X>), g, b, 0, st, A, Lg, ld_flag, mc_flag, mc_rate, mc_draws, dtv, dtf, groupbit)
+  const int sel = (lang ? 8 : 0) | (ucgst ? 4 : 0) | (nve ? 2 : 0) | ((nve && next) ? 1 : 0);
+  switch (sel) {
+    case 0: break;
+    case 2: UCG_PF(false, false, true, false); break;
+    case 3: UCG_PF(false, false, true, true); break;
+    case 4: UCG_PF(false, true, false, false); break;
+    case 6: UCG_PF(false, true, true, false); break;
+    case 7: UCG_PF(false, true, true, true); break;
+    case 8: UCG_PF(true, false, false, false); break;
+    case 10: UCG_PF(true, false, true, false); break;
+    case 11: UCG_PF(true, false, true, true); break;
+    case 12: UCG_PF(true, true, false, false); break;
+    case 14: UCG_PF(true, true, true, false); break;
+    default: UCG_PF(true, true, true, true); break;
+  }
+#undef UCG_PF
   return hipGetLastError();
 }
 

@@ -37,6 +37,9 @@ hipError_t launch_lambda_ke(const AtomsDev &A, int groupbit, double mvv2e, doubl
 hipError_t launch_ucgstate(const AtomsDev &A, int ld_flag, int mc_flag, double mc_rate,
                            const unsigned int *draws, hipStream_t st);
 hipError_t launch_force_clear(const AtomsDev &A, hipStream_t st);
+hipError_t launch_post_fused(const AtomsDev &A, bool lang, const LangevinDev &Lg, bool ucgst, int ld_flag, int mc_flag,
+                             double mc_rate, const unsigned int *mc_draws, bool nve, bool next, double dtv, double dtf,
+                             int groupbit, hipStream_t st);
 hipError_t launch_stream(const void *buf, size_t nbytes, int wide, int *sink, hipStream_t st);
 
 // ---- ucg_ranmars.hip : exact block-parallel RANMAR
@@ -48,7 +51,7 @@ struct RanMarsDev {
   const unsigned int *jump;  // [nchunks_max][97] coefficients of z^(p*CHUNK) mod P(z)
   int nchunks_max;
 };
-constexpr int RANMARS_CHUNK = 4096;
+constexpr int RANMARS_CHUNK = 1024;
 // host: RANMAR seeding (LAMMPS convention) -> 97 lag values oldest first after the warm-up draw
 void ranmars_seed_host(int seed, unsigned int *hist97, long long *count);
 // host: jump polynomials z^(p*CHUNK) mod (z^97 + z^64 - 1) over Z/2^24, p = 0..nchunks-1

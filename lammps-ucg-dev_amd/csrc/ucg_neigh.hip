@@ -976,19 +976,30 @@ int ucg_md_run(ucg_ctx *ctx, long long nsteps, int thermo_every)
 {
   if (!ctx || !ctx->md_pair) return UCG_ERR_INVALID;
   if (int rc = need_domain(ctx)) return rc;
+  // Per step (upstream Verlet::run):
+  //   initial_integrate | decide -> rebuild or halo refresh | pair | post_force fixes | final_integrate | end_of_step
+  // The per-bead hooks after the pair kernel run as ONE fused kernel; when no thermo output has to
+  // look at the state between two steps, that kernel also performs the next step's
+  // initial_integrate (same forces, same statement order: bit-identical, one HBM pass fewer).
+  bool initial_done = false;
   for (long long s = 0; s < nsteps; s++) {
     ctx->ntimestep++;
     const int ev = (thermo_every > 0 && (ctx->ntimestep % thermo_every == 0)) ? 1 : 0;
     int rc;
-    if (ctx->md_nve && (rc = ucg_fix_nve_initial(ctx, ctx->groupbit))) return rc;
+    if (ctx->md_nve && !initial_done && (rc = ucg_fix_nve_initial(ctx, ctx->groupbit))) return rc;
+    initial_done = false;
     rc = guarded(ctx, [&]() -> int {
       if (decide(ctx)) rebuild(ctx);
       else halo_forward(ctx);
       return UCG_OK;
     });
     if (rc) return rc;
-    if ((rc = forces_and_post_force(ctx, ev))) return rc;
-    if (ctx->md_nve && (rc = ucg_fix_nve_final(ctx, ctx->groupbit))) return rc;
+    if ((rc = ucg_pair_compute(ctx->md_pair, ev, ev, nullptr, nullptr))) return rc;
+    const bool fuse_next = ctx->md_nve && !ev && (s + 1 < nsteps) && !ctx->md_no_fuse;
+    if ((rc = ucg_md_post_fused(ctx, ctx->md_lang, ctx->md_ucgst, ctx->md_nve, fuse_next, ctx->groupbit, ctx->ntimestep,
+                                ctx->beginstep, ctx->endstep)))
+      return rc;
+    initial_done = fuse_next;
     // end_of_step: the lambda temperature is a diagnostic (compute_scalar); evaluated on thermo steps
     if (ev && ctx->md_lang && (rc = ucg_fix_langevin_end_of_step(ctx, ctx->groupbit, nullptr))) return rc;
   }

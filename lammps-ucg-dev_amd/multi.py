@@ -185,19 +185,25 @@ class RankSim:
     def run(self, nsteps, thermo_every=0):
         ctx = self.ctx
         last = None
-        for _ in range(nsteps):
+        initial_done = False
+        for s in range(nsteps):
             self.ntimestep += 1
             ev = 1 if (thermo_every > 0 and self.ntimestep % thermo_every == 0) else 0
-            ctx.fix_nve_ucgld_initial_integrate(self.groupbit)
+            if not initial_done:
+                ctx.fix_nve_ucgld_initial_integrate(self.groupbit)
             due, flag = ctx.decide_local()
             if due and self.tr.allreduce_max(flag):
                 self.rebuild()
             else:
                 self.halo_forward()
-            out = self._forces_and_post_force(ev)
+            out = self.pair.compute(ev, ev)
             if ev:
                 last = out
-            ctx.fix_nve_ucgld_final_integrate(self.groupbit)
+            # langevin -> ucgstate -> final_integrate (-> next initial_integrate) as one launch
+            fuse_next = (not ev) and (s + 1 < nsteps)
+            ctx.md_post_fused(self.use_langevin, self.use_ucgstate, True, fuse_next, self.ntimestep, self.beginstep,
+                              self.endstep, self.groupbit)
+            initial_done = fuse_next
         return last
 
 
