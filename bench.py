@@ -79,10 +79,14 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the UCG hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    force_multi = os.environ.get("UCG_FORCE_MULTI") == "1"  # exercise the decomposed path (RCCL transport) with 1 rank
+    if world > 1 or force_multi:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if "MASTER_ADDR" not in os.environ:
+            os.environ["MASTER_ADDR"] = "127.0.0.1"
+            os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     pkg = entry.load_package()
     capi, synth = pkg.capi, pkg.synth
@@ -90,7 +94,7 @@ def main():
     workdir = tempfile.mkdtemp(prefix=f"ucgbench_r{rank}_")
     deck = synth.make_deck(workdir, args.tabstyle, args.tablength)
 
-    if world > 1:
+    if world > 1 or force_multi:
         from lammps_ucg_dev_amd import multi  # spatial decomposition + RCCL halo
 
         result = multi.run_bench(args, deck, rank, world, local_rank, dist)

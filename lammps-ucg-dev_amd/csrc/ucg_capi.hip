@@ -365,7 +365,6 @@ int ucg_pair_init(ucg_pair *p, int ntypes, double T)
     D.dens_as_shipped = ctx->density_proximity_as_shipped ? 1 : 0;
     D.kT = M.kT;
     D.rkT = 1.0 / M.kT;
-    D.gather_slots = ctx->gather_slots;
     for (int i = 0; i < 4; i++) D.special_lj[i] = ctx->special_lj[i];
     {
       // FAST kernels: same arithmetic, less work (see ucg_pair.hip).  Conditions checked here.
@@ -396,7 +395,10 @@ int ucg_pair_init(ucg_pair *p, int ntypes, double T)
       const size_t bytes = fast ? ((nslots + 1) / 2) * sizeof(double4) : (size_t) ntab * tl * sizeof(double4);
       D.tab_in_lds = (bytes <= 152 * 1024) ? 1 : 0;
       // own-bead staging: 36 bytes per bead of the workgroup behind the tables, if the 160 KB allow it
-      const size_t own = (size_t) (1024 / ctx->gather_slots) * 36;
+      const int slots0 = ctx->gather_slots > 0 ? ctx->gather_slots : 1;
+      D.gather_slots = slots0;
+      p->tab_lds_bytes = bytes;
+      const size_t own = (size_t) (1024 / slots0) * 36;
       const size_t used = (D.tab_in_lds ? bytes : 0) + own + 6 * 1024;  // + the static model arrays
       D.stage_own = (ctx->stage_own && used <= 160 * 1024) ? 1 : 0;
     }
@@ -487,6 +489,14 @@ int ucg_pair_compute(ucg_pair *p, int eflag, int vflag, double *eng_vdwl, double
     if (!p->uploaded) return fail(ctx, UCG_ERR_INVALID, "ucg_pair_compute before ucg_pair_init");
     if (ctx->list_inum != ctx->nlocal) return fail(ctx, UCG_ERR_INVALID, "neighbour list does not match the resident atoms");
     const bool ev = (eflag || vflag);
+    if (ctx->gather_slots == 0) {
+      // auto: enough lanes per bead to give every CU at least ~2 workgroups (small per-GPU shares)
+      int slots = 1;
+      while (slots < 16 && (long long) ctx->nlocal * slots < 2LL * 256 * 1024) slots = (slots == 1) ? 4 : slots * 2;
+      p->dev.gather_slots = slots;
+      const size_t own = (size_t) (1024 / slots) * 36;
+      p->dev.stage_own = (ctx->stage_own && (p->dev.tab_in_lds ? p->tab_lds_bytes : 0) + own + 6 * 1024 <= 160 * 1024) ? 1 : 0;
+    }
     const int nb = pair_gather_blocks(ctx->nlocal, p->dev.gather_slots);
     if (ev) p->d_evpart.reserve((size_t) nb * 8 + 8);
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1061,8 +1071,8 @@ int ucg_ctx_set_option(ucg_ctx *ctx, const char *name, int value)
     return UCG_OK;
   }
   if (std::strcmp(name, "gather_slots") == 0) {
-    if (value != 1 && value != 4 && value != 8 && value != 16) {
-      ctx->err = "gather_slots must be 1, 4, 8 or 16";
+    if (value != 0 && value != 1 && value != 4 && value != 8 && value != 16) {
+      ctx->err = "gather_slots must be 0 (auto), 1, 4, 8 or 16";
       return UCG_ERR_INVALID;
     }
     ctx->gather_slots = value;

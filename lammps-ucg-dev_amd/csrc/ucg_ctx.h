@@ -154,6 +154,7 @@ struct ucg_pair {
   ucg::DevBuf<int> d_densflags;
   std::vector<int> tabmap;  // host table id -> device table id (or -1)
   std::string err;
+  size_t tab_lds_bytes = 0;
   double host_boltz = 1.0;  // used by host-only pairs (no context)
   explicit ucg_pair(int style) : model(style) {}
 };

@@ -30,7 +30,7 @@ struct Domain {
   int procgrid[3] = {1, 1, 1}, myloc[3] = {0, 0, 0}, me = 0, world = 1;
   double sublo[3], subhi[3];
   // multi-rank halo: send lists grouped by destination rank, fixed between rebuilds
-  DevBuf<int> send_src, send_code, ghost_perm, dest_of, slot_of, offsets;
+  DevBuf<int> send_src, send_code, ghost_perm, dest_of, slot_of, offsets, holes, movers;
   DevBuf<char> sendbuf;
   std::vector<long long> send_counts, recv_counts;
   long long nsend = 0;
@@ -633,6 +633,8 @@ __device__ __forceinline__ int own_loc(const DomainDev &D, int d, double x)
   return loc;
 }
 
+// owner rank of every bead after the wrap; only LEAVERS (dest != me) take a slot in their
+// destination's send block -- stayers never move through the transport
 __global__ __launch_bounds__(NB) void k_exchange_dest(const DomainDev D, int n, double4 *pos4, int *counts, int *dest_of,
                                                      int *slot_of)
 {
@@ -646,16 +648,16 @@ __global__ __launch_bounds__(NB) void k_exchange_dest(const DomainDev D, int n, 
   const int lx = own_loc(D, 0, p.x), ly = own_loc(D, 1, p.y), lz = own_loc(D, 2, p.z);
   const int r = lx + D.procgrid[0] * (ly + D.procgrid[1] * lz);
   dest_of[i] = r;
-  slot_of[i] = atomicAdd(&counts[r], 1);
+  slot_of[i] = (r != D.me) ? atomicAdd(&counts[r], 1) : -1;
 }
 
-__global__ __launch_bounds__(NB) void k_exchange_pack(int n, const int *dest_of, const int *slot_of, const int *offsets,
-                                                     const double4 *pos4, const double4 *vel4, const double *ucgp,
-                                                     const double *ucgml, const int *meta, const int *tag,
-                                                     const int *mask, const int *nstates, AtomRec *out)
+__global__ __launch_bounds__(NB) void k_exchange_pack(int n, int me, const int *dest_of, const int *slot_of,
+                                                     const int *offsets, const double4 *pos4, const double4 *vel4,
+                                                     const double *ucgp, const double *ucgml, const int *meta,
+                                                     const int *tag, const int *mask, const int *nstates, AtomRec *out)
 {
   const int i = blockIdx.x * NB + threadIdx.x;
-  if (i >= n) return;
+  if (i >= n || dest_of[i] == me) return;
   AtomRec r;
   const double4 p = pos4[i], v = vel4[i];
   r.x = p.x; r.y = p.y; r.z = p.z; r.w = p.w;
@@ -669,13 +671,44 @@ __global__ __launch_bounds__(NB) void k_exchange_pack(int n, const int *dest_of,
   out[offsets[dest_of[i]] + slot_of[i]] = r;
 }
 
-__global__ __launch_bounds__(NB) void k_exchange_unpack(int n, const AtomRec *in, double4 *pos4, double4 *vel4,
-                                                       double *ucgp, double *ucgml, int *meta, int *tag, int *mask,
-                                                       int *nstates)
+// hole filling: with L leavers, the stayers among the last L beads move into the leavers' slots
+// among the first n-L beads (as many of one as of the other); the order is irrelevant, the beads
+// are sorted afterwards
+__global__ __launch_bounds__(NB) void k_exchange_holes(int n, int nkeep, int me, const int *dest_of, int *cnt, int *holes,
+                                                      int *movers)
 {
   const int i = blockIdx.x * NB + threadIdx.x;
   if (i >= n) return;
-  const AtomRec r = in[i];
+  const bool leaver = dest_of[i] != me;
+  if (i < nkeep && leaver) holes[atomicAdd(&cnt[0], 1)] = i;
+  if (i >= nkeep && !leaver) movers[atomicAdd(&cnt[1], 1)] = i;
+}
+
+__global__ __launch_bounds__(NB) void k_exchange_move(int nmove, const int *holes, const int *movers, double4 *pos4,
+                                                     double4 *vel4, double *ucgp, double *ucgml, int *meta, int *tag,
+                                                     int *mask, int *nstates)
+{
+  const int j = blockIdx.x * NB + threadIdx.x;
+  if (j >= nmove) return;
+  const int dst = holes[j], src = movers[j];
+  pos4[dst] = pos4[src];
+  vel4[dst] = vel4[src];
+  ucgp[dst] = ucgp[src];
+  ucgml[dst] = ucgml[src];
+  meta[dst] = meta[src];
+  tag[dst] = tag[src];
+  mask[dst] = mask[src];
+  nstates[dst] = nstates[src];
+}
+
+__global__ __launch_bounds__(NB) void k_exchange_unpack(int nrecv, int base, const AtomRec *in, double4 *pos4,
+                                                       double4 *vel4, double *ucgp, double *ucgml, int *meta, int *tag,
+                                                       int *mask, int *nstates)
+{
+  const int j = blockIdx.x * NB + threadIdx.x;
+  if (j >= nrecv) return;
+  const AtomRec r = in[j];
+  const int i = base + j;
   pos4[i] = make_double4(r.x, r.y, r.z, r.w);
   vel4[i] = make_double4(r.vx, r.vy, r.vz, r.vw);
   ucgp[i] = r.ucgp;
@@ -687,47 +720,41 @@ __global__ __launch_bounds__(NB) void k_exchange_unpack(int n, const AtomRec *in
 }
 
 // every (bead, shift) image that falls in some rank's extended sub-box, except the bead itself
-// on its own rank.  FILL=false counts per destination; FILL=true writes the send lists.
+// on its own rank.  The (rank, shift) loop is uniform over the wavefront, so slots are handed out
+// with ONE atomic per wavefront and destination (ballot + prefix count).  FILL=false counts per
+// destination; FILL=true writes the send lists.
 template <bool FILL>
-__global__ __launch_bounds__(NB) void k_border_candidates(const DomainDev D, double cut, int n, const double4 *pos4,
-                                                         int *counts, const int *offsets, int *send_src,
-                                                         int *send_code)
+__global__ __launch_bounds__(NB) void k_border_candidates(const DomainDev D, double cut, int n, int world,
+                                                         const double4 *pos4, int *counts, const int *offsets,
+                                                         int *send_src, int *send_code)
 {
   const int i = blockIdx.x * NB + threadIdx.x;
-  if (i >= n) return;
-  const double4 p = pos4[i];
-  const double xyz[3] = {p.x, p.y, p.z};
-  for (int code = 0; code < 27; code++) {
-    const int s[3] = {code % 3 - 1, (code / 3) % 3 - 1, code / 9 - 1};
-    double xs[3];
-    int lo[3], hi[3];
-    bool any = true;
-    for (int d = 0; d < 3; d++) {
-      xs[d] = xyz[d] + s[d] * D.prd[d];
-      lo[d] = D.procgrid[d];
-      hi[d] = -1;
-      for (int l = 0; l < D.procgrid[d]; l++) {
-        if (xs[d] >= proc_bound(D, d, l) - cut && xs[d] < proc_bound(D, d, l + 1) + cut) {
-          if (l < lo[d]) lo[d] = l;
-          if (l > hi[d]) hi[d] = l;
-        }
+  const bool live = i < n;
+  double4 p = make_double4(0, 0, 0, 0);
+  if (live) p = pos4[i];
+  const int lane = threadIdx.x & 63;
+  for (int r = 0; r < world; r++) {
+    const int lx = r % D.procgrid[0], ly = (r / D.procgrid[0]) % D.procgrid[1], lz = r / (D.procgrid[0] * D.procgrid[1]);
+    const double xlo = proc_bound(D, 0, lx) - cut, xhi = proc_bound(D, 0, lx + 1) + cut;
+    const double ylo = proc_bound(D, 1, ly) - cut, yhi = proc_bound(D, 1, ly + 1) + cut;
+    const double zlo = proc_bound(D, 2, lz) - cut, zhi = proc_bound(D, 2, lz + 1) + cut;
+    for (int code = 0; code < 27; code++) {
+      if (r == D.me && code == 13) continue;
+      const int sx = code % 3 - 1, sy = (code / 3) % 3 - 1, sz = code / 9 - 1;
+      const double xs = p.x + sx * D.prd[0], ys = p.y + sy * D.prd[1], zs = p.z + sz * D.prd[2];
+      const bool hit = live && xs >= xlo && xs < xhi && ys >= ylo && ys < yhi && zs >= zlo && zs < zhi;
+      const unsigned long long mask = __ballot(hit);
+      if (mask == 0ull) continue;
+      const int leader = __ffsll((long long) mask) - 1;
+      int base = 0;
+      if (lane == leader) base = atomicAdd(&counts[r], __popcll(mask));
+      base = __shfl(base, leader, 64);
+      if (FILL && hit) {
+        const int slot = base + __popcll(mask & ((1ull << lane) - 1ull));
+        send_src[offsets[r] + slot] = i;
+        send_code[offsets[r] + slot] = code;
       }
-      if (hi[d] < 0) any = false;
     }
-    if (!any) continue;
-    for (int lz = lo[2]; lz <= hi[2]; lz++)
-      for (int ly = lo[1]; ly <= hi[1]; ly++)
-        for (int lx = lo[0]; lx <= hi[0]; lx++) {
-          // with procgrid <= 2 per dimension [lo,hi] is exactly the matching set; for larger grids
-          // re-test the box (ranges are contiguous because sub-boxes are ordered)
-          const int r = lx + D.procgrid[0] * (ly + D.procgrid[1] * lz);
-          if (r == D.me && code == 13) continue;
-          const int slot = atomicAdd(&counts[r], 1);
-          if (FILL) {
-            send_src[offsets[r] + slot] = i;
-            send_code[offsets[r] + slot] = code;
-          }
-        }
   }
 }
 
@@ -1078,7 +1105,7 @@ int ucg_exchange_count(ucg_ctx *ctx, long long *sendcounts)
     if (n > 0)
       hipLaunchKernelGGL(k_exchange_dest, dim3(nblk(n)), dim3(NB), 0, ctx->stream, dd, n, ctx->pos4.get(),
                          D.counter.get(), D.dest_of.get(), D.slot_of.get());
-    counts_to_host(ctx, D, sendcounts);
+    counts_to_host(ctx, D, sendcounts);  // leavers only: sendcounts[me] == 0
     for (int r = 0; r < D.world; r++) D.send_counts[(size_t) r] = sendcounts[r];
     return UCG_OK;
   });
@@ -1090,14 +1117,34 @@ int ucg_exchange_pack(ucg_ctx *ctx, void *sendbuf)
   if (int rc = need_domain(ctx)) return rc;
   return guarded(ctx, [&]() -> int {
     Domain &D = *ctx->dom;
+    hipStream_t st = ctx->stream;
     const int n = ctx->nlocal;
-    if (n == 0) return UCG_OK;
+    long long nleave = 0;
+    for (int r = 0; r < D.world; r++) nleave += D.send_counts[(size_t) r];
+    if (nleave == 0) return UCG_OK;
     if (!sendbuf) return UCG_ERR_INVALID;
     offsets_to_device(ctx, D, D.send_counts, D.offsets);
-    hipLaunchKernelGGL(k_exchange_pack, dim3(nblk(n)), dim3(NB), 0, ctx->stream, n, D.dest_of.get(), D.slot_of.get(),
+    hipLaunchKernelGGL(k_exchange_pack, dim3(nblk(n)), dim3(NB), 0, st, n, D.me, D.dest_of.get(), D.slot_of.get(),
                        D.offsets.get(), ctx->pos4.get(), ctx->vel4.get(), ctx->ucgp.get(), ctx->ucgml.get(),
                        ctx->meta.get(), ctx->tag.get(), ctx->mask.get(), ctx->num_ucgstates.get(), (AtomRec *) sendbuf);
+    // close the holes the leavers leave behind
+    const int nkeep = n - (int) nleave;
+    D.holes.reserve((size_t) nleave + 1);
+    D.movers.reserve((size_t) nleave + 1);
+    UCG_HIP(hipMemsetAsync(D.counter.get(), 0, 2 * sizeof(int), st));
+    hipLaunchKernelGGL(k_exchange_holes, dim3(nblk(n)), dim3(NB), 0, st, n, nkeep, D.me, D.dest_of.get(), D.counter.get(),
+                       D.holes.get(), D.movers.get());
+    // both lists have the same length (<= nleave); a launch over nleave lanes with a device-side bound
+    int cnt[2] = {0, 0};
+    UCG_HIP(hipMemcpyAsync(cnt, D.counter.get(), sizeof cnt, hipMemcpyDeviceToHost, st));
+    UCG_HIP(hipStreamSynchronize(st));
+    if (cnt[0] != cnt[1]) throw InputError{"internal error: bead migration holes and movers differ"};
+    if (cnt[0] > 0)
+      hipLaunchKernelGGL(k_exchange_move, dim3(nblk(cnt[0])), dim3(NB), 0, st, cnt[0], D.holes.get(), D.movers.get(),
+                         ctx->pos4.get(), ctx->vel4.get(), ctx->ucgp.get(), ctx->ucgml.get(), ctx->meta.get(),
+                         ctx->tag.get(), ctx->mask.get(), ctx->num_ucgstates.get());
     UCG_HIP(hipGetLastError());
+    ctx->nlocal = nkeep;
     return UCG_OK;
   });
 }
@@ -1107,19 +1154,21 @@ int ucg_exchange_unpack(ucg_ctx *ctx, const void *recvbuf, long long nrecv)
   if (!ctx || nrecv < 0 || (nrecv > 0 && !recvbuf)) return UCG_ERR_INVALID;
   if (int rc = need_domain(ctx)) return rc;
   return guarded(ctx, [&]() -> int {
-    const size_t n = (size_t) nrecv;
-    ctx->pos4.reserve(n);
-    ctx->vel4.reserve(n);
+    hipStream_t st = ctx->stream;
+    const int base = ctx->nlocal;
+    const size_t n = (size_t) base + (size_t) nrecv;
+    ctx->pos4.reserve(n, true, st);
+    ctx->vel4.reserve(n, true, st);
     ctx->frc4.reserve(n);
     ctx->scores.reserve(n);
-    ctx->ucgp.reserve(n);
-    ctx->ucgml.reserve(n);
-    ctx->meta.reserve(n);
-    ctx->tag.reserve(n);
-    ctx->mask.reserve(n);
-    ctx->num_ucgstates.reserve(n);
-    if (n)
-      hipLaunchKernelGGL(k_exchange_unpack, dim3(nblk((long long) n)), dim3(NB), 0, ctx->stream, (int) n,
+    ctx->ucgp.reserve(n, true, st);
+    ctx->ucgml.reserve(n, true, st);
+    ctx->meta.reserve(n, true, st);
+    ctx->tag.reserve(n, true, st);
+    ctx->mask.reserve(n, true, st);
+    ctx->num_ucgstates.reserve(n, true, st);
+    if (nrecv)
+      hipLaunchKernelGGL(k_exchange_unpack, dim3(nblk(nrecv)), dim3(NB), 0, st, (int) nrecv, base,
                          (const AtomRec *) recvbuf, ctx->pos4.get(), ctx->vel4.get(), ctx->ucgp.get(), ctx->ucgml.get(),
                          ctx->meta.get(), ctx->tag.get(), ctx->mask.get(), ctx->num_ucgstates.get());
     UCG_HIP(hipGetLastError());
@@ -1143,7 +1192,7 @@ int ucg_border_count(ucg_ctx *ctx, long long *sendcounts)
     const DomainDev dd = make_dev(D);
     UCG_HIP(hipMemsetAsync(D.counter.get(), 0, (size_t) D.world * sizeof(int), ctx->stream));
     if (n > 0)
-      hipLaunchKernelGGL(k_border_candidates<false>, dim3(nblk(n)), dim3(NB), 0, ctx->stream, dd, D.cutneigh, n,
+      hipLaunchKernelGGL(k_border_candidates<false>, dim3(nblk(n)), dim3(NB), 0, ctx->stream, dd, D.cutneigh, n, D.world,
                          ctx->pos4.get(), D.counter.get(), nullptr, nullptr, nullptr);
     counts_to_host(ctx, D, sendcounts);
     D.nsend = 0;
@@ -1169,7 +1218,7 @@ int ucg_border_pack(ucg_ctx *ctx, void *sendbuf)
     D.send_src.reserve((size_t) D.nsend);
     D.send_code.reserve((size_t) D.nsend);
     UCG_HIP(hipMemsetAsync(D.counter.get(), 0, (size_t) D.world * sizeof(int), ctx->stream));
-    hipLaunchKernelGGL(k_border_candidates<true>, dim3(nblk(n)), dim3(NB), 0, ctx->stream, dd, D.cutneigh, n,
+    hipLaunchKernelGGL(k_border_candidates<true>, dim3(nblk(n)), dim3(NB), 0, ctx->stream, dd, D.cutneigh, n, D.world,
                        ctx->pos4.get(), D.counter.get(), D.offsets.get(), D.send_src.get(), D.send_code.get());
     hipLaunchKernelGGL(k_halo_pack, dim3(nblk(D.nsend)), dim3(NB), 0, ctx->stream, dd, (int) D.nsend, D.send_src.get(),
                        D.send_code.get(), ctx->pos4.get(), ctx->ucgp.get(), ctx->meta.get(), ctx->tag.get(),

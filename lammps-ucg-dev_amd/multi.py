@@ -13,6 +13,8 @@ forwarding -- or, for tests on a single GPU shared by the ranks, ``gloo`` with h
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 
@@ -226,6 +228,8 @@ def run_bench(args, deck, rank, world, local_rank, dist):
     ctx.atoms_upload(n, 0, beads.ntypes, beads.x[sl], beads.v[sl], beads.type[sl], beads.tag[sl], beads.mask[sl],
                      beads.ucgstate[sl], beads.ucgl[sl], beads.ucgvl[sl], beads.ucgml[sl], beads.ucgp[sl], beads.mass)
     ctx.domain_set(beads.boxlo, beads.boxhi, 2.5, 0.3, every=10, delay=0, check=1)
+    # lanes per bead: 0 = chosen from the rank's bead count so that a 1/8 brick still fills 256 CUs
+    ctx.set_option("gather_slots", int(os.environ.get("UCG_GATHER_SLOTS", "0")))
     pair = capi.Pair(ctx, "table_ucgld")
     pair.settings(deck.pair_style_args())
     pair.coeff(deck.pair_coeff_args())
