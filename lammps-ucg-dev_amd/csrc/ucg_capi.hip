@@ -1066,6 +1066,10 @@ int ucg_ctx_set_option(ucg_ctx *ctx, const char *name, int value)
     ctx->md_no_fuse = value != 0;
     return UCG_OK;
   }
+  if (std::strcmp(name, "rows_untiled") == 0) {
+    ctx->rows_untiled = value != 0;
+    return UCG_OK;
+  }
   if (std::strcmp(name, "stage_own") == 0) {
     ctx->stage_own = value != 0;
     return UCG_OK;

@@ -96,6 +96,7 @@ struct ucg_ctx {
   bool stage_own = true;  // option "stage_own": LDS staging of the workgroup's own beads in k_pair_gather
   int gather_slots = 1;  // option "gather_slots": lanes per bead of the ucgld / bethe gather kernels
   bool force_generic_kernels = false;  // option "generic_kernels": never pick the FAST variants
+  bool rows_untiled = false;           // option "rows_untiled": build rows with the one-lane-per-bead kernels
 
   // atoms
   int nlocal = 0, nghost = 0, ntypes = 0;

@@ -49,7 +49,7 @@ struct Domain {
   DevBuf<char> cub_tmp;
   DevBuf<int> scratch;                 // discovery-order rows before the class partition
   DevBuf<unsigned long long> rowstat;  // [0] max row length, [1] total entries
-  int row_capacity = 0;
+  int row_capacity = 0, skin_capacity = 0;
 };
 
 struct DomainDev {
@@ -368,6 +368,232 @@ __global__ __launch_bounds__(NB) void k_rows_partition(int nlocal, const int *ro
   }
 }
 
+// Full-list rows, tiled builder (the default): one workgroup per Morton-aligned brick of 4x4x4
+// bins.  Beads are sorted by (Morton code of bin, tag), so a brick's beads are one contiguous
+// range; every candidate they can see lies in the 8x8x8 bins around the brick.  Those candidates
+// (position, index, tag: 32 B) are staged in LDS once, bin by bin (owned, then ghosts), and each
+// lane then walks its bead's stencil in the specified (dz, dy, dx) order over LDS -- twice: pass A
+// counts the four distance classes, pass B writes the entries straight to their class-partitioned
+// slots.  Same rows, bit for bit, as k_rows_discover + k_rows_partition (kept as the fallback for
+// stencils wider than 2 bins and for bricks whose candidates exceed the staging capacity).
+constexpr int TILE_B = 192;      // lanes per brick
+constexpr int TILE_R = 8;        // region edge in bins: 4 + 2 either side
+constexpr int TILE_CAP = 1536;   // staged candidates per brick (mean ~1100 at rho* = 0.8)
+
+struct __attribute__((aligned(16))) TileCand {
+  double x, y, z;
+  int idx, tag;
+};
+
+// One bead's walk over the staged candidates.  For a fixed (dz, dy) the stencil's bins are
+// consecutive in x, and so are their staged candidates: 25 contiguous LDS ranges per bead instead
+// of 125 bins.  Rows of bins (and their outermost bins in x) that lie farther than cutneigh from
+// the bead are skipped; candidates are fetched four at a time and committed in order: class 0
+// (inside the force cutoff) straight to the front of the bead's row, the skin classes -- tagged
+// in bits 30-31 -- to a side buffer from which the caller appends them class by class.
+__device__ __forceinline__ void tile_walk(const DomainDev &D, const double3 &binsize, const int k, const double4 &pk,
+                                          const int tk, const int bx, const int by, const int bz, const int r0x,
+                                          const int r0y, const int r0z, const int *s_start, const TileCand *s_cand,
+                                          int &c0, int &c1, int &c2, int &c3, int *neigh, int *skin, const int pitch,
+                                          const int cap, const int capskin)
+{
+  const double prune = D.cutneighsq * (1.0 + 1.0e-9) + 1.0e-12;
+  c0 = c1 = c2 = c3 = 0;
+  int ns = 0;
+  const int xlo_bin = max(bx - D.sten[0], 0), xhi_bin = min(bx + D.sten[0], D.nbin[0] - 1);
+  for (int dz = -D.sten[2]; dz <= D.sten[2]; dz++) {
+    const int cz = bz + dz;
+    if (cz < 0 || cz >= D.nbin[2]) continue;
+    const double zlo = D.bboxlo[2] + cz * binsize.z;
+    const double ez = pk.z < zlo ? zlo - pk.z : (pk.z > zlo + binsize.z ? pk.z - (zlo + binsize.z) : 0.0);
+    for (int dy = -D.sten[1]; dy <= D.sten[1]; dy++) {
+      const int cy = by + dy;
+      if (cy < 0 || cy >= D.nbin[1]) continue;
+      const double ylo = D.bboxlo[1] + cy * binsize.y;
+      const double ey = pk.y < ylo ? ylo - pk.y : (pk.y > ylo + binsize.y ? pk.y - (ylo + binsize.y) : 0.0);
+      const double d2 = ez * ez + ey * ey;
+      if (d2 > prune) continue;
+      int cx0 = xlo_bin, cx1 = xhi_bin;
+      while (cx0 < bx) {  // bins to the left of the bead's own
+        const double ex = pk.x - (D.bboxlo[0] + cx0 * binsize.x + binsize.x);
+        if (ex > 0.0 && d2 + ex * ex > prune) cx0++;
+        else break;
+      }
+      while (cx1 > bx) {  // and to the right
+        const double ex = (D.bboxlo[0] + cx1 * binsize.x) - pk.x;
+        if (ex > 0.0 && d2 + ex * ex > prune) cx1--;
+        else break;
+      }
+      const int rrow = ((cz - r0z) * TILE_R + (cy - r0y)) * TILE_R - r0x;
+      const int j0 = s_start[rrow + cx0], j1 = s_start[rrow + cx1 + 1];
+      for (int j = j0; j < j1; j += 4) {
+        TileCand pm[4];
+        double rsq[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          pm[u] = s_cand[min(j + u, j1 - 1)];
+          const double delx = pk.x - pm[u].x;
+          const double dely = pk.y - pm[u].y;
+          const double delz = pk.z - pm[u].z;
+          rsq[u] = delx * delx + dely * dely + delz * delz;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          // branch-free bookkeeping (plain integer adds and selects: keeps the counters in registers)
+          const bool ok = (j + u < j1) && (pm[u].idx != k) && (rsq[u] < D.cutneighsq);
+          const int in0 = rsq[u] < D.cls_sq[0], in1 = rsq[u] < D.cls_sq[1], in2 = rsq[u] < D.cls_sq[2];
+          const int cls = 3 - in0 - in1 - in2;
+          const int orient = (tk <= pm[u].tag) ? 1 : 0;
+          const int ent = pm[u].idx | (orient << UCG_ORIENT_BIT);
+          if (ok && in0 && c0 < cap) neigh[(size_t) c0 * pitch + k] = ent;
+          if (ok && !in0 && ns < capskin) skin[(size_t) ns * pitch + k] = ent | (cls << 30);
+          c0 += ok ? in0 : 0;
+          c1 += ok ? (in1 - in0) : 0;
+          c2 += ok ? (in2 - in1) : 0;
+          c3 += ok ? (1 - in2) : 0;
+          ns += (ok && !in0) ? 1 : 0;
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(TILE_B) void k_rows_tile(const DomainDev D, const double4 *pos4, const int *tag,
+                                                      const int *bin_of, const int4 *cells, int *rowcount, int *neigh,
+                                                      int *skin, int pitch, int cap, int capskin, const double3 binsize,
+                                                      const int3 nbrick, int *maxrow, unsigned long long *total,
+                                                      int *fallback, int *maxskin)
+{
+  __shared__ TileCand s_cand[TILE_CAP];
+  __shared__ int s_start[TILE_R * TILE_R * TILE_R + 1], s_cnt[TILE_R * TILE_R * TILE_R];
+  __shared__ int s_range[4];  // first bead, end bead, owned beads in the brick's bins, staged candidates
+  __shared__ int s_max[TILE_B / 64], s_maxs[TILE_B / 64];
+  __shared__ unsigned long long s_tot[TILE_B / 64];
+  constexpr int NREG = TILE_R * TILE_R * TILE_R;
+  const int t = threadIdx.x;
+  const int bxb = blockIdx.x % nbrick.x, byb = (blockIdx.x / nbrick.x) % nbrick.y, bzb = blockIdx.x / (nbrick.x * nbrick.y);
+  const int r0x = 4 * bxb - 2, r0y = 4 * byb - 2, r0z = 4 * bzb - 2;
+  if (t == 0) {
+    s_range[0] = 0x7FFFFFFF;
+    s_range[1] = 0;
+    s_range[2] = 0;
+  }
+  __syncthreads();
+  // the region's bins: candidate counts; the brick's own bins also give its bead range
+  for (int r = t; r < NREG; r += TILE_B) {
+    const int rx = r % TILE_R, ry = (r / TILE_R) % TILE_R, rz = r / (TILE_R * TILE_R);
+    const int cx = r0x + rx, cy = r0y + ry, cz = r0z + rz;
+    int n = 0;
+    if (cx >= 0 && cx < D.nbin[0] && cy >= 0 && cy < D.nbin[1] && cz >= 0 && cz < D.nbin[2]) {
+      const int4 cell = cells[(cz * D.nbin[1] + cy) * D.nbin[0] + cx];
+      n = (cell.y - cell.x) + (cell.w - cell.z);
+      if (rx >= 2 && rx < 6 && ry >= 2 && ry < 6 && rz >= 2 && rz < 6 && cell.y > cell.x) {
+        atomicMin(&s_range[0], cell.x);
+        atomicMax(&s_range[1], cell.y);
+        atomicAdd(&s_range[2], cell.y - cell.x);
+      }
+    }
+    s_cnt[r] = n;
+  }
+  __syncthreads();
+  const int kbeg = s_range[0], kend = s_range[1];
+  if (s_range[2] == 0) return;  // no owned bead in this brick
+  // exclusive scan of the 512 counts by the first wavefront: 8 bins per lane
+  if (t < 64) {
+    int loc[8], sum = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      loc[i] = sum;
+      sum += s_cnt[t * 8 + i];
+    }
+    int incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int v = __shfl_up(incl, off, 64);
+      if (t >= off) incl += v;
+    }
+    const int excl = incl - sum;
+#pragma unroll
+    for (int i = 0; i < 8; i++) s_start[t * 8 + i] = excl + loc[i];
+    if (t == 63) s_range[3] = s_start[TILE_R * TILE_R * TILE_R] = incl;
+  }
+  __syncthreads();
+  if (s_range[3] > TILE_CAP || s_range[2] != kend - kbeg) {
+    if (t == 0) atomicOr(fallback, 1);
+    return;
+  }
+  // stage the candidates bin by bin: owned (ascending tag), then ghosts (ascending tag, shift code)
+  for (int r = t; r < NREG; r += TILE_B) {
+    if (s_cnt[r] == 0) continue;
+    const int rx = r % TILE_R, ry = (r / TILE_R) % TILE_R, rz = r / (TILE_R * TILE_R);
+    const int4 cell = cells[((r0z + rz) * D.nbin[1] + (r0y + ry)) * D.nbin[0] + (r0x + rx)];
+    int j = s_start[r];
+    for (int m = cell.x; m < cell.y; m++, j++) {
+      const double4 p = pos4[m];
+      TileCand c;
+      c.x = p.x; c.y = p.y; c.z = p.z; c.idx = m; c.tag = tag[m];
+      s_cand[j] = c;
+    }
+    for (int m = cell.z; m < cell.w; m++, j++) {
+      const double4 p = pos4[m];
+      TileCand c;
+      c.x = p.x; c.y = p.y; c.z = p.z; c.idx = m; c.tag = tag[m];
+      s_cand[j] = c;
+    }
+  }
+  __syncthreads();
+  int mx = 0, mxs = 0;
+  unsigned long long tot = 0;
+  for (int k = kbeg + t; k < kend; k += TILE_B) {
+    const double4 pk = pos4[k];
+    const int tk = tag[k];
+    const int b = bin_of[k];
+    const int bx = b % D.nbin[0], by = (b / D.nbin[0]) % D.nbin[1], bz = b / (D.nbin[0] * D.nbin[1]);
+    int c0, c1, c2, c3;
+    tile_walk(D, binsize, k, pk, tk, bx, by, bz, r0x, r0y, r0z, s_start, s_cand, c0, c1, c2, c3, neigh, skin, pitch, cap,
+              capskin);
+    const int ns = c1 + c2 + c3, cnt = c0 + ns;
+    if (cnt <= cap && ns <= capskin) {
+      // append the skin classes behind class 0, each in discovery order (the lane reads back its own writes)
+      int p1 = c0, p2 = c0 + c1, p3 = c0 + c1 + c2;
+      for (int e = 0; e < ns; e++) {
+        const int ent = skin[(size_t) e * pitch + k];
+        const int cls = (ent >> 30) & 3;
+        const int slot = cls == 1 ? p1 : (cls == 2 ? p2 : p3);
+        p1 += cls == 1;
+        p2 += cls == 2;
+        p3 += cls == 3;
+        neigh[(size_t) slot * pitch + k] = ent & 0x3FFFFFFF;
+      }
+    }
+    mxs = max(mxs, ns);
+    rowcount[k] = cnt;
+    mx = max(mx, cnt);
+    tot += (unsigned long long) cnt;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    mx = max(mx, __shfl_down(mx, off, 64));
+    mxs = max(mxs, __shfl_down(mxs, off, 64));
+    tot += __shfl_down(tot, off, 64);
+  }
+  if ((t & 63) == 0) {
+    s_max[t >> 6] = mx;
+    s_maxs[t >> 6] = mxs;
+    s_tot[t >> 6] = tot;
+  }
+  __syncthreads();
+  if (t == 0) {
+    for (int w = 1; w < TILE_B / 64; w++) {
+      mx = max(mx, s_max[w]);
+      mxs = max(mxs, s_maxs[w]);
+      tot += s_tot[w];
+    }
+    atomicMax(maxrow, mx);
+    atomicMax(maxskin, mxs);
+    atomicAdd(total, tot);
+  }
+}
+
 __global__ __launch_bounds__(NB) void k_store_xhold(int n, const double4 *pos4, double4 *xhold)
 {
   const int i = blockIdx.x * NB + threadIdx.x;
@@ -525,38 +751,74 @@ void build_bins_and_rows(ucg_ctx *ctx)
   UCG_HIP(hipMemsetAsync(D.cells.get(), 0, nb1 * sizeof(int4), st));
   hipLaunchKernelGGL(k_cell_ranges, dim3(nblk(n)), dim3(NB), 0, st, n, 0, D.bin_of.get(), D.cells.get(), 0);
   if (ng > 0) hipLaunchKernelGGL(k_cell_ranges, dim3(nblk(ng)), dim3(NB), 0, st, ng, n, D.bin_of.get(), D.cells.get(), 1);
-  D.bpos.reserve((size_t) n + ng);
-  hipLaunchKernelGGL(k_builder_records, dim3(nblk((long long) n + ng)), dim3(NB), 0, st, n + ng, ctx->pos4.get(),
-                     ctx->tag.get(), D.bpos.get());
 
-  // (5) rows: discover into a scratch list (capacity from the previous build), then partition
+  // (5) rows.  Row capacity comes from the previous build; a row that does not fit is counted,
+  // not stored, and the build repeats with the measured maximum.
   const int pitch = ((n + 63) / 64) * 64;
   ctx->numneigh.reserve((size_t) pitch);
-  D.rowclass.reserve((size_t) pitch * 3);
   D.rowstat.reserve(4);
   const double3 bs = make_double3(D.binsize[0], D.binsize[1], D.binsize[2]);
   int cap = D.row_capacity > 0 ? D.row_capacity : 96;
   int maxrow = 0;
   long long total = 0;
-  for (int attempt = 0; attempt < 3; attempt++) {
-    D.scratch.reserve((size_t) pitch * (size_t) cap);
-    UCG_HIP(hipMemsetAsync(D.rowstat.get(), 0, 4 * sizeof(unsigned long long), st));
-    hipLaunchKernelGGL(k_rows_discover, dim3(nblk(n)), dim3(NB), 0, st, dd, n, D.bpos.get(), D.bin_of.get(),
-                       D.cells.get(), ctx->numneigh.get(), D.rowclass.get(), D.scratch.get(), pitch, cap, bs,
-                       (int *) D.rowstat.get(), D.rowstat.get() + 1);
-    unsigned long long stat[2];
-    UCG_HIP(hipMemcpyAsync(stat, D.rowstat.get(), sizeof stat, hipMemcpyDeviceToHost, st));
-    UCG_HIP(hipStreamSynchronize(st));
-    maxrow = (int) (stat[0] & 0xFFFFFFFFull);
-    total = (long long) stat[1];
-    if (maxrow <= cap) break;
-    cap = maxrow + 16;  // a row did not fit: grow and rediscover
+  bool tiled = !ctx->rows_untiled && D.sten[0] <= 2 && D.sten[1] <= 2 && D.sten[2] <= 2;
+  if (tiled) {
+    const int3 nbrick = make_int3((D.nbin[0] + 3) / 4, (D.nbin[1] + 3) / 4, (D.nbin[2] + 3) / 4);
+    const long long nblocks = (long long) nbrick.x * nbrick.y * nbrick.z;
+    int capskin = D.skin_capacity > 0 ? D.skin_capacity : 48;
+    for (int attempt = 0; attempt < 4; attempt++) {
+      ctx->neigh.reserve((size_t) pitch * (size_t) cap);
+      D.scratch.reserve((size_t) pitch * (size_t) capskin);
+      UCG_HIP(hipMemsetAsync(D.rowstat.get(), 0, 4 * sizeof(unsigned long long), st));
+      hipLaunchKernelGGL(k_rows_tile, dim3((unsigned) nblocks), dim3(TILE_B), 0, st, dd, ctx->pos4.get(), ctx->tag.get(),
+                         D.bin_of.get(), D.cells.get(), ctx->numneigh.get(), ctx->neigh.get(), D.scratch.get(), pitch, cap,
+                         capskin, bs, nbrick, (int *) D.rowstat.get(), D.rowstat.get() + 1, (int *) (D.rowstat.get() + 2),
+                         (int *) (D.rowstat.get() + 3));
+      unsigned long long stat[4];
+      UCG_HIP(hipMemcpyAsync(stat, D.rowstat.get(), sizeof stat, hipMemcpyDeviceToHost, st));
+      UCG_HIP(hipStreamSynchronize(st));
+      if (stat[2] & 0xFFFFFFFFull) {  // a brick exceeded the staging capacity: the untiled builder takes over
+        tiled = false;
+        break;
+      }
+      maxrow = (int) (stat[0] & 0xFFFFFFFFull);
+      total = (long long) stat[1];
+      const int maxskin = (int) (stat[3] & 0xFFFFFFFFull);
+      const bool fits = maxrow <= cap && maxskin <= capskin;
+      D.skin_capacity = maxskin + 8;
+      if (fits) break;
+      if (maxrow > cap) cap = maxrow + 16;
+      if (maxskin > capskin) capskin = maxskin + 8;
+      if (attempt == 3) throw InputError{"neighbour rows keep overflowing their buffers"};
+    }
+  }
+  if (!tiled) {
+    D.bpos.reserve((size_t) n + ng);
+    hipLaunchKernelGGL(k_builder_records, dim3(nblk((long long) n + ng)), dim3(NB), 0, st, n + ng, ctx->pos4.get(),
+                       ctx->tag.get(), D.bpos.get());
+    D.rowclass.reserve((size_t) pitch * 3);
+    for (int attempt = 0; attempt < 3; attempt++) {
+      D.scratch.reserve((size_t) pitch * (size_t) cap);
+      UCG_HIP(hipMemsetAsync(D.rowstat.get(), 0, 4 * sizeof(unsigned long long), st));
+      hipLaunchKernelGGL(k_rows_discover, dim3(nblk(n)), dim3(NB), 0, st, dd, n, D.bpos.get(), D.bin_of.get(),
+                         D.cells.get(), ctx->numneigh.get(), D.rowclass.get(), D.scratch.get(), pitch, cap, bs,
+                         (int *) D.rowstat.get(), D.rowstat.get() + 1);
+      unsigned long long stat[2];
+      UCG_HIP(hipMemcpyAsync(stat, D.rowstat.get(), sizeof stat, hipMemcpyDeviceToHost, st));
+      UCG_HIP(hipStreamSynchronize(st));
+      maxrow = (int) (stat[0] & 0xFFFFFFFFull);
+      total = (long long) stat[1];
+      if (maxrow <= cap) break;
+      cap = maxrow + 16;  // a row did not fit: grow and rediscover
+    }
+    if (maxrow <= cap) {
+      ctx->neigh.reserve((size_t) pitch * (size_t) (maxrow > 0 ? maxrow : 1));
+      hipLaunchKernelGGL(k_rows_partition, dim3(nblk(n)), dim3(NB), 0, st, n, ctx->numneigh.get(), D.rowclass.get(),
+                         D.scratch.get(), ctx->neigh.get(), pitch);
+    }
   }
   if (maxrow > cap) throw InputError{"neighbour rows keep overflowing their buffers"};
   D.row_capacity = maxrow + 16;
-  ctx->neigh.reserve((size_t) pitch * (size_t) (maxrow > 0 ? maxrow : 1));
-  hipLaunchKernelGGL(k_rows_partition, dim3(nblk(n)), dim3(NB), 0, st, n, ctx->numneigh.get(), D.rowclass.get(),
-                     D.scratch.get(), ctx->neigh.get(), pitch);
   ctx->list_inum = n;
   ctx->list_pitch = pitch;
   ctx->list_maxrow = maxrow;

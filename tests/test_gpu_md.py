@@ -14,8 +14,10 @@ def _setup_gpu(gpu_ctx, beads, dt, every):
     gpu_ctx.domain_set(beads.boxlo, beads.boxhi, 2.5, 0.3, every=every, delay=0, check=1)
 
 
-@pytest.mark.parametrize("ncell", [5, 8, 14])
-def test_device_rebuild_matches_spec(gpu_ctx, pkg, orc, ncell):
+@pytest.mark.parametrize("untiled", [0, 1])
+@pytest.mark.parametrize("ncell", [5, 8, 14, 21])
+def test_device_rebuild_matches_spec(gpu_ctx, pkg, orc, ncell, untiled):
+    """both row builders (brick-tiled over LDS, and one lane per bead) against the specification"""
     deck = util.make_deck("spline", 1024)
     beads = pkg.synth.make_beads(ncell, seed=ncell)
     # push a few beads out of the box so that the wrap is exercised
@@ -26,7 +28,11 @@ def test_device_rebuild_matches_spec(gpu_ctx, pkg, orc, ncell):
     sim = util.oracle_sim(beads, op, mode=1)
     sim.rebuild()
     _setup_gpu(gpu_ctx, beads, 0.002, 1)
-    gpu_ctx.neigh_rebuild()
+    gpu_ctx.set_option("rows_untiled", untiled)
+    try:
+        gpu_ctx.neigh_rebuild()
+    finally:
+        gpu_ctx.set_option("rows_untiled", 0)
     G = gpu_ctx.atoms_download(with_ghosts=True)
     O = sim.arrays(ghosts=True)
     assert (G["nlocal"], G["nghost"]) == (O["nlocal"], O["nghost"])

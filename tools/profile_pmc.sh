@@ -1,16 +1,18 @@
 #!/bin/bash
 # PMC passes for the pair kernel (run on the GPU box through gpurun; counters in their own
 # runs, never combined with trace domains other than --kernel-trace).
-# usage: tools/profile_pmc.sh <outdir> [extra bench args]
+# usage: [KERNEL=regex] [STEPS=n] tools/profile_pmc.sh <outdir> [extra bench args]
 set -u
 OUT=${1:-gpurun_out/pmc}
 shift || true
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python3 bench.py --steps 10 --warmup 5 --no-cpu-baseline $*"
+KERNEL=${KERNEL:-k_pair_gather}
+STEPS=${STEPS:-10}
+BENCH="python3 bench.py --steps $STEPS --warmup 5 --no-cpu-baseline $*"
 pass() {
   name=$1; shift
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --kernel-include-regex 'k_pair_gather' \
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc "$@" --kernel-include-regex "$KERNEL" \
      --output-format csv -d "$OUT/$name" -- $BENCH > "$OUT/$name.log" 2>&1
   echo "$name rc=$?" >> "$OUT/passes.log"
 }
