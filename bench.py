@@ -62,6 +62,10 @@ def main():
     ap.add_argument("--ncell", type=int, default=100, help="beads = ncell^3 (default 100 -> 1 M)")
     ap.add_argument("--tabstyle", default="spline")
     ap.add_argument("--tablength", type=int, default=1024)
+    ap.add_argument("--style", default="table_ucgld",
+                    choices=["table_ucgld", "table_ucg_bethe", "table_ucg_bethe_density"],
+                    help="pair style of the 1-GPU leg (default: the headline table_ucgld workload; the others are "
+                         "BASELINE.md configs 3 and 5 at 1 M beads, reported with their own algorithmic bytes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-ncell", type=int, default=64)
     ap.add_argument("--cpu-steps", type=int, default=10)
@@ -92,7 +96,15 @@ def main():
     capi, synth = pkg.capi, pkg.synth
     dt = 0.002
     workdir = tempfile.mkdtemp(prefix=f"ucgbench_r{rank}_")
-    deck = synth.make_deck(workdir, args.tabstyle, args.tablength)
+    if args.style == "table_ucg_bethe":
+        deck = synth.make_deck(workdir, args.tabstyle, args.tablength,
+                               extra_keywords=("method", "bethe", "pseudo", "yes", "prior", "ucgl"))
+    elif args.style == "table_ucg_bethe_density":
+        deck = synth.make_deck(workdir, args.tabstyle, args.tablength, density=(11.3, 1.5), extra11=0.05)
+    else:
+        deck = synth.make_deck(workdir, args.tabstyle, args.tablength)
+    if args.style != "table_ucgld" and (world > 1 or force_multi):
+        raise SystemExit("--style other than table_ucgld is a 1-GPU leg")
 
     if world > 1 or force_multi:
         from lammps_ucg_dev_amd import multi  # spatial decomposition + RCCL halo
@@ -107,13 +119,18 @@ def main():
             ctx.set_option("stage_own", int(os.environ["UCG_STAGE_OWN"]))
         ctx.upload_beads(beads)
         ctx.domain_set(beads.boxlo, beads.boxhi, 2.5, 0.3, every=10, delay=0, check=1)
-        pair = capi.Pair(ctx, "table_ucgld")
+        pair = capi.Pair(ctx, args.style)
         pair.settings(deck.pair_style_args())
         pair.coeff(deck.pair_coeff_args())
         pair.init(2, 1.0)
-        ctx.fix_ucgld_langevin(1.0, 1.0, 1.0, 48279)
-        ctx.fix_ucgstate("ld")
-        ctx.md_attach(pair, nve=True, langevin=True, ucgstate=True)
+        if args.style == "table_ucgld":
+            ctx.fix_ucgld_langevin(1.0, 1.0, 1.0, 48279)
+            ctx.fix_ucgstate("ld")
+        elif args.style == "table_ucg_bethe":
+            ctx.fix_ucgstate(None)  # state = round(ucgp), ucgl = ucgp (the prior of the next step)
+        else:
+            ctx.fix_ucgstate("mc", 9127, 0.01)
+        ctx.md_attach(pair, nve=True, langevin=args.style == "table_ucgld", ucgstate=True)
         ctx.md_setup(args.warmup + args.steps)
         ctx.md_run(args.warmup, 0)
         ctx.synchronize()
@@ -145,11 +162,17 @@ def main():
     # the roofline line is about ONE launch of the pair kernel: rank 0's share of the beads for N > 1
     e_half = result.get("rank0_list_entries", result["list_entries"]) / 2.0
     n_launch = result.get("rank0_nlocal", n)
-    alg_bytes = 44.0 * e_half + 96.0 * n_launch  # B_alg(ucgld) = 44 E + 96 N per launch
+    if args.style == "table_ucg_bethe_density":
+        alg_bytes = 116.0 * 2.0 * e_half + 220.0 * n_launch  # 116 E_full + 220 N (three passes)
+    else:
+        alg_bytes = 44.0 * e_half + 96.0 * n_launch  # B_alg(ucgld) = B_alg(bethe) = 44 E + 96 N
     pair_avg_s = (result["pair_ms"] / max(result["pair_launches"], 1)) * 1e-3
     achieved = alg_bytes / pair_avg_s / 1e9 if pair_avg_s > 0 else 0.0
     out = {
-        "metric": "timesteps/sec at 1M UCG beads (table_ucgld + nve/ucgld + ucgld/langevin + ucgstate ld)",
+        "metric": "timesteps/sec at 1M UCG beads (" + {
+            "table_ucgld": "table_ucgld + nve/ucgld + ucgld/langevin + ucgstate ld",
+            "table_ucg_bethe": "table_ucg_bethe method bethe pseudo yes prior ucgl + nve/ucgld + ucgstate",
+            "table_ucg_bethe_density": "table_ucg_bethe_density + nve/ucgld + ucgstate mc 9127 0.01"}[args.style] + ")",
         "value": steps_per_s,
         "unit": "timesteps/s",
         "n_gpus": world,
@@ -164,8 +187,11 @@ def main():
         "atom_steps_per_s": steps_per_s * n,
         "config": {
             "workload": f"{n} beads (sc lattice {args.ncell}^3 + jitter), rho*=0.8, rc=2.5, skin=0.3, dt=0.002, "
-                        f"pair_style table_ucgld {args.tabstyle} {args.tablength} (2-state, 4 LJ-like tables) + "
-                        "fix nve/ucgld + fix ucgld/langevin 1.0 1.0 1.0 48279 + fix ucgstate ld; "
+                        f"pair_style {args.style} {args.tabstyle} {args.tablength} (2-state, 4 LJ-like tables) + " + {
+                            "table_ucgld": "fix nve/ucgld + fix ucgld/langevin 1.0 1.0 1.0 48279 + fix ucgstate ld; ",
+                            "table_ucg_bethe": "method bethe pseudo yes prior ucgl + fix nve/ucgld + fix ucgstate; ",
+                            "table_ucg_bethe_density": "density 11.3 1.5 + fix nve/ucgld + fix ucgstate mc 9127 0.01; ",
+                        }[args.style] +
                         "neigh_modify every 10 check yes; rebuilds inside the timed region: "
                         f"{result['rebuilds']}",
             "beads": n,
@@ -176,7 +202,8 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "k_pair_gather<table_ucgld>",
+            "kernel": ("k_density_pass1+2+3" if args.style == "table_ucg_bethe_density"
+                       else f"k_pair_gather<{args.style}>"),
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -190,11 +217,12 @@ def main():
     # HBM traffic of the pair kernel: measured in separate rocprofv3 --pmc passes of this same
     # command (tools/profile_pmc.sh) and committed under profiles/; valid for the default workload
     tfile = os.path.join(ROOT, "profiles", "r01_pair_traffic.json")
-    if world == 1 and args.ncell == 100 and args.tabstyle == "spline" and args.tablength == 1024 and os.path.exists(tfile):
+    if (world == 1 and args.style == "table_ucgld" and args.ncell == 100 and args.tabstyle == "spline"
+            and args.tablength == 1024 and os.path.exists(tfile)):
         with open(tfile) as fh:
             out["roofline"]["traffic"] = json.load(fh)["traffic_bytes_per_launch"]
         out["roofline"]["traffic_note"] = "HBM bytes per launch from rocprofv3 PMC (FETCH_SIZE x2 per the gfx950 calibration + WRITE_SIZE), profiles/r01_pair_traffic.json"
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and args.style == "table_ucgld":
         cb = cpu_baseline(pkg, deck, args.cpu_ncell, args.cpu_steps, dt)
         out["cpu_baseline"] = {
             "value": cb["atom_steps_per_s"] / n,

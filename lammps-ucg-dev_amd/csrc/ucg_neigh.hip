@@ -376,9 +376,14 @@ __global__ __launch_bounds__(NB) void k_rows_partition(int nlocal, const int *ro
 // counts the four distance classes, pass B writes the entries straight to their class-partitioned
 // slots.  Same rows, bit for bit, as k_rows_discover + k_rows_partition (kept as the fallback for
 // stencils wider than 2 bins and for bricks whose candidates exceed the staging capacity).
-constexpr int TILE_B = 192;      // lanes per brick
-constexpr int TILE_R = 8;        // region edge in bins: 4 + 2 either side
+constexpr int TILE_B = 192;      // lanes per brick (mean ~145 beads at rho* = 0.8)
+constexpr int TILE_BX = 4;       // brick = 4 x 4 x 4 bins = the low 6 bits of the Morton code (8 x 4 x 4 with
+                                 // 320 lanes measured slower: one workgroup per CU instead of three)
+constexpr int TILE_RX = TILE_BX + 4, TILE_R = 8;  // region in bins: the brick + 2 either side
+constexpr int TILE_NREG = TILE_RX * TILE_R * TILE_R;
+constexpr int TILE_PER_LANE = TILE_NREG / 64;     // bins per lane of the scanning wavefront
 constexpr int TILE_CAP = 1536;   // staged candidates per brick (mean ~1100 at rho* = 0.8)
+static_assert(TILE_NREG % 64 == 0, "region bins are scanned by one wavefront");
 
 struct __attribute__((aligned(16))) TileCand {
   double x, y, z;
@@ -424,7 +429,7 @@ __device__ __forceinline__ void tile_walk(const DomainDev &D, const double3 &bin
         if (ex > 0.0 && d2 + ex * ex > prune) cx1--;
         else break;
       }
-      const int rrow = ((cz - r0z) * TILE_R + (cy - r0y)) * TILE_R - r0x;
+      const int rrow = ((cz - r0z) * TILE_R + (cy - r0y)) * TILE_RX - r0x;
       const int j0 = s_start[rrow + cx0], j1 = s_start[rrow + cx1 + 1];
       for (int j = j0; j < j1; j += 4) {
         TileCand pm[4];
@@ -465,14 +470,14 @@ __global__ __launch_bounds__(TILE_B) void k_rows_tile(const DomainDev D, const d
                                                       int *fallback, int *maxskin)
 {
   __shared__ TileCand s_cand[TILE_CAP];
-  __shared__ int s_start[TILE_R * TILE_R * TILE_R + 1], s_cnt[TILE_R * TILE_R * TILE_R];
+  __shared__ int s_start[TILE_NREG + 1], s_cnt[TILE_NREG];
   __shared__ int s_range[4];  // first bead, end bead, owned beads in the brick's bins, staged candidates
   __shared__ int s_max[TILE_B / 64], s_maxs[TILE_B / 64];
   __shared__ unsigned long long s_tot[TILE_B / 64];
-  constexpr int NREG = TILE_R * TILE_R * TILE_R;
+  constexpr int NREG = TILE_NREG;
   const int t = threadIdx.x;
   const int bxb = blockIdx.x % nbrick.x, byb = (blockIdx.x / nbrick.x) % nbrick.y, bzb = blockIdx.x / (nbrick.x * nbrick.y);
-  const int r0x = 4 * bxb - 2, r0y = 4 * byb - 2, r0z = 4 * bzb - 2;
+  const int r0x = TILE_BX * bxb - 2, r0y = 4 * byb - 2, r0z = 4 * bzb - 2;
   if (t == 0) {
     s_range[0] = 0x7FFFFFFF;
     s_range[1] = 0;
@@ -481,13 +486,13 @@ __global__ __launch_bounds__(TILE_B) void k_rows_tile(const DomainDev D, const d
   __syncthreads();
   // the region's bins: candidate counts; the brick's own bins also give its bead range
   for (int r = t; r < NREG; r += TILE_B) {
-    const int rx = r % TILE_R, ry = (r / TILE_R) % TILE_R, rz = r / (TILE_R * TILE_R);
+    const int rx = r % TILE_RX, ry = (r / TILE_RX) % TILE_R, rz = r / (TILE_RX * TILE_R);
     const int cx = r0x + rx, cy = r0y + ry, cz = r0z + rz;
     int n = 0;
     if (cx >= 0 && cx < D.nbin[0] && cy >= 0 && cy < D.nbin[1] && cz >= 0 && cz < D.nbin[2]) {
       const int4 cell = cells[(cz * D.nbin[1] + cy) * D.nbin[0] + cx];
       n = (cell.y - cell.x) + (cell.w - cell.z);
-      if (rx >= 2 && rx < 6 && ry >= 2 && ry < 6 && rz >= 2 && rz < 6 && cell.y > cell.x) {
+      if (rx >= 2 && rx < 2 + TILE_BX && ry >= 2 && ry < 6 && rz >= 2 && rz < 6 && cell.y > cell.x) {
         atomicMin(&s_range[0], cell.x);
         atomicMax(&s_range[1], cell.y);
         atomicAdd(&s_range[2], cell.y - cell.x);
@@ -498,13 +503,13 @@ __global__ __launch_bounds__(TILE_B) void k_rows_tile(const DomainDev D, const d
   __syncthreads();
   const int kbeg = s_range[0], kend = s_range[1];
   if (s_range[2] == 0) return;  // no owned bead in this brick
-  // exclusive scan of the 512 counts by the first wavefront: 8 bins per lane
+  // exclusive scan of the region's counts by the first wavefront
   if (t < 64) {
-    int loc[8], sum = 0;
+    int loc[TILE_PER_LANE], sum = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < TILE_PER_LANE; i++) {
       loc[i] = sum;
-      sum += s_cnt[t * 8 + i];
+      sum += s_cnt[t * TILE_PER_LANE + i];
     }
     int incl = sum;
 #pragma unroll
@@ -514,8 +519,8 @@ __global__ __launch_bounds__(TILE_B) void k_rows_tile(const DomainDev D, const d
     }
     const int excl = incl - sum;
 #pragma unroll
-    for (int i = 0; i < 8; i++) s_start[t * 8 + i] = excl + loc[i];
-    if (t == 63) s_range[3] = s_start[TILE_R * TILE_R * TILE_R] = incl;
+    for (int i = 0; i < TILE_PER_LANE; i++) s_start[t * TILE_PER_LANE + i] = excl + loc[i];
+    if (t == 63) s_range[3] = s_start[TILE_NREG] = incl;
   }
   __syncthreads();
   if (s_range[3] > TILE_CAP || s_range[2] != kend - kbeg) {
@@ -525,7 +530,7 @@ __global__ __launch_bounds__(TILE_B) void k_rows_tile(const DomainDev D, const d
   // stage the candidates bin by bin: owned (ascending tag), then ghosts (ascending tag, shift code)
   for (int r = t; r < NREG; r += TILE_B) {
     if (s_cnt[r] == 0) continue;
-    const int rx = r % TILE_R, ry = (r / TILE_R) % TILE_R, rz = r / (TILE_R * TILE_R);
+    const int rx = r % TILE_RX, ry = (r / TILE_RX) % TILE_R, rz = r / (TILE_RX * TILE_R);
     const int4 cell = cells[((r0z + rz) * D.nbin[1] + (r0y + ry)) * D.nbin[0] + (r0x + rx)];
     int j = s_start[r];
     for (int m = cell.x; m < cell.y; m++, j++) {
@@ -763,7 +768,7 @@ void build_bins_and_rows(ucg_ctx *ctx)
   long long total = 0;
   bool tiled = !ctx->rows_untiled && D.sten[0] <= 2 && D.sten[1] <= 2 && D.sten[2] <= 2;
   if (tiled) {
-    const int3 nbrick = make_int3((D.nbin[0] + 3) / 4, (D.nbin[1] + 3) / 4, (D.nbin[2] + 3) / 4);
+    const int3 nbrick = make_int3((D.nbin[0] + TILE_BX - 1) / TILE_BX, (D.nbin[1] + 3) / 4, (D.nbin[2] + 3) / 4);
     const long long nblocks = (long long) nbrick.x * nbrick.y * nbrick.z;
     int capskin = D.skin_capacity > 0 ? D.skin_capacity : 48;
     for (int attempt = 0; attempt < 4; attempt++) {

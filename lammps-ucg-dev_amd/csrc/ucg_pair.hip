@@ -136,6 +136,22 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
       }
     }
 
+    // FAST Bethe rows: the full-SCE scores divide by the ROW bead's priors (as "i" or as "j"), so
+    // their reciprocals are formed once per row and each division becomes an exact
+    // reciprocal-multiply with two FMA residual steps (div_by_const); denominators outside its
+    // proven range keep the hardware division.
+    double rk_i0 = 0.0, rk_i1 = 0.0, rk_j0 = 0.0, rk_j1 = 0.0;
+    bool rk_ok = false;
+    if (STYLE == 1 && FAST) {
+      rk_ok = !k_first_chempot && recip_ok(pk_as_i0) && recip_ok(pk_as_i1) && recip_ok(pk_as_j0) && recip_ok(pk_as_j1);
+      if (rk_ok) {
+        rk_i0 = 1.0 / pk_as_i0;
+        rk_i1 = 1.0 / pk_as_i1;
+        rk_j0 = 1.0 / pk_as_j0;
+        rk_j1 = 1.0 / pk_as_j1;
+      }
+    }
+
     // one actual type (the usual UCG deck): cutoff and table ids are the same for every pair
     const bool onetype = (P.n_actual == 1);
     const double cut11 = s_cutsq[na1 + 1];
@@ -269,9 +285,10 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
           const double pj0 = k_is_i ? pm_as_j0 : kj0, pj1 = k_is_i ? pm_as_j1 : kj1;
 
           double Jij = q.u11 + q.u00 - cu01 - cu10;
-          if (Jij / kT < -709.0) Jij = -700.0 * kT;
-          const double bij = ucg_exp(-Jij / kT);
-          const double aij = ucg_expm1(-Jij / kT);
+          if ((FAST ? div_by_const(Jij, kT, rkT) : Jij / kT) < -709.0) Jij = -700.0 * kT;
+          const double mJkT = FAST ? div_by_const(-Jij, kT, rkT) : -Jij / kT;
+          const double bij = ucg_exp(mJkT);
+          const double aij = ucg_expm1(mJkT);
           const double Qij = (pi1 + pj1) * aij + 1.;
           double Dij = Qij * Qij - 4. * aij * bij * pi1 * pj1;
           Dij = (Dij > 0.0) ? Dij : 0.0;
@@ -288,7 +305,21 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
           const double pij01 = pj1 - pij11;
           if (P.pseudo_flag == 1) {
             // full-SCE scores exactly as shipped (:583-601)
-            if (k_is_i) {
+            if (FAST && rk_ok) {
+              // same quotients; the row bead's priors are pi when it is "i" and pj when it is "j"
+              const double d0 = k_is_i ? pi0 : pj0, d1 = k_is_i ? pi1 : pj1;
+              const double r0 = k_is_i ? rk_i0 : rk_j0, r1 = k_is_i ? rk_i1 : rk_j1;
+              const double n01 = k_is_i ? pij01 : pij10, n10 = k_is_i ? pij10 : pij01;
+              const double qa = div_by_const(pij00, d0, r0), qb = div_by_const(n01, d0, r0);
+              const double qc = div_by_const(n10, d1, r1), qd = div_by_const(pij11, d1, r1);
+              if (k_is_i) {
+                s0 -= div_by_const(qa * q.u00 + qc * cu01, kT, rkT);
+                s1 -= div_by_const(qb * cu10 + qd * q.u11, kT, rkT);
+              } else {
+                s0 -= div_by_const(qa * q.u00 + qb * cu01, kT, rkT);
+                s1 -= div_by_const(qc * cu10 + qd * q.u11, kT, rkT);
+              }
+            } else if (k_is_i) {
               const double pj0i0 = pij00 / pi0, pj0i1 = pij01 / pi0, pj1i0 = pij10 / pi1, pj1i1 = pij11 / pi1;
               s0 -= (pj0i0 * q.u00 + pj1i0 * cu01) / kT;
               s1 -= (pj0i1 * cu10 + pj1i1 * q.u11) / kT;

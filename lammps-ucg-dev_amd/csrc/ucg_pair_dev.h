@@ -18,15 +18,25 @@ struct Quad {
 };
 
 // correctly rounded a / b from y = RN(1/b): q0 = RN(a*y), then two FMA residual steps.
-// Exact for normal-range operands when b's significand is not all ones (checked on the host).
+// Exact when b's significand is not all ones and neither the quotient nor the residuals leave the
+// normal range: b within 2^+-200 (recip_ok / the host check of kT) and |a| within 1e+-200; anything
+// else takes the hardware division.
 __device__ __forceinline__ double div_by_const(const double a, const double b, const double y)
 {
-  if (!(fabs(a) > 1.0e-280 && fabs(a) < 1.0e280)) return a / b;
+  if (!(fabs(a) > 1.0e-200 && fabs(a) < 1.0e200)) return a / b;
   double q = a * y;
   double r = fma(-b, q, a);
   q = fma(r, y, q);
   r = fma(-b, q, a);
   return fma(r, y, q);
+}
+
+// is b a denominator div_by_const is exact for?  (normal, mid-range exponent, significand not all ones)
+__device__ __forceinline__ bool recip_ok(const double b)
+{
+  const unsigned long long kb = (unsigned long long) __double_as_longlong(b);
+  const unsigned long long mant = kb & 0xFFFFFFFFFFFFFull, ex = (kb >> 52) & 0x7FF;
+  return mant != 0xFFFFFFFFFFFFFull && ex >= 1023 - 200 && ex <= 1023 + 200;
 }
 
 // knot index of rsq on one table's r^2 grid (the shared part of UCG/pair_table_ucgld.cpp:436-459)

@@ -23,6 +23,7 @@ deck = synth.make_deck(tempfile.mkdtemp(), "spline", 1024)
 ctx = capi.Context(0, dt=0.002)
 ctx.upload_beads(beads)
 ctx.domain_set(beads.boxlo, beads.boxhi, 2.5, 0.3, every=10, delay=0, check=1)
+ctx.set_option("gather_slots", 0)
 pair = capi.Pair(ctx, "table_ucgld")
 pair.settings(deck.pair_style_args()); pair.coeff(deck.pair_coeff_args()); pair.init(2, 1.0)
 ctx.fix_ucgld_langevin(1.0, 1.0, 1.0, 48279)
@@ -73,6 +74,28 @@ for k, v in reb.items():
 print("beads", beads.n, "wall per step (sync after each phase): %.1f us" % ((time.perf_counter() - t_all) / N * 1e6))
 for k, v in acc.items():
     print(f"  {k:12s} {v / N * 1e6:9.1f} us/step")
+# host cost of each call alone (no sync inside the step; one sync per step keeps the queue empty)
+host = {}
+def ht(name, fn):
+    t0 = time.perf_counter(); r = fn(); host[name] = host.get(name, 0.0) + time.perf_counter() - t0; return r
+nh = 0
+for s in range(N):
+    sim.ntimestep += 1
+    ht("initial", lambda: ctx.fix_nve_ucgld_initial_integrate(1))
+    due, flag = ht("decide", lambda: ctx.decide_local())
+    if due and tr.allreduce_max(flag):
+        sim.rebuild()
+    else:
+        nh += 1
+        ht("halo_pack", lambda: ctx.halo_pack(sim._halo_send.data_ptr()))
+        rb = ht("alltoall", lambda: tr.alltoall_bytes(sim._halo_send, sim.halo_send_counts, sim.halo_recv_counts, sim.halo_bytes))
+        ht("halo_unpack", lambda: ctx.halo_unpack(rb.data_ptr()))
+    ht("pair", lambda: pair.compute(0, 0))
+    ht("post_fused", lambda: ctx.md_post_fused(True, True, True, False, sim.ntimestep, sim.beginstep, sim.endstep))
+    torch.cuda.synchronize()
+print("host time of each call (no sync), us/step:")
+for k, v in host.items():
+    print(f"  {k:12s} {v / N * 1e6:9.1f}")
 torch.cuda.synchronize(); t0 = time.perf_counter(); sim.run(N); torch.cuda.synchronize()
 print("pipelined sim.run: %.1f us/step" % ((time.perf_counter() - t0) / N * 1e6))
 dist.destroy_process_group()
