@@ -205,6 +205,17 @@ int ucg_decide_local(ucg_ctx *ctx, int *due, int *flag);
 int ucg_fix_nve_initial(ucg_ctx *ctx, int groupbit);
 int ucg_fix_nve_final(ucg_ctx *ctx, int groupbit);
 
+/* ---------------------------------------------------------------- fix nve/ucgld/wall/hard
+ * FixNVE_UCGLD_Wall_Hard (UCG/fix_nve_ucgld_wall_hard.cpp): the nve/ucgld update, plus
+ * ucgstate = (ucgl < 0.5 ? 0 : 1) after the drift (initial_integrate :97-103), reflection of ucgl
+ * and ucgvl at 0 and 1 after the second half-kick (final_integrate :171-177), and -- with the
+ * keyword `bias_potential [barrier]` (:21-33, default barrier 0.1) -- the bias force
+ * (-7980 x^9 + 2 x) * 10 * barrier, x = ucgl - 0.5, added to ucgforce in post_force (:216-241). */
+int ucg_fix_nve_wall_hard_set(ucg_ctx *ctx, int bias_potential, double barrier);
+int ucg_fix_nve_wall_hard_initial(ucg_ctx *ctx, int groupbit);
+int ucg_fix_nve_wall_hard_final(ucg_ctx *ctx, int groupbit);
+int ucg_fix_nve_wall_hard_post_force(ucg_ctx *ctx, int groupbit);
+
 /* ----------------------------------------------------------- fix ucgld/langevin
  * replaces Fix_UCGLD_Langevin (UCG/fix_ucgld_langevin.cpp): constructor :54-119,
  * init :149-183, post_force_templated<0> :226-297, end_of_step :303-312,
@@ -235,7 +246,10 @@ int ucg_ranmars_fill(ucg_ctx *ctx, int seed, long long skip, int n, double *out)
 
 /* ------------------------------------------------------ resident Verlet driver
  * step order of upstream Verlet::setup()/run() with the
- * whole state resident in HBM; used by bench.py and the trajectory-parity tests */
+ * whole state resident in HBM; used by bench.py and the trajectory-parity tests.
+ * use_nve: 0 no integrator, 1 fix nve/ucgld, 2 fix nve/ucgld/wall/hard (its bias_potential keyword
+ * comes from ucg_fix_nve_wall_hard_set; being the first fix of the deck its post_force runs before
+ * the thermostat's) */
 int ucg_md_attach(ucg_ctx *ctx, ucg_pair *pair, int use_nve, int use_langevin, int use_ucgstate);
 /* the per-bead hooks that follow the pair kernel as ONE launch, in the reference's order:
  * ucgld/langevin post_force -> ucgstate post_force -> nve/ucgld final_integrate [-> the next

@@ -40,6 +40,8 @@ SYMBOLS = [
     "ucg_neigh_upload_full", "ucg_domain_set", "ucg_neigh_rebuild", "ucg_halo_forward", "ucg_neigh_download",
     "ucg_ghosts_download",
     "ucg_fix_nve_initial", "ucg_fix_nve_final",
+    "ucg_fix_nve_wall_hard_set", "ucg_fix_nve_wall_hard_initial", "ucg_fix_nve_wall_hard_final",
+    "ucg_fix_nve_wall_hard_post_force",
     "ucg_fix_langevin_create", "ucg_fix_langevin_init", "ucg_fix_langevin_init_from_ucgml",
     "ucg_fix_langevin_post_force", "ucg_fix_langevin_end_of_step", "ucg_fix_langevin_t_target",
     "ucg_fix_ucgstate_create", "ucg_fix_ucgstate_post_force",
@@ -117,6 +119,10 @@ def lib():
     L.ucg_ghosts_download.argtypes = [vp, c_int_p, c_int_p, C.c_int]
     L.ucg_fix_nve_initial.argtypes = [vp, C.c_int]
     L.ucg_fix_nve_final.argtypes = [vp, C.c_int]
+    L.ucg_fix_nve_wall_hard_set.argtypes = [vp, C.c_int, C.c_double]
+    L.ucg_fix_nve_wall_hard_initial.argtypes = [vp, C.c_int]
+    L.ucg_fix_nve_wall_hard_final.argtypes = [vp, C.c_int]
+    L.ucg_fix_nve_wall_hard_post_force.argtypes = [vp, C.c_int]
     L.ucg_fix_langevin_create.argtypes = [vp, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int]
     L.ucg_fix_langevin_init.argtypes = [vp, C.c_int, c_double_p, c_double_p]
     L.ucg_fix_langevin_init_from_ucgml.argtypes = [vp, C.c_int, c_double_p]
@@ -304,6 +310,19 @@ class Context:
     def fix_nve_ucgld_final_integrate(self, groupbit=1):
         self.chk(self.L.ucg_fix_nve_final(self.h, groupbit))
 
+    # ---- fix nve/ucgld/wall/hard [bias_potential [barrier]]
+    def fix_nve_ucgld_wall_hard(self, bias_potential=False, barrier=0.1):
+        self.chk(self.L.ucg_fix_nve_wall_hard_set(self.h, int(bool(bias_potential)), float(barrier)))
+
+    def fix_nve_ucgld_wall_hard_initial_integrate(self, groupbit=1):
+        self.chk(self.L.ucg_fix_nve_wall_hard_initial(self.h, groupbit))
+
+    def fix_nve_ucgld_wall_hard_final_integrate(self, groupbit=1):
+        self.chk(self.L.ucg_fix_nve_wall_hard_final(self.h, groupbit))
+
+    def fix_nve_ucgld_wall_hard_post_force(self, groupbit=1):
+        self.chk(self.L.ucg_fix_nve_wall_hard_post_force(self.h, groupbit))
+
     # ---- fix ucgld/langevin
     def fix_ucgld_langevin(self, t_start, t_stop, damp, seed, me=0):
         self.chk(self.L.ucg_fix_langevin_create(self.h, t_start, t_stop, damp, int(seed), me))
@@ -384,7 +403,9 @@ class Context:
 
     # ---- resident driver
     def md_attach(self, pair, nve=True, langevin=False, ucgstate=False):
-        self.chk(self.L.ucg_md_attach(self.h, pair.h, int(nve), int(langevin), int(ucgstate)))
+        """nve: False | True (fix nve/ucgld) | "wall" (fix nve/ucgld/wall/hard, see fix_nve_ucgld_wall_hard)"""
+        kind = 2 if nve == "wall" else int(bool(nve))
+        self.chk(self.L.ucg_md_attach(self.h, pair.h, kind, int(langevin), int(ucgstate)))
 
     def md_post_fused(self, langevin, ucgstate, nve, fuse_next, ntimestep, beginstep, endstep, groupbit=1):
         self.chk(self.L.ucg_md_post_fused(self.h, int(langevin), int(ucgstate), int(nve), int(fuse_next), groupbit,

@@ -794,7 +794,7 @@ int ucg_fix_nve_initial(ucg_ctx *ctx, int groupbit)
   if (!ctx) return UCG_ERR_INVALID;
   return guarded(ctx, [&]() -> int {
     // dtv = dt, dtf = 0.5*dt*ftm2v  (UCG/fix_nve_ucgld.cpp:36-38)
-    UCG_HIP(launch_nve_initial(ctx->atoms_dev(), ctx->dt, 0.5 * ctx->dt * ctx->ftm2v, groupbit, ctx->stream));
+    UCG_HIP(launch_nve_initial(ctx->atoms_dev(), ctx->dt, 0.5 * ctx->dt * ctx->ftm2v, groupbit, 0, ctx->stream));
     return UCG_OK;
   });
 }
@@ -803,7 +803,45 @@ int ucg_fix_nve_final(ucg_ctx *ctx, int groupbit)
 {
   if (!ctx) return UCG_ERR_INVALID;
   return guarded(ctx, [&]() -> int {
-    UCG_HIP(launch_nve_final(ctx->atoms_dev(), 0.5 * ctx->dt * ctx->ftm2v, groupbit, ctx->stream));
+    UCG_HIP(launch_nve_final(ctx->atoms_dev(), 0.5 * ctx->dt * ctx->ftm2v, groupbit, 0, ctx->stream));
+    return UCG_OK;
+  });
+}
+
+/* fix nve/ucgld/wall/hard (UCG/fix_nve_ucgld_wall_hard.cpp) */
+int ucg_fix_nve_wall_hard_set(ucg_ctx *ctx, int bias_potential, double barrier)
+{
+  if (!ctx) return UCG_ERR_INVALID;
+  // the constructor's keyword loop (:21-33): "bias_potential [barrier]", default barrier 0.1
+  ctx->wall_bias = bias_potential != 0;
+  ctx->wall_barrier = barrier;
+  return UCG_OK;
+}
+
+int ucg_fix_nve_wall_hard_initial(ucg_ctx *ctx, int groupbit)
+{
+  if (!ctx) return UCG_ERR_INVALID;
+  return guarded(ctx, [&]() -> int {
+    UCG_HIP(launch_nve_initial(ctx->atoms_dev(), ctx->dt, 0.5 * ctx->dt * ctx->ftm2v, groupbit, 2, ctx->stream));
+    return UCG_OK;
+  });
+}
+
+int ucg_fix_nve_wall_hard_final(ucg_ctx *ctx, int groupbit)
+{
+  if (!ctx) return UCG_ERR_INVALID;
+  return guarded(ctx, [&]() -> int {
+    UCG_HIP(launch_nve_final(ctx->atoms_dev(), 0.5 * ctx->dt * ctx->ftm2v, groupbit, 2, ctx->stream));
+    return UCG_OK;
+  });
+}
+
+int ucg_fix_nve_wall_hard_post_force(ucg_ctx *ctx, int groupbit)
+{
+  if (!ctx) return UCG_ERR_INVALID;
+  return guarded(ctx, [&]() -> int {
+    // setmask() adds POST_FORCE only with bias_potential (:41-52)
+    if (ctx->wall_bias) UCG_HIP(launch_wall_bias(ctx->atoms_dev(), ctx->wall_barrier, groupbit, ctx->stream));
     return UCG_OK;
   });
 }
@@ -993,7 +1031,7 @@ int ucg_md_post_fused(ucg_ctx *ctx, int use_langevin, int use_ucgstate, int use_
     }
     UCG_HIP(launch_post_fused(ctx->atoms_dev(), use_langevin != 0, Lg, use_ucgstate != 0, S.ld_flag, S.mc_flag, S.mc_rate,
                               mc_draws, use_nve != 0, fuse_next_initial != 0, ctx->dt, 0.5 * ctx->dt * ctx->ftm2v,
-                              groupbit, ctx->stream));
+                              groupbit, use_nve >= 2 ? (ctx->wall_bias ? 3 : 2) : 0, ctx->wall_barrier, ctx->stream));
     return UCG_OK;
   });
 }

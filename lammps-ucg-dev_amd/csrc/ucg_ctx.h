@@ -122,7 +122,10 @@ struct ucg_ctx {
   ucg::Domain *dom = nullptr;
   // resident driver
   ucg_pair *md_pair = nullptr;
-  bool md_nve = false, md_lang = false, md_ucgst = false;
+  int md_nve = 0;  // 0 none, 1 fix nve/ucgld, 2 fix nve/ucgld/wall/hard
+  bool md_lang = false, md_ucgst = false;
+  bool wall_bias = false;       // fix nve/ucgld/wall/hard ... bias_potential [barrier]
+  double wall_barrier = 0.1;
   bool md_no_fuse = false;  // option "md_no_fuse": keep initial_integrate a separate launch
   long long ntimestep = 0, beginstep = 0, endstep = 0;
   int groupbit = 1;

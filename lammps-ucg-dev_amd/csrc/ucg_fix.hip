@@ -3,6 +3,9 @@
 //
 //   k_nve_initial / k_nve_final   FixNVE_UCGLD::initial_integrate / final_integrate
 //                                 (UCG/fix_nve_ucgld.cpp:44-101, 104-153, per-type mass branch)
+//                                 wall != 0: FixNVE_UCGLD_Wall_Hard (UCG/fix_nve_ucgld_wall_hard.cpp:61-199),
+//                                 i.e. ucgstate from lambda after the drift, reflection of lambda at 0 / 1
+//   k_wall_bias                   FixNVE_UCGLD_Wall_Hard::post_force + bias_force (:216-241)
 //   k_langevin                    Fix_UCGLD_Langevin::post_force_templated<0>
 //                                 (UCG/fix_ucgld_langevin.cpp:226-297)
 //   k_lambda_ke                   Fix_UCGLD_Langevin::end_of_step (:303-312)
@@ -23,8 +26,15 @@ namespace {
 
 constexpr int FIX_BLOCK = 256;
 
+// bias_force (UCG/fix_nve_ucgld_wall_hard.cpp:216-221), products left to right as written there
+__device__ __forceinline__ double wall_bias_force(const double lmd, const double H)
+{
+  const double x = lmd - 0.5;
+  return (-7980.0 * x * x * x * x * x * x * x * x * x + 2.0 * x) * 10.0 * H;
+}
+
 __global__ __launch_bounds__(FIX_BLOCK) void k_nve_initial(const AtomsDev A, const double dtv, const double dtf,
-                                                          const int groupbit)
+                                                          const int groupbit, const int wall)
 {
   const int i = blockIdx.x * FIX_BLOCK + threadIdx.x;
   if (i >= A.nlocal) return;
@@ -44,9 +54,11 @@ __global__ __launch_bounds__(FIX_BLOCK) void k_nve_initial(const AtomsDev A, con
   x.w += dtv * v.w;
   A.vel4[i] = v;
   A.pos4[i] = x;
+  if (wall) A.meta[i] = (A.meta[i] & 0xFFFF) | ((x.w < 0.5 ? 0 : 1) << 16);
 }
 
-__global__ __launch_bounds__(FIX_BLOCK) void k_nve_final(const AtomsDev A, const double dtf, const int groupbit)
+__global__ __launch_bounds__(FIX_BLOCK) void k_nve_final(const AtomsDev A, const double dtf, const int groupbit,
+                                                        const int wall)
 {
   const int i = blockIdx.x * FIX_BLOCK + threadIdx.x;
   if (i >= A.nlocal) return;
@@ -59,7 +71,29 @@ __global__ __launch_bounds__(FIX_BLOCK) void k_nve_final(const AtomsDev A, const
   v.z += dtfm * f.z;
   const double dtflm = dtf / A.ucgml[i];
   v.w += dtflm * f.w;
+  if (wall) {
+    double4 x = A.pos4[i];
+    if (x.w < 0.0) {
+      x.w = -x.w;
+      v.w = -v.w;
+      A.pos4[i] = x;
+    } else if (x.w > 1.0) {
+      x.w = 2.0 - x.w;
+      v.w = -v.w;
+      A.pos4[i] = x;
+    }
+  }
   A.vel4[i] = v;
+}
+
+__global__ __launch_bounds__(FIX_BLOCK) void k_wall_bias(const AtomsDev A, const double barrier, const int groupbit)
+{
+  const int i = blockIdx.x * FIX_BLOCK + threadIdx.x;
+  if (i >= A.nlocal) return;
+  if (!(A.mask[i] & groupbit)) return;
+  double4 f = A.frc4[i];
+  f.w += wall_bias_force(A.pos4[i].w, barrier);
+  A.frc4[i] = f;
 }
 
 __global__ __launch_bounds__(FIX_BLOCK) void k_langevin(const AtomsDev A, const LangevinDev Lg, const int groupbit)
@@ -125,7 +159,8 @@ __global__ __launch_bounds__(FIX_BLOCK) void k_ucgstate(const AtomsDev A, const 
 }
 
 // Resident-loop fusion of the per-bead hooks that follow the pair kernel, in the reference's
-// order: fix ucgld/langevin post_force -> fix ucgstate post_force -> fix nve/ucgld final_integrate
+// order: [wall/hard bias post_force ->] fix ucgld/langevin post_force -> fix ucgstate post_force ->
+// fix nve/ucgld[/wall/hard] final_integrate
 // [-> the NEXT step's initial_integrate when nothing has to look at the state in between].
 // Each bead is independent and every statement is the one of the stand-alone kernels above,
 // in the same order, so the results are bit-identical; only the HBM passes are merged.
@@ -133,8 +168,9 @@ template <bool LANG, bool UCGST, bool NVE, bool NEXT>
 __global__ __launch_bounds__(FIX_BLOCK) void k_post_fused(const AtomsDev A, const LangevinDev Lg, const int ld_flag,
                                                          const int mc_flag, const double mc_rate,
                                                          const unsigned int *mc_draws, const double dtv, const double dtf,
-                                                         const int groupbit)
+                                                         const int groupbit, const int wall, const double barrier)
 {
+  // wall: 0 fix nve/ucgld, 2 fix nve/ucgld/wall/hard, 3 the same with bias_potential (uniform branches)
   const int i = blockIdx.x * FIX_BLOCK + threadIdx.x;
   if (i >= A.nlocal) return;
   const bool ingroup = (A.mask[i] & groupbit) != 0;
@@ -142,7 +178,13 @@ __global__ __launch_bounds__(FIX_BLOCK) void k_post_fused(const AtomsDev A, cons
   double4 f = A.frc4[i];
   double4 v = A.vel4[i];
   double4 x;
-  bool x_loaded = false, x_dirty = false;
+  bool x_loaded = false, x_dirty = false, f_dirty = false, meta_dirty = false;
+  if (NVE && wall == 3 && ingroup) {
+    x = A.pos4[i];
+    x_loaded = true;
+    f.w += wall_bias_force(x.w, barrier);
+    f_dirty = true;
+  }
   if (LANG && ingroup) {
     const int t = UCG_META_TYPE(meta);
     const double gamma1 = Lg.gfactor1[t];
@@ -151,11 +193,11 @@ __global__ __launch_bounds__(FIX_BLOCK) void k_post_fused(const AtomsDev A, cons
     const double fran = gamma2 * (uni - 0.5);
     const double fdrag = gamma1 * v.w;
     f.w += fdrag + fran;
-    A.frc4[i] = f;
+    f_dirty = true;
   }
+  if (f_dirty) A.frc4[i] = f;
   if (UCGST) {
     double ucgp;
-    bool meta_dirty = false;
     if (A.num_ucgstates[i] == 1) {
       if (!ld_flag) { meta &= 0xFFFF; meta_dirty = true; }
       ucgp = 1.0;
@@ -188,8 +230,7 @@ __global__ __launch_bounds__(FIX_BLOCK) void k_post_fused(const AtomsDev A, cons
     }
     A.ucgp[i] = ucgp;
     if (!ld_flag) {
-      if (meta_dirty) A.meta[i] = meta;
-      x = A.pos4[i];
+      if (!x_loaded) x = A.pos4[i];
       x_loaded = true;
       x.w = ucgp;
       x_dirty = true;
@@ -203,6 +244,19 @@ __global__ __launch_bounds__(FIX_BLOCK) void k_post_fused(const AtomsDev A, cons
     v.y += dtfm * f.y;
     v.z += dtfm * f.z;
     v.w += dtflm * f.w;
+    if (wall) {
+      if (!x_loaded) x = A.pos4[i];
+      x_loaded = true;
+      if (x.w < 0.0) {
+        x.w = -x.w;
+        v.w = -v.w;
+        x_dirty = true;
+      } else if (x.w > 1.0) {
+        x.w = 2.0 - x.w;
+        v.w = -v.w;
+        x_dirty = true;
+      }
+    }
     if (NEXT) {
       // initial_integrate of the next step (same forces)
       if (!x_loaded) x = A.pos4[i];
@@ -215,9 +269,14 @@ __global__ __launch_bounds__(FIX_BLOCK) void k_post_fused(const AtomsDev A, cons
       v.w += dtflm * f.w;
       x.w += dtv * v.w;
       x_dirty = true;
+      if (wall) {
+        meta = (meta & 0xFFFF) | ((x.w < 0.5 ? 0 : 1) << 16);
+        meta_dirty = true;
+      }
     }
     A.vel4[i] = v;
   }
+  if (meta_dirty) A.meta[i] = meta;
   if (x_dirty) A.pos4[i] = x;
 }
 
@@ -308,17 +367,24 @@ hipError_t launch_stream(const void *buf, size_t nbytes, int wide, int *sink, hi
   return hipGetLastError();
 }
 
-hipError_t launch_nve_initial(const AtomsDev &A, double dtv, double dtf, int groupbit, hipStream_t st)
+hipError_t launch_nve_initial(const AtomsDev &A, double dtv, double dtf, int groupbit, int wall, hipStream_t st)
 {
   if (A.nlocal == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_nve_initial, dim3(nblk(A.nlocal)), dim3(FIX_BLOCK), 0, st, A, dtv, dtf, groupbit);
+  hipLaunchKernelGGL(k_nve_initial, dim3(nblk(A.nlocal)), dim3(FIX_BLOCK), 0, st, A, dtv, dtf, groupbit, wall);
   return hipGetLastError();
 }
 
-hipError_t launch_nve_final(const AtomsDev &A, double dtf, int groupbit, hipStream_t st)
+hipError_t launch_nve_final(const AtomsDev &A, double dtf, int groupbit, int wall, hipStream_t st)
 {
   if (A.nlocal == 0) return hipSuccess;
-  hipLaunchKernelGGL(k_nve_final, dim3(nblk(A.nlocal)), dim3(FIX_BLOCK), 0, st, A, dtf, groupbit);
+  hipLaunchKernelGGL(k_nve_final, dim3(nblk(A.nlocal)), dim3(FIX_BLOCK), 0, st, A, dtf, groupbit, wall);
+  return hipGetLastError();
+}
+
+hipError_t launch_wall_bias(const AtomsDev &A, double barrier, int groupbit, hipStream_t st)
+{
+  if (A.nlocal == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_wall_bias, dim3(nblk(A.nlocal)), dim3(FIX_BLOCK), 0, st, A, barrier, groupbit);
   return hipGetLastError();
 }
 
@@ -339,12 +405,13 @@ hipError_t launch_ucgstate(const AtomsDev &A, int ld_flag, int mc_flag, double m
 
 hipError_t launch_post_fused(const AtomsDev &A, bool lang, const LangevinDev &Lg, bool ucgst, int ld_flag, int mc_flag,
                              double mc_rate, const unsigned int *mc_draws, bool nve, bool next, double dtv, double dtf,
-                             int groupbit, hipStream_t st)
+                             int groupbit, int wall, double barrier, hipStream_t st)
 {
   if (A.nlocal == 0) return hipSuccess;
   const dim3 g(nblk(A.nlocal)), b(FIX_BLOCK);
 #define UCG_PF(L, U, N, X) \
-  hipLaunchKernelGGL((k_post_fused<L, U, N, X>), g, b, 0, st, A, Lg, ld_flag, mc_flag, mc_rate, mc_draws, dtv, dtf, groupbit)
+  hipLaunchKernelGGL((k_post_fused<L, U, N, X>), g, b, 0, st, A, Lg, ld_flag, mc_flag, mc_rate, mc_draws, dtv, dtf, groupbit, \
+                     wall, barrier)
   const int sel = (lang ? 8 : 0) | (ucgst ? 4 : 0) | (nve ? 2 : 0) | ((nve && next) ? 1 : 0);
   switch (sel) {
     case 0: break;

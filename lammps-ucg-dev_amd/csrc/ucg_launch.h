@@ -29,8 +29,9 @@ struct LangevinDev {
   double tsqrt;
   const unsigned int *draws;  // 24-bit RanMars integers, one per owned bead
 };
-hipError_t launch_nve_initial(const AtomsDev &A, double dtv, double dtf, int groupbit, hipStream_t st);
-hipError_t launch_nve_final(const AtomsDev &A, double dtf, int groupbit, hipStream_t st);
+hipError_t launch_nve_initial(const AtomsDev &A, double dtv, double dtf, int groupbit, int wall, hipStream_t st);
+hipError_t launch_nve_final(const AtomsDev &A, double dtf, int groupbit, int wall, hipStream_t st);
+hipError_t launch_wall_bias(const AtomsDev &A, double barrier, int groupbit, hipStream_t st);
 hipError_t launch_langevin(const AtomsDev &A, const LangevinDev &Lg, int groupbit, hipStream_t st);
 hipError_t launch_lambda_ke(const AtomsDev &A, int groupbit, double mvv2e, double *part, double *out,
                             hipStream_t st);
@@ -39,7 +40,7 @@ hipError_t launch_ucgstate(const AtomsDev &A, int ld_flag, int mc_flag, double m
 hipError_t launch_force_clear(const AtomsDev &A, hipStream_t st);
 hipError_t launch_post_fused(const AtomsDev &A, bool lang, const LangevinDev &Lg, bool ucgst, int ld_flag, int mc_flag,
                              double mc_rate, const unsigned int *mc_draws, bool nve, bool next, double dtv, double dtf,
-                             int groupbit, hipStream_t st);
+                             int groupbit, int wall, double barrier, hipStream_t st);
 hipError_t launch_stream(const void *buf, size_t nbytes, int wide, int *sink, hipStream_t st);
 
 // ---- ucg_ranmars.hip : exact block-parallel RANMAR

@@ -1228,7 +1228,8 @@ int ucg_md_attach(ucg_ctx *ctx, ucg_pair *pair, int use_nve, int use_langevin, i
 {
   if (!ctx || !pair || pair->ctx != ctx) return UCG_ERR_INVALID;
   ctx->md_pair = pair;
-  ctx->md_nve = use_nve != 0;
+  if (use_nve < 0 || use_nve > 2) return UCG_ERR_INVALID;
+  ctx->md_nve = use_nve;  // 1: fix nve/ucgld, 2: fix nve/ucgld/wall/hard
   ctx->md_lang = use_langevin != 0;
   ctx->md_ucgst = use_ucgstate != 0;
   if (ctx->md_lang && !ctx->lang.active) {
@@ -1280,7 +1281,9 @@ int ucg_md_run(ucg_ctx *ctx, long long nsteps, int thermo_every)
     ctx->ntimestep++;
     const int ev = (thermo_every > 0 && (ctx->ntimestep % thermo_every == 0)) ? 1 : 0;
     int rc;
-    if (ctx->md_nve && !initial_done && (rc = ucg_fix_nve_initial(ctx, ctx->groupbit))) return rc;
+    if (ctx->md_nve && !initial_done &&
+        (rc = ctx->md_nve == 2 ? ucg_fix_nve_wall_hard_initial(ctx, ctx->groupbit) : ucg_fix_nve_initial(ctx, ctx->groupbit)))
+      return rc;
     initial_done = false;
     rc = guarded(ctx, [&]() -> int {
       if (decide(ctx)) rebuild(ctx);

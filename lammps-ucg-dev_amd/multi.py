@@ -114,8 +114,11 @@ class Transport:
 class RankSim:
     """The Verlet step order of SURVEY.md section 3.1 on one rank of a decomposed run."""
 
-    def __init__(self, ctx, pair, transport: Transport, grid, use_langevin=True, use_ucgstate=True, groupbit=1):
+    def __init__(self, ctx, pair, transport: Transport, grid, use_langevin=True, use_ucgstate=True, groupbit=1,
+                 integrator="nve"):
+        """integrator: "nve" = fix nve/ucgld, "wall" = fix nve/ucgld/wall/hard (Context.fix_nve_ucgld_wall_hard)"""
         self.ctx, self.pair, self.tr = ctx, pair, transport
+        self.nve_kind = 2 if integrator == "wall" else 1
         self.grid = list(grid)
         self.me = transport.rank
         self.world = transport.world
@@ -192,7 +195,10 @@ class RankSim:
             self.ntimestep += 1
             ev = 1 if (thermo_every > 0 and self.ntimestep % thermo_every == 0) else 0
             if not initial_done:
-                ctx.fix_nve_ucgld_initial_integrate(self.groupbit)
+                if self.nve_kind == 2:
+                    ctx.fix_nve_ucgld_wall_hard_initial_integrate(self.groupbit)
+                else:
+                    ctx.fix_nve_ucgld_initial_integrate(self.groupbit)
             due, flag = ctx.decide_local()
             if due and self.tr.allreduce_max(flag):
                 self.rebuild()
@@ -203,7 +209,7 @@ class RankSim:
                 last = out
             # langevin -> ucgstate -> final_integrate (-> next initial_integrate) as one launch
             fuse_next = (not ev) and (s + 1 < nsteps)
-            ctx.md_post_fused(self.use_langevin, self.use_ucgstate, True, fuse_next, self.ntimestep, self.beginstep,
+            ctx.md_post_fused(self.use_langevin, self.use_ucgstate, self.nve_kind, fuse_next, self.ntimestep, self.beginstep,
                               self.endstep, self.groupbit)
             initial_done = fuse_next
         return last

@@ -178,6 +178,11 @@ void orc_force_clear(orc_atoms *a, int include_ghosts);
 /* fix nve/ucgld (UCG/fix_nve_ucgld.cpp:36-153) */
 void orc_fix_nve_initial(orc_atoms *a, double dt, double ftm2v, int groupbit);
 void orc_fix_nve_final(orc_atoms *a, double dt, double ftm2v, int groupbit);
+/* fix nve/ucgld/wall/hard (UCG/fix_nve_ucgld_wall_hard.cpp:61-241) */
+void orc_fix_nve_wall_initial(orc_atoms *a, double dt, double ftm2v, int groupbit);
+void orc_fix_nve_wall_final(orc_atoms *a, double dt, double ftm2v, int groupbit);
+double orc_wall_bias_force(double lmd, double H);
+void orc_fix_nve_wall_post_force(orc_atoms *a, double barrier, int groupbit);
 
 /* fix ucgld/langevin (UCG/fix_ucgld_langevin.cpp) */
 typedef struct {

@@ -106,6 +106,11 @@ def lib():
     L.orc_force_clear.argtypes = [C.POINTER(Atoms), C.c_int]
     L.orc_fix_nve_initial.argtypes = [C.POINTER(Atoms), C.c_double, C.c_double, C.c_int]
     L.orc_fix_nve_final.argtypes = [C.POINTER(Atoms), C.c_double, C.c_double, C.c_int]
+    L.orc_fix_nve_wall_initial.argtypes = [C.POINTER(Atoms), C.c_double, C.c_double, C.c_int]
+    L.orc_fix_nve_wall_final.argtypes = [C.POINTER(Atoms), C.c_double, C.c_double, C.c_int]
+    L.orc_fix_nve_wall_post_force.argtypes = [C.POINTER(Atoms), C.c_double, C.c_int]
+    L.orc_wall_bias_force.argtypes = [C.c_double, C.c_double]
+    L.orc_wall_bias_force.restype = C.c_double
     L.orc_fix_langevin_create.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int]
     L.orc_fix_langevin_create.restype = C.c_void_p
     L.orc_fix_langevin_destroy.argtypes = [C.c_void_p]
@@ -134,6 +139,7 @@ def lib():
     L.orc_sim_setup.argtypes = [C.c_void_p, C.c_longlong]
     L.orc_sim_run.argtypes = [C.c_void_p, C.c_longlong, C.c_int]
     L.orc_sim_set_run_params.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.orc_sim_set_wall_barrier.argtypes = [C.c_void_p, C.c_double]
     L.orc_sim_set_units.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double]
     L.orc_sim_attach.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_int, C.c_double]
@@ -336,8 +342,15 @@ class Sim:
         self.L.orc_sim_set_run_params(self.h, dt, every, delay, check, mode)
 
     def attach(self, pair: Pair, langevin=None, nve=True, ucgstate=None, ntypes=2):
-        """langevin = (t_start, t_stop, damp, seed) or None; ucgstate = None | "ld" | "plain" | ("mc", seed, rate)"""
+        """langevin = (t_start, t_stop, damp, seed) or None; ucgstate = None | "ld" | "plain" | ("mc", seed, rate);
+        nve = False | True (fix nve/ucgld) | "wall" (fix nve/ucgld/wall/hard) | ("wall", barrier) (+ bias_potential)"""
         self.pair = pair
+        kind = 1 if nve is True else 0
+        if nve == "wall":
+            kind = 2
+        elif isinstance(nve, tuple):
+            kind = 3
+            self.L.orc_sim_set_wall_barrier(self.h, float(nve[1]))
         if langevin is not None:
             self.lang = self.L.orc_fix_langevin_create(ntypes, langevin[0], langevin[1], langevin[2], int(langevin[3]), 0)
         have_ucg, ld, mc, seed, rate = 0, 0, 0, 0, 0.01
@@ -349,7 +362,7 @@ class Sim:
                 pass
             else:
                 mc, seed, rate = 1, int(ucgstate[1]), float(ucgstate[2])
-        self.L.orc_sim_attach(self.h, pair.h, self.lang, 1 if nve else 0, have_ucg, ld, mc, seed, rate)
+        self.L.orc_sim_attach(self.h, pair.h, self.lang, kind, have_ucg, ld, mc, seed, rate)
 
     def setup(self, nsteps):
         return self.L.orc_sim_setup(self.h, nsteps)

@@ -64,6 +64,75 @@ void orc_fix_nve_final(orc_atoms *a, double dt, double ftm2v, int groupbit)
   }
 }
 
+/* fix nve/ucgld/wall/hard (UCG/fix_nve_ucgld_wall_hard.cpp): the nve/ucgld update, plus
+   ucgstate from lambda in initial_integrate (:97-103, :124-130), reflection of lambda at 0 and 1
+   after the second half-kick (:171-177, :192-198), and an optional bias force (:223-241). */
+void orc_fix_nve_wall_initial(orc_atoms *a, double dt, double ftm2v, int groupbit)
+{
+  const double dtv = dt;
+  const double dtf = 0.5 * dt * ftm2v;
+  double dtfm, dtflm;
+  double *x = a->x, *v = a->v, *f = a->f;
+  for (int i = 0; i < a->nlocal; i++) {
+    if (a->mask[i] & groupbit) {
+      dtfm = dtf / a->mass[a->type[i]];
+      v[3 * i + 0] += dtfm * f[3 * i + 0];
+      v[3 * i + 1] += dtfm * f[3 * i + 1];
+      v[3 * i + 2] += dtfm * f[3 * i + 2];
+      x[3 * i + 0] += dtv * v[3 * i + 0];
+      x[3 * i + 1] += dtv * v[3 * i + 1];
+      x[3 * i + 2] += dtv * v[3 * i + 2];
+
+      dtflm = dtf / a->ucgml[i];
+      a->ucgvl[i] += dtflm * a->ucgforce[i];
+      a->ucgl[i] += dtv * a->ucgvl[i];
+
+      if (a->ucgl[i] < 0.5) a->ucgstate[i] = 0;
+      else a->ucgstate[i] = 1;
+    }
+  }
+}
+
+void orc_fix_nve_wall_final(orc_atoms *a, double dt, double ftm2v, int groupbit)
+{
+  const double dtf = 0.5 * dt * ftm2v;
+  double dtfm, dtflm;
+  double *v = a->v, *f = a->f;
+  for (int i = 0; i < a->nlocal; i++) {
+    if (a->mask[i] & groupbit) {
+      dtfm = dtf / a->mass[a->type[i]];
+      v[3 * i + 0] += dtfm * f[3 * i + 0];
+      v[3 * i + 1] += dtfm * f[3 * i + 1];
+      v[3 * i + 2] += dtfm * f[3 * i + 2];
+
+      dtflm = dtf / a->ucgml[i];
+      a->ucgvl[i] += dtflm * a->ucgforce[i];
+
+      if (a->ucgl[i] < 0.0) {
+        a->ucgl[i] = -a->ucgl[i];
+        a->ucgvl[i] = -a->ucgvl[i];
+      } else if (a->ucgl[i] > 1.0) {
+        a->ucgl[i] = 2.0 - a->ucgl[i];
+        a->ucgvl[i] = -a->ucgvl[i];
+      }
+    }
+  }
+}
+
+/* bias_force (:216-221): minus the derivative of (798 x^10 - x^2 + 0.1) * 10 H, x = lambda - 1/2,
+   with the products taken left to right as written there */
+double orc_wall_bias_force(double lmd, double H)
+{
+  double x = lmd - 0.5;
+  return (-7980 * x * x * x * x * x * x * x * x * x + 2 * x) * 10 * H;
+}
+
+void orc_fix_nve_wall_post_force(orc_atoms *a, double barrier, int groupbit)
+{
+  for (int i = 0; i < a->nlocal; i++)
+    if (a->mask[i] & groupbit) a->ucgforce[i] += orc_wall_bias_force(a->ucgl[i], barrier);
+}
+
 orc_fix_langevin *orc_fix_langevin_create(int ntypes, double t_start, double t_stop,
                                           double t_period, int seed, int me)
 {

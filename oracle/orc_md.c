@@ -518,6 +518,13 @@ static void post_force(orc_sim *s)
   if (s->have_ucgstate) orc_fix_ucgstate_post_force(&s->ucgst, &s->a);
 }
 
+/* the integrator fix is defined first in a deck, so its post_force (the wall/hard bias) runs
+   before the thermostat's; it has no setup() hook, so not at setup */
+static void integrator_post_force(orc_sim *s)
+{
+  if (s->have_nve == 3) orc_fix_nve_wall_post_force(&s->a, s->wall_barrier, s->groupbit);
+}
+
 int orc_sim_setup(orc_sim *s, long long nsteps_planned)
 {
   /* upstream Verlet::setup(): build lists, compute forces, then Modify::setup ->
@@ -538,13 +545,16 @@ int orc_sim_run(orc_sim *s, long long nsteps, int thermo_every)
   for (long long n = 0; n < nsteps; n++) {
     s->ntimestep++;
     const int ev = (thermo_every > 0 && (s->ntimestep % thermo_every == 0)) ? 1 : 0;
-    if (s->have_nve) orc_fix_nve_initial(&s->a, s->dt, s->ftm2v, s->groupbit);
+    if (s->have_nve == 1) orc_fix_nve_initial(&s->a, s->dt, s->ftm2v, s->groupbit);
+    else if (s->have_nve >= 2) orc_fix_nve_wall_initial(&s->a, s->dt, s->ftm2v, s->groupbit);
     if (decide(s)) orc_sim_rebuild(s);
     else orc_sim_forward_comm(s);
     int rc = compute_forces(s, ev, ev);
     if (rc) rc_any = rc;
+    integrator_post_force(s);
     post_force(s);
-    if (s->have_nve) orc_fix_nve_final(&s->a, s->dt, s->ftm2v, s->groupbit);
+    if (s->have_nve == 1) orc_fix_nve_final(&s->a, s->dt, s->ftm2v, s->groupbit);
+    else if (s->have_nve >= 2) orc_fix_nve_wall_final(&s->a, s->dt, s->ftm2v, s->groupbit);
     if (s->lang) orc_fix_langevin_end_of_step(s->lang, &s->a, s->groupbit, s->boltz, s->mvv2e);
   }
   return rc_any;
@@ -577,6 +587,8 @@ void orc_sim_attach(orc_sim *s, orc_pair *pair, orc_fix_langevin *lang, int have
   s->have_ucgstate = have_ucgstate;
   if (have_ucgstate) orc_fix_ucgstate_init(&s->ucgst, ld_flag, mc_flag, mc_seed, mc_rate, 0);
 }
+
+void orc_sim_set_wall_barrier(orc_sim *s, double barrier) { s->wall_barrier = barrier; }
 
 void orc_sim_get_info(const orc_sim *s, long long *out)
 {

@@ -33,7 +33,8 @@ typedef struct {
   orc_pair *pair;              /* borrowed */
   orc_fix_langevin *lang;      /* borrowed, may be NULL */
   orc_fix_ucgstate ucgst;
-  int have_ucgstate, have_nve;
+  int have_ucgstate, have_nve;  /* have_nve: 0 none, 1 nve/ucgld, 2 nve/ucgld/wall/hard, 3 the same with bias_potential */
+  double wall_barrier;
 
   long long ntimestep, beginstep, endstep;
   int ago, nrebuild, pair_errors;
@@ -55,6 +56,7 @@ int orc_sim_setup(orc_sim *s, long long nsteps_planned);
 int orc_sim_run(orc_sim *s, long long nsteps, int thermo_every);
 void orc_sim_set_run_params(orc_sim *s, double dt, int every, int delay, int check, int mode);
 void orc_sim_set_units(orc_sim *s, double boltz, double ftm2v, double mvv2e);
+void orc_sim_set_wall_barrier(orc_sim *s, double barrier);
 void orc_sim_attach(orc_sim *s, orc_pair *pair, orc_fix_langevin *lang, int have_nve,
                     int have_ucgstate, int ld_flag, int mc_flag, int mc_seed, double mc_rate);
 void orc_sim_get_info(const orc_sim *s, long long *out);

@@ -58,24 +58,30 @@ def test_device_rebuild_matches_spec(gpu_ctx, pkg, orc, ncell, untiled):
 
 
 CASES = [
-    # style, extra keywords, langevin, ucgstate, dt, steps, every
-    ("table_ucgld", (), (1.0, 1.0, 1.0, 48279), "ld", 0.004, 120, 1),
-    ("table_ucgld", (), (1.0, 2.0, 0.5, 777), "ld", 0.004, 100, 5),
-    ("table_ucg_bethe", (), None, "plain", 0.004, 80, 1),
-    ("table_ucg_bethe", ("pseudo", "no"), None, ("mc", 9127, 0.2), 0.004, 80, 2),
-    ("table_ucgld", (), None, None, 0.004, 60, 1),
-    ("table_ucg_bethe_density", (), None, ("mc", 4242, 0.3), 0.002, 60, 1),
-    ("table_ucg_bethe_density", (), None, None, 0.002, 40, 2),
+    # style, extra keywords, langevin, ucgstate, dt, steps, every, integrator
+    ("table_ucgld", (), (1.0, 1.0, 1.0, 48279), "ld", 0.004, 120, 1, True),
+    ("table_ucgld", (), (1.0, 2.0, 0.5, 777), "ld", 0.004, 100, 5, True),
+    ("table_ucg_bethe", (), None, "plain", 0.004, 80, 1, True),
+    ("table_ucg_bethe", ("pseudo", "no"), None, ("mc", 9127, 0.2), 0.004, 80, 2, True),
+    ("table_ucgld", (), None, None, 0.004, 60, 1, True),
+    ("table_ucg_bethe_density", (), None, ("mc", 4242, 0.3), 0.002, 60, 1, True),
+    ("table_ucg_bethe_density", (), None, None, 0.002, 40, 2, True),
+    # fix nve/ucgld/wall/hard: states follow lambda, lambda is reflected at 0 and 1 (a light
+    # lambda mass and a hot thermostat make every bead hit the walls), with and without the bias
+    ("table_ucgld", (), (6.0, 6.0, 0.2, 48279), "ld", 0.004, 120, 1, "wall"),
+    ("table_ucgld", (), (6.0, 6.0, 0.2, 1234), "ld", 0.004, 100, 2, ("wall", 0.25)),
+    ("table_ucgld", (), None, None, 0.004, 60, 1, ("wall", 0.1)),
 ]
 
 
-@pytest.mark.parametrize("style,extra,langevin,ucgstate,dt,steps,every", CASES)
-def test_md_trajectory_bitwise(fresh_ctx, pkg, orc, style, extra, langevin, ucgstate, dt, steps, every):
+@pytest.mark.parametrize("style,extra,langevin,ucgstate,dt,steps,every,integrator", CASES)
+def test_md_trajectory_bitwise(fresh_ctx, pkg, orc, style, extra, langevin, ucgstate, dt, steps, every, integrator):
     dens = dict(density=(11.3, 1.5), extra11=0.05) if style.endswith("density") else {}
     deck = util.make_deck("spline", 1024, extra_keywords=extra, **dens)
-    beads = pkg.synth.make_beads(8, seed=31)
+    wall = integrator is not True
+    beads = pkg.synth.make_beads(8, seed=31, ucgml=0.5 if wall else 10.0)
     op = util.oracle_pair(style, deck)
-    sim = util.oracle_sim(beads, op, mode=1, dt=dt, langevin=langevin, nve=True, ucgstate=ucgstate, every=every)
+    sim = util.oracle_sim(beads, op, mode=1, dt=dt, langevin=langevin, nve=integrator, ucgstate=ucgstate, every=every)
     assert sim.setup(steps) == 0
     assert sim.run(steps, 10) == 0
 
@@ -91,7 +97,10 @@ def test_md_trajectory_bitwise(fresh_ctx, pkg, orc, style, extra, langevin, ucgs
             gpu_ctx.fix_ucgstate(None)
         else:
             gpu_ctx.fix_ucgstate("mc", ucgstate[1], ucgstate[2])
-    gpu_ctx.md_attach(gp, nve=True, langevin=langevin is not None, ucgstate=ucgstate is not None)
+    if wall:
+        bias = isinstance(integrator, tuple)
+        gpu_ctx.fix_nve_ucgld_wall_hard(bias, integrator[1] if bias else 0.1)
+    gpu_ctx.md_attach(gp, nve="wall" if wall else True, langevin=langevin is not None, ucgstate=ucgstate is not None)
     gpu_ctx.md_setup(steps)
     gpu_ctx.md_run(steps, 10)
     gp.check_errors()
@@ -109,4 +118,8 @@ def test_md_trajectory_bitwise(fresh_ctx, pkg, orc, style, extra, langevin, ucgs
     if langevin is not None:
         assert abs(th["lambda_temp"] - oth["lambda_temp"]) <= 1e-12 * abs(oth["lambda_temp"])
     if isinstance(ucgstate, tuple):  # mc: both states stay populated
+        assert 0 < G["ucgstate"].sum() < beads.n
+    if wall:
+        # lambda stays between the walls (up to one step's overshoot) and both states are populated
+        assert np.all(G["ucgl"] > -0.3) and np.all(G["ucgl"] < 1.3)
         assert 0 < G["ucgstate"].sum() < beads.n

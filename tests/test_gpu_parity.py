@@ -179,6 +179,42 @@ def test_fix_hooks_parity(gpu_ctx, pkg, orc, mode):
     L.orc_fix_ucgstate_destroy(fx)
 
 
+@pytest.mark.parametrize("barrier", [0.1, 0.37])
+def test_fix_nve_ucgld_wall_hard_hooks_bitwise(gpu_ctx, pkg, orc, barrier):
+    """post_force (bias) -> final_integrate (reflection) -> initial_integrate (state from lambda), hook by hook"""
+    L = orc.lib()
+    dt = 0.004
+    deck = util.make_deck("spline", 1024)
+    beads = pkg.synth.make_beads(7, seed=77)
+    rng = np.random.default_rng(5)
+    beads.ucgl = rng.uniform(-0.4, 1.4, beads.n)  # a third of the beads sit beyond a wall
+    beads.ucgvl = rng.normal(0.0, 3.0, beads.n)
+    op = util.oracle_pair("table_ucgld", deck)
+    sim = util.oracle_sim(beads, op, mode=1, dt=dt)
+    sim.rebuild()
+    assert sim.compute_forces(0, 0) == 0
+    gpu_ctx.set_units(1.0, 1.0, 1.0, dt)
+    util.upload_from_oracle(gpu_ctx, sim, beads)
+    gp = util.gpu_pair(gpu_ctx, "table_ucgld", deck)
+    gp.compute(0, 0)
+    a = L.orc_sim_atoms(sim.h)
+    gpu_ctx.fix_nve_ucgld_wall_hard(True, barrier)
+    for _ in range(3):
+        L.orc_fix_nve_wall_post_force(a, barrier, 1)
+        gpu_ctx.fix_nve_ucgld_wall_hard_post_force()
+        assert util.bits_equal(gpu_ctx.atoms_download()["ucgforce"], sim.arrays()["ucgforce"])
+        L.orc_fix_nve_wall_final(a, dt, 1.0, 1)
+        gpu_ctx.fix_nve_ucgld_wall_hard_final_integrate()
+        L.orc_fix_nve_wall_initial(a, dt, 1.0, 1)
+        gpu_ctx.fix_nve_ucgld_wall_hard_initial_integrate()
+        G, O = gpu_ctx.atoms_download(), sim.arrays()
+        for k in ("x", "v", "ucgl", "ucgvl"):
+            assert util.bits_equal(G[k], O[k]), k
+        assert np.array_equal(G["ucgstate"], O["ucgstate"])
+        assert np.array_equal(G["ucgstate"] == 1, G["ucgl"] >= 0.5)
+    gpu_ctx.fix_nve_ucgld_wall_hard(False, 0.1)
+
+
 @pytest.mark.parametrize("kT", [1.0, 0.7, 2.4942, 1e-3, 300.0 * 0.0019872067])
 def test_exact_division_by_constant(gpu_ctx, kT):
     # the FAST kernels' u / kT: reciprocal + two FMA corrections must equal the IEEE quotient

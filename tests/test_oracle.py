@@ -293,3 +293,35 @@ def test_density_prior_follows_local_density(orc, pkg):
     assert A["nghost"] == 0 or True
     inner, outer = A["ucgp"][r < 1.2], A["ucgp"][r > 2.8]
     assert len(inner) and len(outer)
+
+
+def test_wall_hard_bias_force_is_minus_the_potential_derivative(orc):
+    """UCG/fix_nve_ucgld_wall_hard.cpp:216-221: potential (798 x^10 - x^2 + 0.1) * 10 H, x = lambda - 1/2"""
+    H = 0.3
+    pot = lambda l: (798.0 * (l - 0.5) ** 10 - (l - 0.5) ** 2 + 0.1) * 10.0 * H
+    for lam in np.linspace(0.02, 0.98, 25):
+        h = 1e-6
+        fd = -(pot(lam + h) - pot(lam - h)) / (2 * h)
+        assert abs(orc.lib().orc_wall_bias_force(lam, H) - fd) <= 1e-7 * max(1.0, abs(fd))
+    # the double well: zero force at the barrier top, wells pushed towards lambda = 0 and 1
+    assert orc.lib().orc_wall_bias_force(0.5, H) == 0.0
+    assert orc.lib().orc_wall_bias_force(0.4, H) < 0.0 < orc.lib().orc_wall_bias_force(0.6, H)
+
+
+def test_wall_hard_reflects_lambda_and_sets_states(orc, pkg):
+    beads = pkg.synth.make_beads(4, seed=3)
+    rng = np.random.default_rng(11)
+    beads.ucgl = rng.uniform(-0.9, 1.9, beads.n)
+    beads.ucgvl = rng.normal(0.0, 1.0, beads.n)
+    sim = orc.Sim(beads)
+    a = orc.lib().orc_sim_atoms(sim.h)
+    l0, v0 = beads.ucgl.copy(), beads.ucgvl.copy()
+    orc.lib().orc_fix_nve_wall_final(a, 0.0, 1.0, 1)  # dt = 0: the reflection alone
+    A = sim.arrays()
+    lo, hi = l0 < 0.0, l0 > 1.0
+    assert np.array_equal(A["ucgl"][lo], -l0[lo]) and np.array_equal(A["ucgl"][hi], 2.0 - l0[hi])
+    assert np.array_equal(A["ucgvl"][lo | hi], -v0[lo | hi]) and np.array_equal(A["ucgvl"][~(lo | hi)], v0[~(lo | hi)])
+    assert np.all((A["ucgl"] >= 0.0) & (A["ucgl"] <= 1.0))
+    orc.lib().orc_fix_nve_wall_initial(a, 0.0, 1.0, 1)
+    A = sim.arrays()
+    assert np.array_equal(A["ucgstate"] == 1, A["ucgl"] >= 0.5)
