@@ -54,6 +54,36 @@ def cpu_baseline(pkg, deck, ncell, nsteps, dt):
                 ns_per_entry=t / nsteps / max(info["nhalf"], 1) * 1e9)
 
 
+def cpu_baseline_threads(pkg, deck, ncell, nsteps, dt, nthreads):
+    """P independent copies of the same scalar loop, one per host thread (the oracle is a C library:
+    ctypes releases the GIL), each on its own periodic ncell^3 box -- what `mpirun -np P` of the
+    reference does per rank, without the halo exchange (so an upper bound for it)."""
+    import threading
+
+    orc = entry.load_oracle()
+    sims = []
+    for t in range(nthreads):  # set-up is serial (the parsers use strtok, as the reference's do)
+        beads = pkg.synth.make_beads(ncell, seed=12345 + t)
+        op = orc.Pair("table_ucgld")
+        op.settings(deck.pair_style_args())
+        op.coeff(deck.pair_coeff_args())
+        op.init(2, 1.0, 1.0)
+        sim = orc.Sim(beads)
+        sim.set_run_params(dt=dt, every=10, delay=0, check=1, mode=0)
+        sim.attach(op, langevin=(1.0, 1.0, 1.0, 48279 + t), nve=True, ucgstate="ld")
+        sim.setup(nsteps)
+        sims.append((sim, op, beads.n))
+    threads = [threading.Thread(target=lambda s=s: s[0].run(nsteps, 0)) for s in sims]
+    t0 = time.perf_counter()
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    t = time.perf_counter() - t0
+    n = sum(s[2] for s in sims)
+    return dict(seconds=t, n=n, steps=nsteps, atom_steps_per_s=n * nsteps / t, threads=nthreads, per_thread=sims[0][2])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -69,6 +99,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-ncell", type=int, default=64)
     ap.add_argument("--cpu-steps", type=int, default=10)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the multi-core baseline (0 = min(cores, 16))")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -224,7 +255,7 @@ def main():
         out["roofline"]["traffic_note"] = "HBM bytes per launch from rocprofv3 PMC (FETCH_SIZE x2 per the gfx950 calibration + WRITE_SIZE), profiles/r01_pair_traffic.json"
     if not args.no_cpu_baseline and args.style == "table_ucgld":
         cb = cpu_baseline(pkg, deck, args.cpu_ncell, args.cpu_steps, dt)
-        out["cpu_baseline"] = {
+        one = {
             "value": cb["atom_steps_per_s"] / n,
             "unit": "timesteps/s",
             "cores": 1,
@@ -233,6 +264,23 @@ def main():
                       f"{cb['steps']} full steps in {cb['seconds']:.2f} s = {cb['atom_steps_per_s']:.4g} bead-steps/s "
                       f"({cb['ns_per_entry']:.1f} ns per half-list entry per step), scaled to {n} beads",
         }
+        nthreads = args.cpu_threads or min(os.cpu_count() or 1, 16)
+        if nthreads > 1:
+            # the reference runs one MPI rank per core: P copies of the same scalar loop, one per thread
+            mt = cpu_baseline_threads(pkg, deck, 40, 2 * args.cpu_steps, dt, nthreads)
+            out["cpu_baseline"] = {
+                "value": mt["atom_steps_per_s"] / n,
+                "unit": "timesteps/s",
+                "cores": nthreads,
+                "kind": "port",
+                "sample": f"{nthreads} host threads, each the oracle's reference-order loop on its own periodic box of "
+                          f"{mt['per_thread']} beads x {mt['steps']} full steps (no halo exchange between them: an upper "
+                          f"bound for mpirun -np {nthreads} of the reference), {mt['seconds']:.2f} s = "
+                          f"{mt['atom_steps_per_s']:.4g} bead-steps/s, scaled to {n} beads",
+                "one_core": one,
+            }
+        else:
+            out["cpu_baseline"] = one
     print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -142,6 +142,12 @@ int ucg_atoms_upload(ucg_ctx *ctx, int nlocal, int nghost, int ntypes, const dou
 /* fields_comm of UCG/atom_vec_ucg.cpp:71: refresh x, ucgstate, ucgl, ucgp of all nall atoms */
 int ucg_atoms_upload_comm(ucg_ctx *ctx, const double *x, const int *ucgstate, const double *ucgl,
                           const double *ucgp);
+/* drop-in fix hooks: refresh owned-atom fields a hook reads from LAMMPS' host arrays (any pointer may
+ * be NULL = keep the device value); x/v/f are [nlocal][3], ucgsoftmaxscores [nlocal][2] */
+int ucg_atoms_upload_owned(ucg_ctx *ctx, const double *x, const double *v, const double *f,
+                           const int *ucgstate, const int *num_ucgstates, const double *ucgl,
+                           const double *ucgvl, const double *ucgp, const double *ucgforce,
+                           const double *ucgsoftmaxscores);
 /* any pointer may be NULL; arrays are nlocal long (x: nlocal+nghost if with_ghosts) */
 int ucg_atoms_download(ucg_ctx *ctx, int with_ghosts, double *x, double *v, double *f, int *type,
                        int *tag, int *ucgstate, int *num_ucgstates, double *ucgl, double *ucgvl,

@@ -36,7 +36,7 @@ SYMBOLS = [
     "ucg_pair_cut", "ucg_pair_cutforce", "ucg_pair_gather_slots", "ucg_pair_single", "ucg_pair_table_count",
     "ucg_pair_table_params", "ucg_pair_table_array", "ucg_pair_tabindex", "ucg_pair_compute",
     "ucg_pair_check_errors",
-    "ucg_atoms_upload", "ucg_atoms_upload_comm", "ucg_atoms_download", "ucg_atoms_counts", "ucg_ghosts_upload", "ucg_force_clear",
+    "ucg_atoms_upload", "ucg_atoms_upload_comm", "ucg_atoms_upload_owned", "ucg_atoms_download", "ucg_atoms_counts", "ucg_ghosts_upload", "ucg_force_clear",
     "ucg_neigh_upload_full", "ucg_domain_set", "ucg_neigh_rebuild", "ucg_halo_forward", "ucg_neigh_download",
     "ucg_ghosts_download",
     "ucg_fix_nve_initial", "ucg_fix_nve_final",
@@ -106,6 +106,8 @@ def lib():
     L.ucg_atoms_upload.argtypes = [vp, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p, c_int_p, c_int_p, c_int_p,
                                    c_int_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]
     L.ucg_atoms_upload_comm.argtypes = [vp, c_double_p, c_int_p, c_double_p, c_double_p]
+    L.ucg_atoms_upload_owned.argtypes = [vp, c_double_p, c_double_p, c_double_p, c_int_p, c_int_p, c_double_p,
+                                         c_double_p, c_double_p, c_double_p, c_double_p]
     L.ucg_atoms_download.argtypes = [vp, C.c_int, c_double_p, c_double_p, c_double_p, c_int_p, c_int_p, c_int_p,
                                      c_int_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p, c_double_p]
     L.ucg_atoms_counts.argtypes = [vp, c_int_p, c_int_p]
@@ -302,6 +304,23 @@ class Context:
         sh = np.zeros((max(ng, 1), 3), np.int32)
         self.chk(self.L.ucg_ghosts_download(self.h, _ip(src), _ip(sh), ng))
         return src[:ng], sh[:ng]
+
+    def atoms_upload_owned(self, **fields):
+        """refresh owned-bead fields from host arrays (drop-in fix hooks): x, v, f, ucgstate, num_ucgstates,
+        ucgl, ucgvl, ucgp, ucgforce, scores"""
+        order = ["x", "v", "f", "ucgstate", "num_ucgstates", "ucgl", "ucgvl", "ucgp", "ucgforce", "scores"]
+        keep, args = [], []
+        for k in order:
+            a = fields.pop(k, None)
+            if a is None:
+                args.append(None)
+            elif k in ("ucgstate", "num_ucgstates"):
+                a = _i32(a); keep.append(a); args.append(_ip(a))
+            else:
+                a = _f64(a); keep.append(a); args.append(_dp(a))
+        if fields:
+            raise TypeError(f"unknown fields {sorted(fields)}")
+        self.chk(self.L.ucg_atoms_upload_owned(self.h, *args))
 
     # ---- fix nve/ucgld
     def fix_nve_ucgld_initial_integrate(self, groupbit=1):

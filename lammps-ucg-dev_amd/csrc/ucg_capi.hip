@@ -640,6 +640,52 @@ int ucg_atoms_upload_comm(ucg_ctx *ctx, const double *x, const int *ucgstate, co
   });
 }
 
+int ucg_atoms_upload_owned(ucg_ctx *ctx, const double *x, const double *v, const double *f, const int *ucgstate,
+                           const int *num_ucgstates, const double *ucgl, const double *ucgvl, const double *ucgp,
+                           const double *ucgforce, const double *ucgsoftmaxscores)
+{
+  if (!ctx) return UCG_ERR_INVALID;
+  return guarded(ctx, [&]() -> int {
+    // drop-in fix hooks: LAMMPS owns the host arrays, so what a hook reads is refreshed from them
+    // first.  x/ucgl, v/ucgvl and f/ucgforce share a double4 record: the missing half is kept.
+    const size_t nl = (size_t) ctx->nlocal;
+    if (nl == 0) return UCG_OK;
+    auto merge4 = [&](DevBuf<double4> &buf, const double *a3, const double *w) {
+      if (!a3 && !w) return;
+      std::vector<double4> h(nl);
+      if (!a3 || !w) {
+        d2h(ctx, h.data(), buf.get(), nl);
+        sync(ctx);
+      }
+      for (size_t i = 0; i < nl; i++) {
+        if (a3) {
+          h[i].x = a3[3 * i];
+          h[i].y = a3[3 * i + 1];
+          h[i].z = a3[3 * i + 2];
+        }
+        if (w) h[i].w = w[i];
+      }
+      h2d(ctx, buf.get(), h.data(), nl);
+      sync(ctx);
+    };
+    merge4(ctx->pos4, x, ucgl);
+    merge4(ctx->vel4, v, ucgvl);
+    merge4(ctx->frc4, f, ucgforce);
+    if (ucgstate) {
+      std::vector<int> meta(nl);
+      d2h(ctx, meta.data(), ctx->meta.get(), nl);
+      sync(ctx);
+      for (size_t i = 0; i < nl; i++) meta[i] = (meta[i] & 0xFFFF) | ((ucgstate[i] & 1) << 16);
+      h2d(ctx, ctx->meta.get(), meta.data(), nl);
+    }
+    if (num_ucgstates) h2d(ctx, ctx->num_ucgstates.get(), num_ucgstates, nl);
+    if (ucgp) h2d(ctx, ctx->ucgp.get(), ucgp, nl);
+    if (ucgsoftmaxscores) h2d(ctx, (double *) ctx->scores.get(), ucgsoftmaxscores, 2 * nl);
+    sync(ctx);
+    return UCG_OK;
+  });
+}
+
 int ucg_atoms_download(ucg_ctx *ctx, int with_ghosts, double *x, double *v, double *f, int *type, int *tag,
                        int *ucgstate, int *num_ucgstates, double *ucgl, double *ucgvl, double *ucgml, double *ucgp,
                        double *ucgforce, double *ucgsoftmaxscores)

@@ -1,0 +1,279 @@
+// USER-UCG/GPU fixes: LAMMPS-side binding of libucg_hip.so -- see fix_ucg_gpu.h.
+//
+// Hook by hook the classes below do what the reference's do (file:line in each method); the
+// arithmetic itself runs in the HIP kernels of csrc/ucg_fix.hip through the C ABI.
+#include "fix_ucg_gpu.h"
+
+#include "atom.h"
+#include "atom_vec_ucg_gpu.h"
+#include "comm.h"
+#include "error.h"
+#include "force.h"
+#include "modify.h"
+#include "pair.h"
+#include "update.h"
+#include "utils.h"
+
+#include "ucg_hip.h"
+
+#include <cstring>
+#include <vector>
+
+using namespace LAMMPS_NS;
+using namespace FixConst;
+
+/* ------------------------------------------------------------------ shared plumbing */
+
+FixUCGGPUBase::FixUCGGPUBase(LAMMPS *lmp, int narg, char **arg) : Fix(lmp, narg, arg)
+{
+  AtomVecUCG::get(lmp);    // "requires ucg atom style" (UCG/fix_ucgstate.cpp:41-43)
+  dynamic_group_allow = 1;
+}
+
+void FixUCGGPUBase::init()
+{
+  // one device context per rank: the pair style's (created in its constructor)
+  int dim = 0;
+  ctx = force->pair ? (ucg_ctx *) force->pair->extract("ucg_ctx", dim) : nullptr;
+  if (!ctx) error->all(FLERR, "USER-UCG/GPU fixes need one of the pair styles table_ucgld / table_ucg_bethe / table_ucg_bethe_density");
+  check(ucg_ctx_set_units(ctx, force->boltz, force->ftm2v, force->mvv2e, update->dt, force->special_lj));
+}
+
+void FixUCGGPUBase::check(int rc)
+{
+  if (rc != UCG_OK) error->one(FLERR, ucg_last_error(ctx));
+}
+
+void FixUCGGPUBase::to_device(int fields)
+{
+  auto avec = AtomVecUCG::get(lmp);
+  check(ucg_atoms_upload_owned(ctx, (fields & X) ? &atom->x[0][0] : nullptr, (fields & V) ? &atom->v[0][0] : nullptr,
+                               (fields & F) ? &atom->f[0][0] : nullptr, (fields & STATE) ? avec->ucgstate : nullptr,
+                               (fields & NSTATES) ? avec->num_ucgstates : nullptr, (fields & L) ? avec->ucgl : nullptr,
+                               (fields & VL) ? avec->ucgvl : nullptr, (fields & P) ? avec->ucgp : nullptr,
+                               (fields & LF) ? avec->ucgforce : nullptr,
+                               (fields & SCORES) ? &avec->ucgsoftmaxscores[0][0] : nullptr));
+}
+
+void FixUCGGPUBase::from_device(int fields)
+{
+  auto avec = AtomVecUCG::get(lmp);
+  check(ucg_atoms_download(ctx, 0, (fields & X) ? &atom->x[0][0] : nullptr, (fields & V) ? &atom->v[0][0] : nullptr,
+                           nullptr, nullptr, nullptr, (fields & STATE) ? avec->ucgstate : nullptr, nullptr,
+                           (fields & L) ? avec->ucgl : nullptr, (fields & VL) ? avec->ucgvl : nullptr, nullptr,
+                           (fields & P) ? avec->ucgp : nullptr, (fields & LF) ? avec->ucgforce : nullptr, nullptr));
+}
+
+/* ------------------------------------------------------------------ fix nve/ucgld */
+
+FixNVEUCGLDGPU::FixNVEUCGLDGPU(LAMMPS *lmp, int narg, char **arg) : FixUCGGPUBase(lmp, narg, arg)
+{
+  // UCG/fix_nve_ucgld.cpp:13-20
+  if (utils::strmatch(style, "^nve/ucgld$") && narg > 3)
+    error->all(FLERR, 3, "Unsupported additional arguments for fix {}", style);
+  time_integrate = 1;
+}
+
+int FixNVEUCGLDGPU::setmask()
+{
+  return INITIAL_INTEGRATE | FINAL_INTEGRATE;    // rRESPA hooks of the reference are not offered
+}
+
+void FixNVEUCGLDGPU::init()
+{
+  FixUCGGPUBase::init();
+  if (utils::strmatch(update->integrate_style, "^respa")) error->all(FLERR, "USER-UCG/GPU integrators do not support rRESPA");
+  if (atom->rmass) error->all(FLERR, "USER-UCG/GPU integrators use per-type masses (the reference's else branch)");
+}
+
+void FixNVEUCGLDGPU::reset_dt()
+{
+  check(ucg_ctx_set_units(ctx, force->boltz, force->ftm2v, force->mvv2e, update->dt, force->special_lj));
+}
+
+void FixNVEUCGLDGPU::initial_integrate(int)
+{
+  // UCG/fix_nve_ucgld.cpp:44-101 (wall/hard: UCG/fix_nve_ucgld_wall_hard.cpp:61-136)
+  to_device(X | V | F | L | VL | LF | (wall ? STATE : 0));
+  check(wall ? ucg_fix_nve_wall_hard_initial(ctx, groupbit) : ucg_fix_nve_initial(ctx, groupbit));
+  from_device(X | V | L | VL | (wall ? STATE : 0));
+}
+
+void FixNVEUCGLDGPU::final_integrate()
+{
+  // UCG/fix_nve_ucgld.cpp:104-153 (wall/hard: UCG/fix_nve_ucgld_wall_hard.cpp:139-199)
+  to_device(V | F | L | VL | LF);
+  check(wall ? ucg_fix_nve_wall_hard_final(ctx, groupbit) : ucg_fix_nve_final(ctx, groupbit));
+  from_device(V | VL | (wall ? L : 0));
+}
+
+/* ------------------------------------------------------------------ fix nve/ucgld/wall/hard */
+
+FixNVEUCGLDWallHardGPU::FixNVEUCGLDWallHardGPU(LAMMPS *lmp, int narg, char **arg) : FixNVEUCGLDGPU(lmp, narg, arg)
+{
+  // UCG/fix_nve_ucgld_wall_hard.cpp:12-34
+  if (narg > 5) error->all(FLERR, 3, "Unsupported additional arguments for fix {}", style);
+  wall = true;
+  int iarg = 3;
+  while (iarg < narg) {
+    if (utils::strmatch(arg[iarg], "bias_potential")) {
+      bias_potential_flag = 1;
+      iarg++;
+      if (iarg < narg) barrier = utils::numeric(FLERR, arg[iarg], false, lmp);
+      iarg++;
+    } else
+      error->all(FLERR, "Unknown argument for fix {}", style);
+  }
+}
+
+int FixNVEUCGLDWallHardGPU::setmask()
+{
+  int mask = INITIAL_INTEGRATE | FINAL_INTEGRATE;
+  if (bias_potential_flag) mask |= POST_FORCE;    // :41-52
+  return mask;
+}
+
+void FixNVEUCGLDWallHardGPU::init()
+{
+  FixNVEUCGLDGPU::init();
+  check(ucg_fix_nve_wall_hard_set(ctx, bias_potential_flag, barrier));
+}
+
+void FixNVEUCGLDWallHardGPU::post_force(int)
+{
+  // :223-241
+  to_device(L | LF | F);
+  check(ucg_fix_nve_wall_hard_post_force(ctx, groupbit));
+  from_device(LF);
+}
+
+/* ------------------------------------------------------------------ fix ucgld/langevin */
+
+FixUCGLDLangevinGPU::FixUCGLDLangevinGPU(LAMMPS *lmp, int narg, char **arg) : FixUCGGPUBase(lmp, narg, arg)
+{
+  // UCG/fix_ucgld_langevin.cpp:54-84
+  if (narg < 7) error->all(FLERR, "Illegal fix langevin command");
+  scalar_flag = 1;
+  global_freq = 1;
+  extscalar = 1;
+  nevery = 1;
+  if (utils::strmatch(arg[3], "^v_"))
+    error->all(FLERR, "lambda dynamic variable is not supported with variable temperature");
+  t_start = utils::numeric(FLERR, arg[3], false, lmp);
+  t_target = t_start;
+  t_stop = utils::numeric(FLERR, arg[4], false, lmp);
+  t_period = utils::numeric(FLERR, arg[5], false, lmp);
+  seed = utils::inumeric(FLERR, arg[6], false, lmp);
+  if (t_period <= 0.0) error->all(FLERR, "Fix langevin period must be > 0.0");
+  if (seed <= 0) error->all(FLERR, "Illegal fix langevin command");
+}
+
+int FixUCGLDLangevinGPU::setmask()
+{
+  return POST_FORCE | END_OF_STEP;    // :137-144 without the rRESPA hook
+}
+
+void FixUCGLDLangevinGPU::init()
+{
+  FixUCGGPUBase::init();
+  if (!created) {
+    // RanMars(seed + comm->me), :85
+    check(ucg_fix_langevin_create(ctx, t_start, t_stop, t_period, seed, comm->me));
+    created = true;
+  }
+  // :149-183: the prefactors read atom->ucgml[TYPE INDEX] -- same here
+  auto avec = AtomVecUCG::get(lmp);
+  std::vector<double> ml((size_t) atom->ntypes + 1, 0.0);
+  for (int i = 1; i <= atom->ntypes; i++) ml[(size_t) i] = (i < atom->nlocal) ? avec->ucgml[i] : (atom->nlocal ? avec->ucgml[0] : 1.0);
+  check(ucg_fix_langevin_init_from_ucgml(ctx, atom->ntypes, ml.data()));
+}
+
+void FixUCGLDLangevinGPU::setup(int vflag)
+{
+  post_force(vflag);    // :187-197
+}
+
+void FixUCGLDLangevinGPU::post_force(int)
+{
+  // :226-297 (compute_target :318-353 inside the library: needs the run's begin/end steps)
+  to_device(VL | LF | F);
+  check(ucg_fix_langevin_post_force(ctx, groupbit, update->ntimestep, update->beginstep, update->endstep));
+  t_target = ucg_fix_langevin_t_target(ctx);
+  from_device(LF);
+}
+
+void FixUCGLDLangevinGPU::end_of_step()
+{
+  // :303-312: kinetic temperature of lambda
+  to_device(VL | V);
+  check(ucg_fix_langevin_end_of_step(ctx, groupbit, &lambda_temp));
+}
+
+double FixUCGLDLangevinGPU::compute_scalar()
+{
+  return lambda_temp;    // :403-406
+}
+
+void *FixUCGLDLangevinGPU::extract(const char *str, int &dim)
+{
+  // :412-417: polled by the pair styles and by fix ucgstate
+  dim = 0;
+  if (strcmp(str, "t_target") == 0) return &t_target;
+  return nullptr;
+}
+
+/* ------------------------------------------------------------------ fix ucgstate */
+
+FixUCGStateGPU::FixUCGStateGPU(LAMMPS *lmp, int narg, char **arg) : FixUCGGPUBase(lmp, narg, arg)
+{
+  // UCG/fix_ucgstate.cpp:24-67
+  if (narg > 6) error->all(FLERR, 3, "Too many arguments for fix {}", style);
+  if (narg > 3) {
+    if (utils::strmatch(arg[3], "ld")) ld_flag = 1;
+    else if (utils::strmatch(arg[3], "mc")) {
+      mc_flag = 1;
+      if (narg == 4) error->all(FLERR, 1, "fix ucgstate mc requires seed and rate information");
+      if (narg == 5) error->all(FLERR, 1, "fix ucgstate mc requires rate information");
+      mc_seed = utils::inumeric(FLERR, arg[4], false, lmp);
+      mc_rate = utils::numeric(FLERR, arg[5], false, lmp);
+    } else
+      error->all(FLERR, 1, "Unknown argument for fix {}: {}", style, arg[3]);
+  }
+  time_integrate = 0;
+}
+
+int FixUCGStateGPU::setmask()
+{
+  return POST_FORCE | MIN_POST_FORCE;    // :75-81 without the rRESPA hook
+}
+
+void FixUCGStateGPU::init()
+{
+  FixUCGGPUBase::init();
+  if (!created) {
+    check(ucg_fix_ucgstate_create(ctx, ld_flag, mc_flag, mc_seed, mc_rate, comm->me));    // RanMars(mc_seed + me), :57
+    created = true;
+  }
+}
+
+void FixUCGStateGPU::setup(int vflag)
+{
+  // :142-171: a thermostat exporting t_target must be defined BEFORE this fix
+  double *pT = nullptr;
+  int pdim;
+  for (int ifix = 0; ifix < modify->nfix; ifix++) {
+    pT = (double *) modify->fix[ifix]->extract("t_target", pdim);
+    if (pT) break;
+  }
+  if (pT == nullptr)
+    error->all(FLERR, "FixUCGState requires a thermostat fix BEFORE ITSELF to set the target temperature T.");
+  post_force(vflag);
+}
+
+void FixUCGStateGPU::post_force(int)
+{
+  // :88-132
+  to_device(SCORES | NSTATES | STATE | L);
+  check(ucg_fix_ucgstate_post_force(ctx));
+  from_device(P | (ld_flag ? 0 : (STATE | L)));
+}

@@ -1,0 +1,107 @@
+/* -*- c++ -*- ----------------------------------------------------------
+   USER-UCG/GPU: the UCG fixes backed by libucg_hip.so (include/ucg_hip.h), with the
+   reference's style names and argument lists:
+
+     fix ID group nve/ucgld                                  (UCG/fix_nve_ucgld.h:15-16)
+     fix ID group nve/ucgld/wall/hard [bias_potential [H]]   (UCG/fix_nve_ucgld_wall_hard.h:12)
+     fix ID group ucgld/langevin Tstart Tstop damp seed      (UCG/fix_ucgld_langevin.h:14-17)
+     fix ID group ucgstate [ld | mc seed rate]               (UCG/fix_ucgstate.h:1-3)
+
+   Drop-in mode: LAMMPS owns the host arrays, so every hook refreshes what it reads
+   (ucg_atoms_upload_owned), launches the kernel and copies back what it wrote
+   (ucg_atoms_download).  The device context is the pair style's (Pair::extract("ucg_ctx")).
+   For production runs the whole loop stays resident instead: see `run_style`-level entry
+   ucg_md_run in INTEGRATION.md.
+
+   Compiles only inside a LAMMPS source tree (needs fix.h); see INTEGRATION.md.
+------------------------------------------------------------------------- */
+#ifdef FIX_CLASS
+// clang-format off
+FixStyle(nve/ucgld,FixNVEUCGLDGPU);
+FixStyle(nve/ucgld/wall/hard,FixNVEUCGLDWallHardGPU);
+FixStyle(ucgld/langevin,FixUCGLDLangevinGPU);
+FixStyle(ucgstate,FixUCGStateGPU);
+// clang-format on
+#else
+#ifndef LMP_FIX_UCG_GPU_H
+#define LMP_FIX_UCG_GPU_H
+
+#include "fix.h"
+
+struct ucg_ctx;
+
+namespace LAMMPS_NS {
+
+// shared plumbing: find the pair style's device context, move fields either way
+class FixUCGGPUBase : public Fix {
+ public:
+  FixUCGGPUBase(class LAMMPS *, int, char **);
+  void init() override;
+
+ protected:
+  ucg_ctx *ctx = nullptr;
+  void check(int rc);
+  enum { X = 1, V = 2, F = 4, STATE = 8, NSTATES = 16, L = 32, VL = 64, P = 128, LF = 256, SCORES = 512 };
+  void to_device(int fields);
+  void from_device(int fields);
+};
+
+class FixNVEUCGLDGPU : public FixUCGGPUBase {
+ public:
+  FixNVEUCGLDGPU(class LAMMPS *, int, char **);
+  int setmask() override;
+  void init() override;
+  void initial_integrate(int) override;
+  void final_integrate() override;
+  void reset_dt() override;
+
+ protected:
+  bool wall = false;
+};
+
+class FixNVEUCGLDWallHardGPU : public FixNVEUCGLDGPU {
+ public:
+  FixNVEUCGLDWallHardGPU(class LAMMPS *, int, char **);
+  int setmask() override;
+  void init() override;
+  void post_force(int) override;
+
+ protected:
+  int bias_potential_flag = 0;
+  double barrier = 0.1;
+};
+
+class FixUCGLDLangevinGPU : public FixUCGGPUBase {
+ public:
+  FixUCGLDLangevinGPU(class LAMMPS *, int, char **);
+  int setmask() override;
+  void init() override;
+  void setup(int) override;
+  void post_force(int) override;
+  void end_of_step() override;
+  double compute_scalar() override;
+  void *extract(const char *, int &) override;
+
+ protected:
+  double t_start, t_stop, t_period, t_target, lambda_temp = 0.0;
+  int seed;
+  bool created = false;
+};
+
+class FixUCGStateGPU : public FixUCGGPUBase {
+ public:
+  FixUCGStateGPU(class LAMMPS *, int, char **);
+  int setmask() override;
+  void init() override;
+  void setup(int) override;
+  void post_force(int) override;
+
+ protected:
+  int ld_flag = 0, mc_flag = 0, mc_seed = 0;
+  double mc_rate = 0.01;
+  bool created = false;
+};
+
+}    // namespace LAMMPS_NS
+#endif
+#endif

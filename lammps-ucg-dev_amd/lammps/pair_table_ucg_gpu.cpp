@@ -24,6 +24,7 @@
 
 #include "ucg_hip.h"
 
+#include <cstring>
 #include <vector>
 
 using namespace LAMMPS_NS;
@@ -180,4 +181,12 @@ double PairTableUCGGPU::single(int, int, int itype, int jtype, double rsq, doubl
   double e = 0.0;
   check(ucg_pair_single(gpair, itype, jtype, rsq, factor_lj, &fforce, &e), false);
   return e;
+}
+
+void *PairTableUCGGPU::extract(const char *str, int &dim)
+{
+  // the USER-UCG/GPU fixes share this style's device context (fix_ucg_gpu.cpp)
+  dim = 0;
+  if (strcmp(str, "ucg_ctx") == 0) return (void *) ctx;
+  return nullptr;
 }

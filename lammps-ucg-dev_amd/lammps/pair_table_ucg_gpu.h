@@ -33,6 +33,7 @@ class PairTableUCGGPU : public Pair {
   void init_style() override;
   double init_one(int, int) override;
   double single(int, int, int, int, double, double, double, double &) override;
+  void *extract(const char *, int &) override;
   void write_restart(FILE *) override {}
   void read_restart(FILE *) override {}
 
