@@ -245,6 +245,27 @@ int ucg_fix_ucgstate_create(ucg_ctx *ctx, int ld_flag, int mc_flag, int mc_seed,
                             int me);
 int ucg_fix_ucgstate_post_force(ucg_ctx *ctx);
 
+/* ---------------------------------------------------------------- fix cluster_switch
+ * replaces FixClusterSwitch (UCG/fix_cluster_switch.cpp): constructor + read_file + read_contacts
+ * :37-344, pre_exchange :452-469, check_cluster :551-719, attempt_switch / confirm_molecule /
+ * switch_flag / gather_statistics :721-935, compute_vector :887-897.  Needs atom->molecule
+ * (ucg_atoms_upload_molecule, same order as the last ucg_atoms_upload) and the device-built full
+ * list; single rank.  In the resident loop (ucg_md_run) it forces a re-neighbour every
+ * switch_freq steps, as the reference's force_reneighbor / next_reneighbor do. */
+int ucg_atoms_upload_molecule(ucg_ctx *ctx, const int *molecule);
+int ucg_atoms_download_molecule(ucg_ctx *ctx, int *molecule);
+/* fix ID group cluster_switch mol_seed mol_offset cutoff seed rateFreq switch_freq rateFile F contactFile F */
+int ucg_fix_cluster_switch_create(ucg_ctx *ctx, int groupbit, int mol_seed, int mol_offset, double cutoff,
+                                  int seed, int switch_freq, const char *rate_file,
+                                  const char *contact_file);
+int ucg_fix_cluster_switch_check_cluster(ucg_ctx *ctx);
+int ucg_fix_cluster_switch_attempt_switch(ucg_ctx *ctx);
+int ucg_fix_cluster_switch_maxmol(const ucg_ctx *ctx);
+/* which: 0 mol_cluster, 1 mol_state, 2 mol_restrict, 3 mol_accept; out has maxmol+1 entries */
+int ucg_fix_cluster_switch_array(ucg_ctx *ctx, int which, int *out);
+/* compute_vector: attempts, successes, attempts ON, attempts OFF, successes ON, successes OFF, cluster size */
+int ucg_fix_cluster_switch_vector(const ucg_ctx *ctx, double *out7);
+
 /* ------------------------------------------------------- RanMars on the device
  * the upstream generator behind both fixes, exposed for known-answer tests:
  * n draws of RanMars(seed).uniform() (after its constructor warm-up draw) */

@@ -42,6 +42,9 @@ SYMBOLS = [
     "ucg_fix_nve_initial", "ucg_fix_nve_final",
     "ucg_fix_nve_wall_hard_set", "ucg_fix_nve_wall_hard_initial", "ucg_fix_nve_wall_hard_final",
     "ucg_fix_nve_wall_hard_post_force",
+    "ucg_atoms_upload_molecule", "ucg_atoms_download_molecule", "ucg_fix_cluster_switch_create",
+    "ucg_fix_cluster_switch_check_cluster", "ucg_fix_cluster_switch_attempt_switch", "ucg_fix_cluster_switch_maxmol",
+    "ucg_fix_cluster_switch_array", "ucg_fix_cluster_switch_vector",
     "ucg_fix_langevin_create", "ucg_fix_langevin_init", "ucg_fix_langevin_init_from_ucgml",
     "ucg_fix_langevin_post_force", "ucg_fix_langevin_end_of_step", "ucg_fix_langevin_t_target",
     "ucg_fix_ucgstate_create", "ucg_fix_ucgstate_post_force",
@@ -125,6 +128,15 @@ def lib():
     L.ucg_fix_nve_wall_hard_initial.argtypes = [vp, C.c_int]
     L.ucg_fix_nve_wall_hard_final.argtypes = [vp, C.c_int]
     L.ucg_fix_nve_wall_hard_post_force.argtypes = [vp, C.c_int]
+    L.ucg_atoms_upload_molecule.argtypes = [vp, c_int_p]
+    L.ucg_atoms_download_molecule.argtypes = [vp, c_int_p]
+    L.ucg_fix_cluster_switch_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_char_p,
+                                                C.c_char_p]
+    L.ucg_fix_cluster_switch_check_cluster.argtypes = [vp]
+    L.ucg_fix_cluster_switch_attempt_switch.argtypes = [vp]
+    L.ucg_fix_cluster_switch_maxmol.argtypes = [vp]
+    L.ucg_fix_cluster_switch_array.argtypes = [vp, C.c_int, c_int_p]
+    L.ucg_fix_cluster_switch_vector.argtypes = [vp, c_double_p]
     L.ucg_fix_langevin_create.argtypes = [vp, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int]
     L.ucg_fix_langevin_init.argtypes = [vp, C.c_int, c_double_p, c_double_p]
     L.ucg_fix_langevin_init_from_ucgml.argtypes = [vp, C.c_int, c_double_p]
@@ -238,6 +250,8 @@ class Context:
         """all beads owned, no ghosts (the device builder makes the periodic images)"""
         self.atoms_upload(beads.n, 0, beads.ntypes, beads.x, beads.v, beads.type, beads.tag, beads.mask,
                           beads.ucgstate, beads.ucgl, beads.ucgvl, beads.ucgml, beads.ucgp, beads.mass)
+        if getattr(beads, "molecule", None) is not None:
+            self.upload_molecule(beads.molecule)
 
     def atoms_upload_comm(self, x, ucgstate, ucgl, ucgp):
         k = [_f64(x), _i32(ucgstate), _f64(ucgl), _f64(ucgp)]
@@ -328,6 +342,42 @@ class Context:
 
     def fix_nve_ucgld_final_integrate(self, groupbit=1):
         self.chk(self.L.ucg_fix_nve_final(self.h, groupbit))
+
+    # ---- fix cluster_switch
+    def upload_molecule(self, molecule):
+        m = _i32(molecule)
+        self.chk(self.L.ucg_atoms_upload_molecule(self.h, _ip(m)))
+
+    def download_molecule(self):
+        nl, _ = self.counts()
+        out = np.zeros(nl, dtype=np.int32)
+        self.chk(self.L.ucg_atoms_download_molecule(self.h, _ip(out)))
+        return out
+
+    def fix_cluster_switch(self, mol_seed, mol_offset, cutoff, seed, switch_freq, rate_file, contact_file, groupbit=1):
+        self.chk(self.L.ucg_fix_cluster_switch_create(self.h, groupbit, int(mol_seed), int(mol_offset), float(cutoff),
+                                                      int(seed), int(switch_freq), rate_file.encode(),
+                                                      contact_file.encode()))
+
+    def fix_cluster_switch_check_cluster(self):
+        self.chk(self.L.ucg_fix_cluster_switch_check_cluster(self.h))
+
+    def fix_cluster_switch_attempt_switch(self):
+        self.chk(self.L.ucg_fix_cluster_switch_attempt_switch(self.h))
+
+    def fix_cluster_switch_arrays(self):
+        n = self.L.ucg_fix_cluster_switch_maxmol(self.h) + 1
+        out = {}
+        for w, k in enumerate(("mol_cluster", "mol_state", "mol_restrict", "mol_accept")):
+            a = np.zeros(max(n, 1), dtype=np.int32)
+            self.chk(self.L.ucg_fix_cluster_switch_array(self.h, w, _ip(a)))
+            out[k] = a[:n]
+        return out
+
+    def fix_cluster_switch_vector(self):
+        out = np.zeros(7)
+        self.chk(self.L.ucg_fix_cluster_switch_vector(self.h, _dp(out)))
+        return out
 
     # ---- fix nve/ucgld/wall/hard [bias_potential [barrier]]
     def fix_nve_ucgld_wall_hard(self, bias_potential=False, barrier=0.1):

@@ -146,6 +146,7 @@ void ucg_ctx_destroy(ucg_ctx *ctx)
   (void) hipStreamSynchronize(ctx->stream);
   for (auto ev : ctx->prof_ev) (void) hipEventDestroy(ev);
   domain_destroy(ctx);
+  cluster_destroy(ctx);
   if (ctx->own_stream && ctx->stream) (void) hipStreamDestroy(ctx->stream);
   delete ctx;
 }

@@ -83,6 +83,7 @@ struct FixUcgState {
 struct ucg_pair;
 namespace ucg {
 struct Domain;
+struct ClusterSwitch;
 }
 
 struct ucg_ctx {
@@ -103,6 +104,8 @@ struct ucg_ctx {
   ucg::DevBuf<double4> pos4, vel4, frc4;
   ucg::DevBuf<double2> scores;
   ucg::DevBuf<int> meta, tag, mask, num_ucgstates;
+  ucg::DevBuf<int> mol;  // atom->molecule of the owned beads (optional: ucg_atoms_upload_molecule)
+  bool has_mol = false;
   ucg::DevBuf<double> ucgp, ucgml, mass;
   // neighbour list
   ucg::DevBuf<int> neigh, numneigh;
@@ -120,6 +123,9 @@ struct ucg_ctx {
   ucg::FixUcgState ucgst;
   // domain / rebuild (ucg_neigh.hip)
   ucg::Domain *dom = nullptr;
+  int dom_world = 1;
+  // fix cluster_switch (ucg_cluster.hip)
+  ucg::ClusterSwitch *cs = nullptr;
   // resident driver
   ucg_pair *md_pair = nullptr;
   int md_nve = 0;  // 0 none, 1 fix nve/ucgld, 2 fix nve/ucgld/wall/hard
@@ -166,4 +172,7 @@ struct ucg_pair {
 namespace ucg {
 // ucg_neigh.hip
 void domain_destroy(ucg_ctx *ctx);
+void cluster_destroy(ucg_ctx *ctx);
+bool cluster_forces_rebuild(const ucg_ctx *ctx);
+void cluster_pre_exchange(ucg_ctx *ctx);
 }

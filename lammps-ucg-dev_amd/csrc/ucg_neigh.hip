@@ -681,6 +681,7 @@ void sort_owned(ucg_ctx *ctx, bool wrap)
   permute(ctx, n, perm, ctx->num_ucgstates, D.tmpi);
   permute(ctx, n, perm, ctx->ucgml, D.tmpd);
   permute(ctx, n, perm, ctx->ucgp, D.tmpd);
+  if (ctx->has_mol) permute(ctx, n, perm, ctx->mol, D.tmpi);
   D.bin_of.reserve((size_t) n);
   hipLaunchKernelGGL(k_bins_from_pos, dim3(nblk(n)), dim3(NB), 0, st, dd, n, 0, ctx->pos4.get(), D.bin_of.get());
 
@@ -851,8 +852,10 @@ void halo_forward(ucg_ctx *ctx)
 
 bool decide(ucg_ctx *ctx)
 {
-  // upstream Neighbor::decide()
+  // upstream Neighbor::decide(): a fix with force_reneighbor (fix cluster_switch) whose
+  // next_reneighbor is this step forces the build before `ago` is incremented
   Domain &D = *ctx->dom;
+  if (cluster_forces_rebuild(ctx)) return true;
   D.ago++;
   if (D.ago >= D.delay && D.ago % D.every == 0) {
     if (D.check == 0) return true;
@@ -1164,6 +1167,7 @@ int ucg_domain_set(ucg_ctx *ctx, const double *boxlo, const double *boxhi, doubl
     }
     D.me = 0;
     D.world = 1;
+    ctx->dom_world = 1;
     D.cutforce = cutforce;
     D.skin = skin;
     D.cutneigh = cutforce + skin;
@@ -1286,8 +1290,16 @@ int ucg_md_run(ucg_ctx *ctx, long long nsteps, int thermo_every)
       return rc;
     initial_done = false;
     rc = guarded(ctx, [&]() -> int {
-      if (decide(ctx)) rebuild(ctx);
-      else halo_forward(ctx);
+      if (decide(ctx)) {
+        rebuild(ctx);
+        // FixClusterSwitch::pre_exchange (UCG/fix_cluster_switch.cpp:452-469): its own exchange /
+        // borders / build and Verlet's see the same positions, so one rebuild serves both
+        if (cluster_forces_rebuild(ctx)) {
+          cluster_pre_exchange(ctx);
+          halo_forward(ctx);  // comm->forward_comm(this): the ghosts' new types
+        }
+      } else
+        halo_forward(ctx);
       return UCG_OK;
     });
     if (rc) return rc;
@@ -1342,6 +1354,7 @@ int ucg_decomp_set(ucg_ctx *ctx, const int *procgrid, int me)
     if (procgrid[0] < 1 || procgrid[1] < 1 || procgrid[2] < 1 || me < 0 || me >= world)
       throw InputError{"Bad processor grid"};
     D.world = world;
+    ctx->dom_world = world;
     D.me = me;
     for (int d = 0; d < 3; d++) D.procgrid[d] = procgrid[d];
     D.myloc[0] = me % procgrid[0];

@@ -136,6 +136,80 @@ def make_deck(workdir: str, tabstyle: str = "spline", tablength: int = 1024, mu=
 
 
 @dataclass
+class MultiDeck:
+    """A deck with several ACTUAL atom types, each with two formal types: actual type a (1-based) has the
+    formal types (2a-1, 2a); atom->ntypes = 2 * n_actual.  One pair_coeff command per actual pair i <= j."""
+    workdir: str
+    table_file: str
+    conf_file: str
+    n_actual: int
+    tabstyle: str = "spline"
+    tablength: int = 1024
+    cut: float = 2.5
+    extra_keywords: tuple = ()
+
+    @property
+    def ntypes(self):
+        return 2 * self.n_actual
+
+    def pair_style_args(self):
+        return [self.tabstyle, str(self.tablength), self.conf_file, *self.extra_keywords]
+
+    def pair_coeff_commands(self):
+        """argument lists of `pair_coeff i j Ns_i Ns_j (file keyword cutoff) x 4` (UCG/pair_table_ucgld.cpp:719-745)"""
+        cmds = []
+        for i in range(1, self.n_actual + 1):
+            for j in range(i, self.n_actual + 1):
+                args = [str(i), str(j), "2", "2"]
+                for a in (0, 1):
+                    for b in (0, 1):
+                        args += [self.table_file, f"P{i}{j}_{a}{b}", repr(float(self.cut))]
+                cmds.append(args)
+        return cmds
+
+
+def make_multi_deck(workdir: str, n_actual: int = 2, tabstyle: str = "spline", tablength: int = 1024,
+                    mu=(0.0, 0.5), n_file: int = 1200, rlo: float = 0.6, rhi: float = 2.5, cut: float = 2.5,
+                    extra_keywords=()) -> MultiDeck:
+    """n_actual two-state atom types; the LJ-like well depths of DEFAULT_EPS are scaled per actual pair so that
+    every one of the 4 * n_actual (n_actual + 1) / 2 tables is different (u_ab of pair (i, j), i < j, is NOT
+    symmetric in the states: state a belongs to type i, state b to type j)."""
+    os.makedirs(workdir, exist_ok=True)
+    sections = {}
+    for i in range(1, n_actual + 1):
+        for j in range(i, n_actual + 1):
+            scale = 1.0 - 0.12 * (j - i) - 0.05 * (i + j - 2)
+            for a in (0, 1):
+                for b in (0, 1):
+                    eps = DEFAULT_EPS[f"{a}{b}"] * scale * (1.0 + (0.07 * (a - b) if i != j else 0.0))
+                    sections[f"P{i}{j}_{a}{b}"] = (eps, 0.0)
+    tfile = write_table_file(os.path.join(workdir, "ucg_multi.table"), sections, n_file, rlo, rhi, "R")
+    cfile = os.path.join(workdir, "ucg_multi.conf")
+    with open(cfile, "w") as fh:
+        fh.write(f"{n_actual} {2 * n_actual} 2\n")
+        for a in range(1, n_actual + 1):
+            fh.write(f"{a} 2\n{2 * a - 1} {2 * a}\n{float(mu[0] + 0.1 * (a - 1))!r} {float(mu[1] - 0.05 * (a - 1))!r}\n")
+    return MultiDeck(workdir, tfile, cfile, n_actual, tabstyle, tablength, cut, tuple(extra_keywords))
+
+
+def write_cluster_switch_files(workdir: str, prob_on: float, types_on, types_off, contacts):
+    """rates file (probON / nSwitchTypes / ON types / OFF types) and contact-map file
+    (label nContactTypes / label nAtomsPerContact / one type pair per line), UCG/fix_cluster_switch.cpp:207-344"""
+    os.makedirs(workdir, exist_ok=True)
+    rates = os.path.join(workdir, "rates.txt")
+    with open(rates, "w") as fh:
+        fh.write(f"{float(prob_on)!r}\n{len(types_on)}\n")
+        fh.write(" ".join(str(int(t)) for t in types_on) + "\n")
+        fh.write(" ".join(str(int(t)) for t in types_off) + "\n")
+    cfile = os.path.join(workdir, "contacts.txt")
+    with open(cfile, "w") as fh:
+        fh.write(f"nContactTypes {len(contacts)}\nnAtomsPerContact 1\n")
+        for a, b in contacts:
+            fh.write(f"{int(a)} {int(b)}\n")
+    return rates, cfile
+
+
+@dataclass
 class Beads:
     """Per-bead arrays in the layout LAMMPS hands to a pair style (AoS x[n][3])."""
     n: int
@@ -153,6 +227,7 @@ class Beads:
     ucgp: np.ndarray     # [n] f64 (-1 = unassigned, data_atom_post)
     mass: np.ndarray = field(default_factory=lambda: np.array([0.0, 1.0, 1.0]))  # per type, 1-based
     ntypes: int = 2
+    molecule: np.ndarray = None  # [n] i32 molecule id (atom->molecule), optional
 
 
 def make_beads(ncell: int, rho: float = 0.8, jitter: float = 0.1, temp: float = 1.0, seed: int = 12345,

@@ -140,6 +140,18 @@ def lib():
     L.orc_sim_run.argtypes = [C.c_void_p, C.c_longlong, C.c_int]
     L.orc_sim_set_run_params.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int]
     L.orc_sim_set_wall_barrier.argtypes = [C.c_void_p, C.c_double]
+    L.orc_sim_molecule.argtypes = [C.c_void_p]
+    L.orc_sim_molecule.restype = c_int_p
+    L.orc_sim_cluster_switch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_char_p, C.c_char_p]
+    L.orc_sim_cluster_switch.restype = C.c_char_p
+    L.orc_sim_cs.argtypes = [C.c_void_p]
+    L.orc_sim_cs.restype = C.c_void_p
+    L.orc_cs_maxmol.argtypes = [C.c_void_p]
+    L.orc_cs_array.argtypes = [C.c_void_p, C.c_int]
+    L.orc_cs_array.restype = c_int_p
+    L.orc_cs_stats.argtypes = [C.c_void_p, c_double_p]
+    L.orc_cs_check_cluster.argtypes = [C.c_void_p, C.POINTER(Atoms), c_int_p, C.POINTER(NList)]
+    L.orc_cs_attempt_switch.argtypes = [C.c_void_p, C.POINTER(Atoms), c_int_p]
     L.orc_sim_set_units.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double]
     L.orc_sim_attach.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_int, C.c_double]
@@ -324,6 +336,8 @@ class Sim:
         for name in ("ucgl", "ucgvl", "ucgml", "ucgp"):
             np.ctypeslib.as_array(getattr(a, name), shape=(n,))[:] = getattr(beads, name)
         np.ctypeslib.as_array(L.orc_sim_mass(self.h), shape=(beads.ntypes + 1,))[:] = beads.mass
+        mol = getattr(beads, "molecule", None)
+        np.ctypeslib.as_array(L.orc_sim_molecule(self.h), shape=(n,))[:] = beads.tag if mol is None else mol
         self.pair = None
         self.lang = None
 
@@ -400,7 +414,26 @@ class Sim:
             out[name] = np.ctypeslib.as_array(getattr(a, name), shape=(n,)).copy()
         for name in ("ucgvl", "ucgml"):
             out[name] = np.ctypeslib.as_array(getattr(a, name), shape=(a.nlocal,)).copy()
+        out["molecule"] = np.ctypeslib.as_array(self.L.orc_sim_molecule(self.h), shape=(n,)).copy()
         out["nlocal"], out["nghost"] = a.nlocal, a.nghost
+        return out
+
+    # ---- fix cluster_switch (orc_cluster.c)
+    def cluster_switch(self, mol_seed, mol_offset, cutoff, seed, switch_freq, rate_file, contact_file):
+        err = self.L.orc_sim_cluster_switch(self.h, int(mol_seed), int(mol_offset), float(cutoff), int(seed),
+                                            int(switch_freq), rate_file.encode(), contact_file.encode())
+        if err:
+            raise ValueError(err.decode())
+
+    def cs_arrays(self):
+        cs = self.L.orc_sim_cs(self.h)
+        n = self.L.orc_cs_maxmol(cs) + 1
+        names = ("mol_cluster", "mol_state", "mol_restrict", "mol_accept")
+        return {k: np.ctypeslib.as_array(self.L.orc_cs_array(cs, w), shape=(n,)).copy() for w, k in enumerate(names)}
+
+    def cs_stats(self):
+        out = np.zeros(7)
+        self.L.orc_cs_stats(self.L.orc_sim_cs(self.h), _dp(out))
         return out
 
     def ghost_map(self):

@@ -87,6 +87,7 @@ void orc_sim_grow(orc_sim *s, int nmax)
   s->ghost_src = (int *) xrealloc(s->ghost_src, n * sizeof(int));
   s->ghost_shift = (int *) xrealloc(s->ghost_shift, 3 * n * sizeof(int));
   s->bin_of = (int *) xrealloc(s->bin_of, n * sizeof(int));
+  s->molecule = (int *) xrealloc(s->molecule, n * sizeof(int));
   for (int i = s->nmax; i < nmax; i++) {
     a->num_ucgstates[i] = 0;
     a->ucgforce[i] = 0.0;
@@ -103,7 +104,8 @@ void orc_sim_destroy(orc_sim *s)
   free(a->x); free(a->v); free(a->f); free(a->type); free(a->tag); free(a->mask);
   free(a->ucgstate); free(a->num_ucgstates); free(a->ucgl); free(a->ucgvl); free(a->ucgml);
   free(a->ucgp); free(a->ucgforce); free(a->scores); free(a->mass);
-  free(s->xhold); free(s->ghost_src); free(s->ghost_shift); free(s->bin_of);
+  free(s->xhold); free(s->ghost_src); free(s->ghost_shift); free(s->bin_of); free(s->molecule);
+  orc_cs_destroy(s->cs);
   free(s->binstart_owned); free(s->binstart_ghost);
   free(s->full.ilist); free(s->full.numneigh); free(s->full.first); free(s->full.neigh);
   free(s->half.ilist); free(s->half.numneigh); free(s->half.first); free(s->half.neigh);
@@ -226,6 +228,7 @@ static void sort_owned(orc_sim *s)
   permute_i(a->mask, r, n, ti);
   permute_i(a->ucgstate, r, n, ti);
   permute_i(a->num_ucgstates, r, n, ti);
+  permute_i(s->molecule, r, n, ti);
   for (int i = 0; i < n; i++) s->bin_of[i] = r[i].bin;
   free(td);
   free(ti);
@@ -282,6 +285,7 @@ static void build_ghosts(orc_sim *s)
     a->tag[n + g] = a->tag[src];
     a->type[n + g] = a->type[src];
     a->mask[n + g] = a->mask[src];
+    s->molecule[n + g] = s->molecule[src];
   }
   free(r);
   orc_sim_forward_comm(s);
@@ -300,6 +304,7 @@ void orc_sim_forward_comm(orc_sim *s)
     a->ucgstate[n + g] = a->ucgstate[src];
     a->ucgl[n + g] = a->ucgl[src];
     a->ucgp[n + g] = a->ucgp[src];
+    if (s->cs) a->type[n + g] = a->type[src]; /* fix cluster_switch forwards atom->type (UCG/fix_cluster_switch.cpp:498-527) */
   }
 }
 
@@ -481,7 +486,9 @@ static int check_distance(const orc_sim *s)
 
 static int decide(orc_sim *s)
 {
-  /* upstream Neighbor::decide() */
+  /* upstream Neighbor::decide(): a fix with force_reneighbor whose next_reneighbor is this step
+     forces the build before `ago` is even incremented */
+  if (s->cs && s->cs->next_reneighbor == s->ntimestep) return 1;
   s->ago++;
   if (s->ago >= s->delay && s->ago % s->every == 0) {
     if (s->check == 0) return 1;
@@ -547,8 +554,20 @@ int orc_sim_run(orc_sim *s, long long nsteps, int thermo_every)
     const int ev = (thermo_every > 0 && (s->ntimestep % thermo_every == 0)) ? 1 : 0;
     if (s->have_nve == 1) orc_fix_nve_initial(&s->a, s->dt, s->ftm2v, s->groupbit);
     else if (s->have_nve >= 2) orc_fix_nve_wall_initial(&s->a, s->dt, s->ftm2v, s->groupbit);
-    if (decide(s)) orc_sim_rebuild(s);
-    else orc_sim_forward_comm(s);
+    if (decide(s)) {
+      /* FixClusterSwitch::pre_exchange (UCG/fix_cluster_switch.cpp:452-469) runs before Verlet's own
+         exchange / borders / build; both rebuilds see the same positions, so one is done here */
+      orc_sim_rebuild(s);
+      if (s->cs && s->cs->next_reneighbor == s->ntimestep) {
+        if (s->cs->switchFreq != 0) {
+          orc_cs_check_cluster(s->cs, &s->a, s->molecule, &s->full);
+          if (orc_cs_attempt_switch(s->cs, &s->a, s->molecule)) return 1;
+          orc_sim_forward_comm(s); /* comm->forward_comm(this): types of the ghosts */
+          s->cs->next_reneighbor = s->ntimestep + s->cs->switchFreq;
+        }
+      }
+    } else
+      orc_sim_forward_comm(s);
     int rc = compute_forces(s, ev, ev);
     if (rc) rc_any = rc;
     integrator_post_force(s);
@@ -589,6 +608,18 @@ void orc_sim_attach(orc_sim *s, orc_pair *pair, orc_fix_langevin *lang, int have
 }
 
 void orc_sim_set_wall_barrier(orc_sim *s, double barrier) { s->wall_barrier = barrier; }
+
+int *orc_sim_molecule(orc_sim *s) { return s->molecule; }
+orc_cluster_switch *orc_sim_cs(orc_sim *s) { return s->cs; }
+
+const char *orc_sim_cluster_switch(orc_sim *s, int mol_seed, int mol_offset, double cutoff, int seed, int switchFreq,
+                                   const char *rateFile, const char *contactFile)
+{
+  orc_cs_destroy(s->cs);
+  s->cs = orc_cs_create(&s->a, s->molecule, s->ntypes, s->groupbit, mol_seed, mol_offset, cutoff, seed, switchFreq,
+                        rateFile, contactFile, s->ntimestep);
+  return orc_cs_error(s->cs);
+}
 
 void orc_sim_get_info(const orc_sim *s, long long *out)
 {

@@ -3,6 +3,7 @@
 #define ORC_MD_H
 
 #include "orc.h"
+#include "orc_cluster.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -35,6 +36,8 @@ typedef struct {
   orc_fix_ucgstate ucgst;
   int have_ucgstate, have_nve;  /* have_nve: 0 none, 1 nve/ucgld, 2 nve/ucgld/wall/hard, 3 the same with bias_potential */
   double wall_barrier;
+  int *molecule;               /* [nall] molecule id (atom->molecule); default = tag */
+  orc_cluster_switch *cs;      /* borrowed, may be NULL: fix cluster_switch */
 
   long long ntimestep, beginstep, endstep;
   int ago, nrebuild, pair_errors;
@@ -57,6 +60,11 @@ int orc_sim_run(orc_sim *s, long long nsteps, int thermo_every);
 void orc_sim_set_run_params(orc_sim *s, double dt, int every, int delay, int check, int mode);
 void orc_sim_set_units(orc_sim *s, double boltz, double ftm2v, double mvv2e);
 void orc_sim_set_wall_barrier(orc_sim *s, double barrier);
+int *orc_sim_molecule(orc_sim *s);
+/* fix cluster_switch on this run (created from the sim's current atoms); returns NULL-error or message */
+const char *orc_sim_cluster_switch(orc_sim *s, int mol_seed, int mol_offset, double cutoff, int seed, int switchFreq,
+                                   const char *rateFile, const char *contactFile);
+orc_cluster_switch *orc_sim_cs(orc_sim *s);
 void orc_sim_attach(orc_sim *s, orc_pair *pair, orc_fix_langevin *lang, int have_nve,
                     int have_ucgstate, int ld_flag, int mc_flag, int mc_seed, double mc_rate);
 void orc_sim_get_info(const orc_sim *s, long long *out);

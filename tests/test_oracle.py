@@ -325,3 +325,70 @@ def test_wall_hard_reflects_lambda_and_sets_states(orc, pkg):
     orc.lib().orc_fix_nve_wall_initial(a, 0.0, 1.0, 1)
     A = sim.arrays()
     assert np.array_equal(A["ucgstate"] == 1, A["ucgl"] >= 0.5)
+
+
+def test_cluster_switch_labels_are_connected_components(orc, pkg):
+    """with mol_offset = 0 the cluster of mol_seed is the connected component of the contact graph
+    (allowed type pair, distance below the cutoff, minimum image) -- checked with a brute-force union-find"""
+    deck = util.make_multi_deck(2, "spline", 128)
+    beads = util.multi_type_beads(pkg, 7, 2, seed=21, molecule_size=2)
+    cutoff = 1.2
+    rates, contacts = pkg.synth.write_cluster_switch_files(deck.workdir, 0.3, [1], [2], [(1, 1)])
+    mol_seed = int(beads.molecule[np.flatnonzero(beads.type == 1)[0]])
+    op = util.oracle_pair_multi("table_ucgld", deck)
+    sim = util.oracle_sim(beads, op, mode=1)
+    sim.rebuild()
+    sim.cluster_switch(mol_seed, 0, cutoff, 7, 5, rates, contacts)
+    L = orc.lib()
+    cs = L.orc_sim_cs(sim.h)
+    assert L.orc_cs_check_cluster(cs, L.orc_sim_atoms(sim.h), L.orc_sim_molecule(sim.h), L.orc_sim_full_list(sim.h)) == 0
+    lab = sim.cs_arrays()["mol_cluster"]
+    # brute force
+    A = sim.arrays()
+    x, t, m = A["x"][: beads.n], A["type"][: beads.n], A["molecule"][: beads.n]
+    prd = beads.boxhi - beads.boxlo
+    parent = np.arange(m.max() + 1)
+
+    def find(a):
+        while parent[a] != a:
+            parent[a] = parent[parent[a]]
+            a = parent[a]
+        return a
+
+    on = np.flatnonzero(t == 1)
+    for ii, i in enumerate(on):
+        d = x[on[ii + 1:]] - x[i]
+        d -= prd * np.round(d / prd)
+        close = on[ii + 1:][(d * d).sum(axis=1) < cutoff * cutoff]
+        for j in close:
+            a, b = find(m[i]), find(m[j])
+            if a != b:
+                parent[max(a, b)] = min(a, b)
+    comp = np.array([find(k) for k in range(m.max() + 1)])
+    mols = np.unique(m)
+    assert np.array_equal(lab[mols] == lab[mol_seed], comp[mols] == comp[mol_seed])
+    # every component carries its smallest molecule id as the label
+    assert np.array_equal(lab[mols], comp[mols])
+    st = sim.cs_arrays()
+    inside = lab[mols] == lab[mol_seed]
+    assert np.all(st["mol_restrict"][mols[inside]] == -1) and np.all(st["mol_state"][mols[inside]] == 1)
+    assert np.all(st["mol_restrict"][mols[~inside]] == 1)
+
+
+def test_cluster_switch_acceptance_rates(orc, pkg):
+    deck = util.make_multi_deck(2, "spline", 128)
+    beads = util.multi_type_beads(pkg, 8, 2, seed=2, molecule_size=1)
+    rates, contacts = pkg.synth.write_cluster_switch_files(deck.workdir, 0.25, [1], [2], [(1, 1)])
+    mol_seed = int(beads.molecule[np.flatnonzero(beads.type == 1)[0]])
+    op = util.oracle_pair_multi("table_ucgld", deck)
+    sim = util.oracle_sim(beads, op, mode=1)
+    sim.rebuild()
+    sim.cluster_switch(mol_seed, 0, 1.0, 31337, 5, rates, contacts)
+    L = orc.lib()
+    cs = L.orc_sim_cs(sim.h)
+    L.orc_cs_check_cluster(cs, L.orc_sim_atoms(sim.h), L.orc_sim_molecule(sim.h), L.orc_sim_full_list(sim.h))
+    assert L.orc_cs_attempt_switch(cs, L.orc_sim_atoms(sim.h), L.orc_sim_molecule(sim.h)) == 0
+    att, suc, att_on, att_off, suc_on, suc_off, ncl = sim.cs_stats()
+    assert att == att_on + att_off and suc == suc_on + suc_off and att > 300
+    # probON = 0.25 for OFF -> ON, probOFF = 0.75 for ON -> OFF (RanPark draws)
+    assert abs(suc_on / att_on - 0.25) < 0.08 and abs(suc_off / att_off - 0.75) < 0.08

@@ -68,3 +68,42 @@ def max_ulp(a, b):
     ia[ia < 0] = np.int64(-2**63) - ia[ia < 0]
     ib[ib < 0] = np.int64(-2**63) - ib[ib < 0]
     return int(np.abs(ia - ib).max()) if a.size else 0
+
+
+def make_multi_deck(n_actual=2, tabstyle="spline", tablength=256, **kw):
+    pkg = load_package()
+    return pkg.synth.make_multi_deck(tempfile.mkdtemp(prefix="ucgmdeck_"), n_actual, tabstyle, tablength, **kw)
+
+
+def multi_type_beads(pkg, ncell, n_actual, seed, molecule_size=1):
+    """beads of several actual atom types (random), masses for 2 * n_actual formal types, molecule ids"""
+    beads = pkg.synth.make_beads(ncell, seed=seed)
+    rng = np.random.default_rng(seed + 1000)
+    beads.ntypes = 2 * n_actual
+    beads.mass = np.concatenate([[0.0], 1.0 + 0.25 * np.arange(2 * n_actual)])
+    beads.molecule = ((beads.tag - 1) // molecule_size + 1).astype(np.int32)
+    # one type per molecule, so that a molecule is wholly ON or OFF
+    mtype = rng.integers(1, n_actual + 1, size=beads.molecule.max() + 1)
+    beads.type = mtype[beads.molecule].astype(np.int32)
+    return beads
+
+
+def oracle_pair_multi(style, deck, T=1.0, slots=GATHER_SLOTS):
+    orc = load_oracle()
+    p = orc.Pair(style)
+    p.settings(deck.pair_style_args())
+    for cmd in deck.pair_coeff_commands():
+        p.coeff(cmd, deck.ntypes)
+    p.init(deck.ntypes, T, 1.0)
+    p.set_gather_slots(slots)
+    return p
+
+
+def gpu_pair_multi(ctx, style, deck, T=1.0):
+    pkg = load_package()
+    p = pkg.capi.Pair(ctx, style)
+    p.settings(deck.pair_style_args())
+    for cmd in deck.pair_coeff_commands():
+        p.coeff(cmd, deck.ntypes)
+    p.init(deck.ntypes, T)
+    return p
