@@ -491,9 +491,10 @@ int ucg_pair_compute(ucg_pair *p, int eflag, int vflag, double *eng_vdwl, double
     if (ctx->list_inum != ctx->nlocal) return fail(ctx, UCG_ERR_INVALID, "neighbour list does not match the resident atoms");
     const bool ev = (eflag || vflag);
     if (ctx->gather_slots == 0) {
-      // auto: enough lanes per bead to give every CU at least ~2 workgroups (small per-GPU shares)
+      // auto: one lane per bead while that still gives every CU a workgroup (measured on MI355X: best
+      // down to ~250 k beads per GPU); below that, 4, 8, 16 lanes per bead (125 k beads: 4)
       int slots = 1;
-      while (slots < 16 && (long long) ctx->nlocal * slots < 2LL * 256 * 1024) slots = (slots == 1) ? 4 : slots * 2;
+      while (slots < 16 && (long long) ctx->nlocal * slots < 230000) slots = (slots == 1) ? 4 : slots * 2;
       p->dev.gather_slots = slots;
       const size_t own = (size_t) (1024 / slots) * 36;
       p->dev.stage_own = (ctx->stage_own && (p->dev.tab_in_lds ? p->tab_lds_bytes : 0) + own + 6 * 1024 <= 160 * 1024) ? 1 : 0;
