@@ -130,6 +130,15 @@ int ucg_pair_compute(ucg_pair *p, int eflag, int vflag, double *eng_vdwl, double
 /* device-side table-range violations of the last compute (0 = none); the glue
  * turns a nonzero return into error->one() like UCG/pair_table_ucgld.cpp:437-444 */
 int ucg_pair_check_errors(ucg_pair *p);
+/* table_ucg_bethe_density on a decomposed run: the three passes of compute() one at a time
+ * (phase 1 :219-274 local densities and priors, 2 :284-664 pair forces and CV force accumulators,
+ * 3 :669-734 posterior + CV back-force); between them the caller forwards the ghosts' entries of
+ * buffer 0 (priors, after phase 1) and buffer 1 (CV forces, after phase 2) from their owner ranks
+ * with ucg_halo_aux_pack / ucg_halo_aux_unpack -- the halo the reference's no-op forward_comm
+ *  was meant to be.  ucg_pair_density_buffer returns a DEVICE pointer
+ * (double2 per owned + ghost bead). */
+int ucg_pair_density_phase(ucg_pair *p, int phase, int eflag, int vflag, double *eng_vdwl, double *virial);
+void *ucg_pair_density_buffer(ucg_pair *p, int which);
 
 /* ------------------------------------------------------------- atoms (AtomVecUCG)
  * replaces the per-atom fields of atom style "ucg": UCG/atom_vec_ucg.cpp:48-90,
@@ -203,6 +212,10 @@ int ucg_border_unpack(ucg_ctx *ctx, const void *recvbuf, long long nrecv);
 int ucg_halo_pack(ucg_ctx *ctx, void *sendbuf);
 int ucg_halo_unpack(ucg_ctx *ctx, const void *recvbuf);
 /* Neighbor::decide(): *due = a check is scheduled this step, *flag = a local bead moved > skin/2 */
+/* forward halo of one double2 per bead with the send lists of the last ucg_border_pack
+ * (16 bytes per ghost, grouped by destination rank like ucg_halo_pack) */
+int ucg_halo_aux_pack(ucg_ctx *ctx, const void *field_dev, void *sendbuf);
+int ucg_halo_aux_unpack(ucg_ctx *ctx, void *field_dev, const void *recvbuf);
 int ucg_decide_local(ucg_ctx *ctx, int *due, int *flag);
 
 /* ---------------------------------------------------------------- fix nve/ucgld

@@ -42,6 +42,7 @@ SYMBOLS = [
     "ucg_fix_nve_initial", "ucg_fix_nve_final",
     "ucg_fix_nve_wall_hard_set", "ucg_fix_nve_wall_hard_initial", "ucg_fix_nve_wall_hard_final",
     "ucg_fix_nve_wall_hard_post_force",
+    "ucg_pair_density_phase", "ucg_pair_density_buffer", "ucg_halo_aux_pack", "ucg_halo_aux_unpack",
     "ucg_atoms_upload_molecule", "ucg_atoms_download_molecule", "ucg_fix_cluster_switch_create",
     "ucg_fix_cluster_switch_check_cluster", "ucg_fix_cluster_switch_attempt_switch", "ucg_fix_cluster_switch_maxmol",
     "ucg_fix_cluster_switch_array", "ucg_fix_cluster_switch_vector",
@@ -129,6 +130,11 @@ def lib():
     L.ucg_fix_nve_wall_hard_final.argtypes = [vp, C.c_int]
     L.ucg_fix_nve_wall_hard_post_force.argtypes = [vp, C.c_int]
     L.ucg_atoms_upload_molecule.argtypes = [vp, c_int_p]
+    L.ucg_pair_density_phase.argtypes = [vp, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p]
+    L.ucg_pair_density_buffer.argtypes = [vp, C.c_int]
+    L.ucg_pair_density_buffer.restype = C.c_void_p
+    L.ucg_halo_aux_pack.argtypes = [vp, C.c_void_p, C.c_void_p]
+    L.ucg_halo_aux_unpack.argtypes = [vp, C.c_void_p, C.c_void_p]
     L.ucg_atoms_download_molecule.argtypes = [vp, c_int_p]
     L.ucg_fix_cluster_switch_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_char_p,
                                                 C.c_char_p]
@@ -426,6 +432,12 @@ class Context:
         self.chk(self.L.ucg_decomp_set(self.h, _ip(g), int(me)))
         self._world = int(g[0] * g[1] * g[2])
 
+    def halo_aux_pack(self, field_dev, sendbuf):
+        self.chk(self.L.ucg_halo_aux_pack(self.h, field_dev, sendbuf))
+
+    def halo_aux_unpack(self, field_dev, recvbuf):
+        self.chk(self.L.ucg_halo_aux_unpack(self.h, field_dev, recvbuf))
+
     def record_bytes(self):
         a, b = C.c_int(0), C.c_int(0)
         self.L.ucg_record_bytes(C.byref(a), C.byref(b))
@@ -608,3 +620,14 @@ class Pair:
 
     def check_errors(self):
         self.ctx.chk(self.ctx.L.ucg_pair_check_errors(self.h))
+
+    # table_ucg_bethe_density on a decomposed run: one pass at a time (see multi.RankSim)
+    def density_phase(self, phase, eflag=0, vflag=0):
+        e = C.c_double(0)
+        v = np.zeros(6)
+        self.ctx.chk(self.ctx.L.ucg_pair_density_phase(self.h, phase, eflag, vflag, C.byref(e), _dp(v)))
+        return e.value, v
+
+    def density_buffer(self, which):
+        """device pointer of the priors (0) / CV forces (1): double2 per owned + ghost bead"""
+        return self.ctx.L.ucg_pair_density_buffer(self.h, which)

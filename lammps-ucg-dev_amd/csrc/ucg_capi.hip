@@ -543,6 +543,43 @@ int ucg_pair_compute(ucg_pair *p, int eflag, int vflag, double *eng_vdwl, double
   });
 }
 
+int ucg_pair_density_phase(ucg_pair *p, int phase, int eflag, int vflag, double *eng_vdwl, double *virial)
+{
+  if (!p || !p->ctx || phase < 1 || phase > 3) return UCG_ERR_INVALID;
+  ucg_ctx *ctx = p->ctx;
+  return guarded(ctx, [&]() -> int {
+    if (!p->uploaded || p->model.style != STYLE_BETHE_DENSITY) return fail(ctx, UCG_ERR_INVALID, "not an initialised table_ucg_bethe_density style");
+    if (ctx->list_inum != ctx->nlocal) return fail(ctx, UCG_ERR_INVALID, "no neighbour list for the current beads");
+    const bool ev = (eflag || vflag);
+    if (phase == 1) {
+      const size_t nall = (size_t) ctx->nlocal + ctx->nghost;
+      p->d_prior.reserve(nall + 1);
+      p->d_cv.reserve(nall + 1);
+      p->d_partial.reserve((size_t) ctx->nlocal + 1);
+      p->d_evpart.reserve((size_t) density_evpart_doubles(ctx->nlocal));
+    }
+    UCG_HIP(launch_density_phase(p->dev, ctx->atoms_dev(), ctx->list_dev(), phase, ev, p->d_prior.get(), p->d_partial.get(),
+                                 p->d_cv.get(), p->d_evpart.get(), p->d_evout.get(), p->d_err.get(), ctx->stream));
+    if (phase == 3 && ev) {
+      double out[8];
+      d2h(ctx, out, p->d_evout.get(), 8);
+      sync(ctx);
+      if (eng_vdwl) *eng_vdwl = out[0];
+      if (virial)
+        for (int c = 0; c < 6; c++) virial[c] = out[1 + c];
+      ctx->thermo[0] = out[0];
+      for (int c = 0; c < 6; c++) ctx->thermo[1 + c] = out[1 + c];
+    }
+    return UCG_OK;
+  });
+}
+
+void *ucg_pair_density_buffer(ucg_pair *p, int which)
+{
+  if (!p) return nullptr;
+  return which == 0 ? (void *) p->d_prior.get() : which == 1 ? (void *) p->d_cv.get() : nullptr;
+}
+
 int ucg_pair_check_errors(ucg_pair *p)
 {
   if (!p || !p->ctx) return UCG_ERR_INVALID;

@@ -373,6 +373,38 @@ hipError_t launch_density(const PairDev &P, const AtomsDev &A, const ListDev &L,
   return hipGetLastError();
 }
 
+// the same three passes one at a time, for decomposed runs: the caller refreshes the ghosts' entries of
+// `prior` (after phase 1) and of `cv` (after phase 2) from their owner ranks in between
+hipError_t launch_density_phase(const PairDev &P, const AtomsDev &A, const ListDev &L, int phase, bool ev, double2 *prior,
+                                double *partial0, double2 *cv, double *evpart, double *evout, int *errflag,
+                                hipStream_t st)
+{
+  const int n = A.nlocal;
+  if (n == 0) return hipSuccess;
+  const int nb = (n + DENS_BLOCK - 1) / DENS_BLOCK;
+  const int nb2 = (n + PAIR_BLOCK - 1) / PAIR_BLOCK;
+  if (phase == 1) {
+    hipLaunchKernelGGL(k_density_pass1, dim3(nb), dim3(DENS_BLOCK), 0, st, P, A, L, prior, partial0);
+  } else if (phase == 2) {
+    hipError_t e;
+    switch (P.tabstyle) {
+      case 0: e = launch_pass2<0>(P, A, L, ev, prior, partial0, cv, evpart, errflag, st, nb2); break;
+      case 1: e = launch_pass2<1>(P, A, L, ev, prior, partial0, cv, evpart, errflag, st, nb2); break;
+      default: e = launch_pass2<2>(P, A, L, ev, prior, partial0, cv, evpart, errflag, st, nb2); break;
+    }
+    if (e != hipSuccess) return e;
+  } else {
+    double *evpart3 = evpart + (size_t) nb2 * 8;
+    if (ev) {
+      hipLaunchKernelGGL(k_density_pass3<true>, dim3(nb), dim3(DENS_BLOCK), 0, st, P, A, L, cv, evpart3);
+      hipLaunchKernelGGL(k_ev_final2, dim3(1), dim3(64), 0, st, evpart, nb2, evpart3, nb, evout);
+    } else {
+      hipLaunchKernelGGL(k_density_pass3<false>, dim3(nb), dim3(DENS_BLOCK), 0, st, P, A, L, cv, evpart3);
+    }
+  }
+  return hipGetLastError();
+}
+
 int density_evpart_doubles(int nlocal)
 {
   return 8 * ((nlocal + DENS_BLOCK - 1) / DENS_BLOCK + (nlocal + PAIR_BLOCK - 1) / PAIR_BLOCK) + 16;

@@ -21,6 +21,9 @@ hipError_t launch_selftest_div(double b, unsigned long long seed, int n, unsigne
 hipError_t launch_density(const PairDev &P, const AtomsDev &A, const ListDev &L, const int *ghost_src, bool ev,
                           double2 *prior, double *partial0, double2 *cv, double *evpart, double *evout, int *errflag,
                           hipStream_t st);
+hipError_t launch_density_phase(const PairDev &P, const AtomsDev &A, const ListDev &L, int phase, bool ev, double2 *prior,
+                                double *partial0, double2 *cv, double *evpart, double *evout, int *errflag,
+                                hipStream_t st);
 int density_evpart_doubles(int nlocal);
 
 // ---- ucg_fix.hip

@@ -1078,6 +1078,19 @@ __global__ __launch_bounds__(NB) void k_halo_unpack(int ng, int nlocal, const in
   if (with_tag) tag[nlocal + g] = r.tag;
 }
 
+// auxiliary forward halo of one double2 per bead (the density style's priors / CV forces)
+__global__ __launch_bounds__(NB) void k_halo_aux_pack(int nsend, const int *send_src, const double2 *src, double2 *out)
+{
+  const int j = blockIdx.x * NB + threadIdx.x;
+  if (j < nsend) out[j] = src[send_src[j]];
+}
+
+__global__ __launch_bounds__(NB) void k_halo_aux_unpack(int ng, int nlocal, const int *perm, const double2 *in, double2 *dst)
+{
+  const int g = blockIdx.x * NB + threadIdx.x;
+  if (g < ng) dst[nlocal + g] = in[perm[g]];
+}
+
 void counts_to_host(ucg_ctx *ctx, Domain &D, long long *out)
 {
   std::vector<int> h((size_t) D.world);
@@ -1577,6 +1590,37 @@ int ucg_halo_unpack(ucg_ctx *ctx, const void *recvbuf)
     if (!recvbuf) return UCG_ERR_INVALID;
     hipLaunchKernelGGL(k_halo_unpack, dim3(nblk(ng)), dim3(NB), 0, ctx->stream, ng, ctx->nlocal, D.ghost_perm.get(),
                        (const HaloRec *) recvbuf, ctx->pos4.get(), ctx->meta.get(), ctx->ucgp.get(), ctx->tag.get(), 0);
+    UCG_HIP(hipGetLastError());
+    return UCG_OK;
+  });
+}
+
+int ucg_halo_aux_pack(ucg_ctx *ctx, const void *field_dev, void *sendbuf)
+{
+  if (!ctx || !field_dev) return UCG_ERR_INVALID;
+  if (int rc = need_domain(ctx)) return rc;
+  return guarded(ctx, [&]() -> int {
+    Domain &D = *ctx->dom;
+    if (D.nsend == 0) return UCG_OK;
+    if (!sendbuf) return UCG_ERR_INVALID;
+    hipLaunchKernelGGL(k_halo_aux_pack, dim3(nblk(D.nsend)), dim3(NB), 0, ctx->stream, (int) D.nsend, D.send_src.get(),
+                       (const double2 *) field_dev, (double2 *) sendbuf);
+    UCG_HIP(hipGetLastError());
+    return UCG_OK;
+  });
+}
+
+int ucg_halo_aux_unpack(ucg_ctx *ctx, void *field_dev, const void *recvbuf)
+{
+  if (!ctx || !field_dev) return UCG_ERR_INVALID;
+  if (int rc = need_domain(ctx)) return rc;
+  return guarded(ctx, [&]() -> int {
+    Domain &D = *ctx->dom;
+    const int ng = ctx->nghost;
+    if (ng == 0) return UCG_OK;
+    if (!recvbuf) return UCG_ERR_INVALID;
+    hipLaunchKernelGGL(k_halo_aux_unpack, dim3(nblk(ng)), dim3(NB), 0, ctx->stream, ng, ctx->nlocal, D.ghost_perm.get(),
+                       (const double2 *) recvbuf, (double2 *) field_dev);
     UCG_HIP(hipGetLastError());
     return UCG_OK;
   });

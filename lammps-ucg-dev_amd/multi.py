@@ -119,6 +119,8 @@ class RankSim:
         """integrator: "nve" = fix nve/ucgld, "wall" = fix nve/ucgld/wall/hard (Context.fix_nve_ucgld_wall_hard)"""
         self.ctx, self.pair, self.tr = ctx, pair, transport
         self.nve_kind = 2 if integrator == "wall" else 1
+        self.density = getattr(pair, "style", "") == "table_ucg_bethe_density"
+        self._aux_send = None
         self.grid = list(grid)
         self.me = transport.rank
         self.world = transport.world
@@ -167,8 +169,29 @@ class RankSim:
         ctx.halo_unpack(rb.data_ptr())
         self._keep = rb
 
+    def _aux_halo(self, which):
+        """forward one double2 per ghost (the density style's priors / CV forces) from the owner ranks"""
+        ctx, tr = self.ctx, self.tr
+        if self._aux_send is None or self._aux_send.numel() < 16 * int(self.halo_send_counts.sum()):
+            self._aux_send = self._buf(16 * int(self.halo_send_counts.sum()))
+        field = self.pair.density_buffer(which)
+        ctx.halo_aux_pack(field, self._aux_send.data_ptr())
+        rb = tr.alltoall_bytes(self._aux_send, self.halo_send_counts, self.halo_recv_counts, 16)
+        ctx.halo_aux_unpack(field, rb.data_ptr())
+        self._keep_aux = rb
+
+    def _pair_compute(self, ev):
+        if not self.density:
+            return self.pair.compute(ev, ev)
+        # table_ucg_bethe_density: its two mid-compute halos cross ranks
+        self.pair.density_phase(1, ev, ev)
+        self._aux_halo(0)
+        self.pair.density_phase(2, ev, ev)
+        self._aux_halo(1)
+        return self.pair.density_phase(3, ev, ev)
+
     def _forces_and_post_force(self, ev):
-        out = self.pair.compute(ev, ev)
+        out = self._pair_compute(ev)
         if self.use_langevin:
             self.ctx.fix_ucgld_langevin_post_force(self.ntimestep, self.beginstep, self.endstep, self.groupbit)
         if self.use_ucgstate:
@@ -204,7 +227,7 @@ class RankSim:
                 self.rebuild()
             else:
                 self.halo_forward()
-            out = self.pair.compute(ev, ev)
+            out = self._pair_compute(ev)
             if ev:
                 last = out
             # langevin -> ucgstate -> final_integrate (-> next initial_integrate) as one launch

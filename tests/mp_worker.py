@@ -2,6 +2,7 @@
 
   python mp_worker.py cpu <port> <outdir>   -- gloo on CPU: decomposition + transport protocol
   python mp_worker.py gpu <port> <outdir>   -- gloo (host-staged) with both ranks on ONE GPU
+  python mp_worker.py gpu_density ...       -- the same with table_ucg_bethe_density (two mid-compute halos)
 """
 import os
 import pickle
@@ -47,14 +48,18 @@ def main():
     else:
         capi = pkg.capi
         dt = 0.004
-        deck = util.make_deck("spline", 1024)
+        density = mode == "gpu_density"
+        style = "table_ucg_bethe_density" if density else "table_ucgld"
+        deck = util.make_deck("spline", 1024, **(dict(density=(11.3, 1.5), extra11=0.05) if density else {}))
+        if density:
+            dt = 0.002
         ctx = capi.Context(0, dt=dt)
         sl = slice(rank * beads.n // world, (rank + 1) * beads.n // world)
         n = sl.stop - sl.start
         ctx.atoms_upload(n, 0, beads.ntypes, beads.x[sl], beads.v[sl], beads.type[sl], beads.tag[sl], beads.mask[sl],
                          beads.ucgstate[sl], beads.ucgl[sl], beads.ucgvl[sl], beads.ucgml[sl], beads.ucgp[sl], beads.mass)
         ctx.domain_set(beads.boxlo, beads.boxhi, 2.5, 0.3, every=2, delay=0, check=1)
-        pair = util.gpu_pair(ctx, "table_ucgld", deck)
+        pair = util.gpu_pair(ctx, style, deck)
         tr = multi.Transport(dist, torch.device("cuda", 0), staged=True)
         sim = multi.RankSim(ctx, pair, tr, grid, use_langevin=False, use_ucgstate=False)
         e0, v0 = sim.setup(40)
@@ -65,7 +70,7 @@ def main():
         pair.check_errors()
         A1 = ctx.atoms_download()
         etot = tr.allreduce_sum([e0, last[0]])
-        result = dict(tag0=A0["tag"], f0=A0["f"], uf0=A0["ucgforce"], s0=A0["scores"], inside=inside, tag1=A1["tag"],
+        result = dict(tag0=A0["tag"], f0=A0["f"], uf0=A0["ucgforce"], s0=A0["scores"], p0=A0["ucgp"], inside=inside, tag1=A1["tag"],
                       x1=A1["x"], l1=A1["ucgl"], e0=etot[0], e1=etot[1], nrebuild=sim.nrebuild, nghost=A1["nghost"])
         pair.close()
         ctx.close()

@@ -114,3 +114,41 @@ def test_world2_decomposed_run_matches_single_rank(fresh_ctx, pkg):
     l_multi = by_tag(tag1, np.concatenate([r["l1"] for r in res]))
     assert np.max(np.abs(l_multi - by_tag(S1["tag"], S1["ucgl"]))) < 1e-9
     assert abs(res[0]["e1"] - e_single1) <= 1e-9 * abs(e_single1)
+
+
+@pytest.mark.gpu
+def test_world2_density_style_matches_single_rank(fresh_ctx, pkg):
+    """table_ucg_bethe_density decomposed: the priors and the CV forces of ghosts cross ranks between the passes"""
+    res = _launch("gpu_density")
+    assert all(r["inside"] for r in res)
+    assert all(r["nrebuild"] >= 2 and r["nghost"] > 0 for r in res)
+    ctx = fresh_ctx
+    beads = pkg.synth.make_beads(10, seed=5)
+    deck = util.make_deck("spline", 1024, density=(11.3, 1.5), extra11=0.05)
+    ctx.set_units(1.0, 1.0, 1.0, 0.002)
+    ctx.upload_beads(beads)
+    ctx.domain_set(beads.boxlo, beads.boxhi, 2.5, 0.3, every=2, delay=0, check=1)
+    gp = util.gpu_pair(ctx, "table_ucg_bethe_density", deck)
+    ctx.md_attach(gp, nve=True, langevin=False, ucgstate=False)
+    ctx.md_setup(40)
+    S0 = ctx.atoms_download()
+    e_single0 = ctx.md_thermo()["eng_vdwl"]
+    ctx.md_run(40, 40)
+    S1 = ctx.atoms_download()
+
+    def by_tag(tag, arr):
+        out = np.zeros((beads.n,) + arr.shape[1:])
+        out[tag - 1] = arr
+        return out
+
+    tag0 = np.concatenate([r["tag0"] for r in res])
+    assert sorted(tag0.tolist()) == list(range(1, beads.n + 1))
+    for key, skey in (("f0", "f"), ("p0", "ucgp")):
+        multi = by_tag(tag0, np.concatenate([r[key] for r in res]))
+        single = by_tag(S0["tag"], S0[skey])
+        assert np.max(np.abs(multi - single)) <= 1e-10 * np.max(np.abs(single)), key
+    assert abs(res[0]["e0"] - e_single0) <= 1e-10 * abs(e_single0)
+    tag1 = np.concatenate([r["tag1"] for r in res])
+    d = by_tag(tag1, np.concatenate([r["x1"] for r in res])) - by_tag(S1["tag"], S1["x"])
+    d -= np.round(d / beads.boxhi) * beads.boxhi
+    assert np.max(np.abs(d)) < 1e-8
