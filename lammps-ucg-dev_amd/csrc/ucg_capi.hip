@@ -402,6 +402,7 @@ int ucg_pair_init(ucg_pair *p, int ntypes, double T)
       const size_t own = (size_t) (1024 / slots0) * 36;
       const size_t used = (D.tab_in_lds ? bytes : 0) + own + 6 * 1024;  // + the static model arrays
       D.stage_own = (ctx->stage_own && used <= 160 * 1024) ? 1 : 0;
+      D.stage_own_allowed = ctx->stage_own ? 1 : 0;
     }
     if (M.style == STYLE_BETHE && M.prior_flag == PRIOR_CHEMPOT_NOISE)
       return fail(ctx, UCG_ERR_UNSUPPORTED,

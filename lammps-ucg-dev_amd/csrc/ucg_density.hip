@@ -24,38 +24,91 @@ namespace {
 
 constexpr int DENS_BLOCK = 256;
 
-__device__ __forceinline__ double prox_fn(const double rth, const double r)
+// (r - rth) / (0.1 rth): the divisor is a per-type constant, so the quotient is formed with its
+// reciprocal and two FMA residual steps (exactly the IEEE quotient, see div_by_const) when the
+// divisor qualifies; w = 0.1 * rth and rw = 1 / w come from the caller
+__device__ __forceinline__ double prox_arg(const double r, const double rth, const double w, const double rw, const bool ok)
 {
-  const double t = ucg_tanh((r - rth) / (0.1 * rth));
-  return 0.5 * (1.0 - t);
+  return ok ? div_by_const(r - rth, w, rw) : (r - rth) / w;
 }
 
-__device__ __forceinline__ double prox_der(const double rth, const double r)
+__device__ __forceinline__ double prox_fn_t(const double t) { return 0.5 * (1.0 - t); }
+__device__ __forceinline__ double prox_der_t(const double t, const double w) { return 0.5 * (1.0 - t * t) / w; }
+
+// the workgroup's own beads staged in LDS (same idea as k_pair_gather: with Morton-sorted beads most
+// neighbours of a bead are beads of its own workgroup; the rest go through L1/L2)
+struct OwnBlock {
+  const double4 *pos;
+  const int *meta;
+  int k0;
+  unsigned nown;
+};
+
+__device__ __forceinline__ void stage_own_block(const AtomsDev &A, const int k0, double4 *s_pos, int *s_meta)
 {
-  const double t = ucg_tanh((r - rth) / (0.1 * rth));
-  return 0.5 * (1.0 - t * t) / (0.1 * rth);
+  for (int t = threadIdx.x; t < PAIR_BLOCK; t += blockDim.x)
+    if (k0 + t < A.nlocal) {
+      s_pos[t] = A.pos4[k0 + t];
+      s_meta[t] = A.meta[k0 + t];
+    }
+  __syncthreads();
 }
 
-__global__ __launch_bounds__(DENS_BLOCK) void k_density_pass1(const PairDev P, const AtomsDev A, const ListDev Lst,
+__device__ __forceinline__ void gather_bead(const AtomsDev &A, const OwnBlock &O, const int m, double4 &p, int &mt)
+{
+  const unsigned ml = (unsigned) (m - O.k0);
+  if (ml < O.nown) {
+    p = O.pos[ml];
+    mt = O.meta[ml];
+  } else {
+    p = A.pos4[m];
+    mt = A.meta[m];
+  }
+}
+
+__global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass1(const PairDev P, const AtomsDev A, const ListDev Lst,
                                                              double2 *prior, double *partial0)
 {
-  const int k = blockIdx.x * DENS_BLOCK + threadIdx.x;
+  __shared__ double4 s_pos[PAIR_BLOCK];
+  __shared__ int s_meta[PAIR_BLOCK];
+  const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
+  const int k0 = chunk * PAIR_BLOCK;
+  stage_own_block(A, k0, s_pos, s_meta);
+  OwnBlock O{s_pos, s_meta, k0, (unsigned) max(0, min(PAIR_BLOCK, A.nlocal - k0))};
+  const int k = k0 + threadIdx.x;
   if (k >= A.nlocal) return;
-  const double4 pk = A.pos4[k];
-  const int tk = UCG_META_TYPE(A.meta[k]);
+  const double4 pk = s_pos[threadIdx.x];
+  const int tk = UCG_META_TYPE(s_meta[threadIdx.x]);
   const int na1 = P.n_actual + 1;
   if (P.dens_flags[tk * 2 + 0] == 1) {
     const double rth = P.dens_par[tk * 2 + 1];
+    const double w = 0.1 * rth, rw = 1.0 / w;
+    const bool wok = recip_ok(w);
+    const bool onetype = P.n_actual == 1;
+    const double cut11 = P.cutsq[na1 + 1];
     const int n = Lst.numneigh[k];
     const int *rp = Lst.neigh + k;
+    const size_t pitch = (size_t) Lst.pitch;
     double rho = 0.0;
-    for (int e = 0; e < n; e++, rp += Lst.pitch) {
-      const int m = rp[0] & 0x1FFFFFFF;
-      const double4 pm = A.pos4[m];
-      const int tm = UCG_META_TYPE(A.meta[m]);
+    // one-deep software pipeline: the next entry's bead is in flight while this one is evaluated
+    int ent = n > 0 ? rp[0] : 0, ent_n = n > 1 ? rp[pitch] : ent;
+    double4 pm;
+    int mm;
+    gather_bead(A, O, ent & 0x1FFFFFFF, pm, mm);
+    rp += pitch;
+    for (int e = 0; e < n; e++) {
+      rp += pitch;
+      const int ent_nn = (e + 2 < n) ? rp[0] : ent_n;
+      double4 pm_n;
+      int mm_n;
+      gather_bead(A, O, ent_n & 0x1FFFFFFF, pm_n, mm_n);
+      const int tm = UCG_META_TYPE(mm);
       const double dx = pk.x - pm.x, dy = pk.y - pm.y, dz = pk.z - pm.z;
       const double rsq = dx * dx + dy * dy + dz * dz;
-      if (rsq < P.cutsq[tk * na1 + tm]) rho += prox_fn(rth, sqrt(rsq));
+      if (rsq < (onetype ? cut11 : P.cutsq[tk * na1 + tm])) rho += prox_fn_t(ucg_tanh(prox_arg(sqrt(rsq), rth, w, rw, wok)));
+      ent_n = ent_nn;
+      pm = pm_n;
+      mm = mm_n;
     }
     const double cth = P.dens_par[tk * 2 + 0];
     const double th = ucg_tanh((rho - cth) / (0.1 * cth));
@@ -80,12 +133,13 @@ __global__ __launch_bounds__(DENS_BLOCK) void k_ghost_copy2(int ng, int nlocal, 
 }
 
 // closure as shipped (:608-622): a = b - 1, no guards
-__device__ __forceinline__ void closure_shipped(const double kT, const double u00, const double u01, const double u10,
-                                                const double u11, const double pi1, const double pj1, double &p00,
-                                                double &p01, double &p10, double &p11)
+template <bool FAST>
+__device__ __forceinline__ void closure_shipped(const double kT, const double rkT, const double u00, const double u01,
+                                                const double u10, const double u11, const double pi1, const double pj1,
+                                                double &p00, double &p01, double &p10, double &p11)
 {
   const double Jij = u11 + u00 - u01 - u10;
-  const double bij = ucg_exp(-Jij / kT);
+  const double bij = ucg_exp(FAST ? div_by_const(-Jij, kT, rkT) : -Jij / kT);
   const double aij = bij - 1.;
   const double Qij = (pi1 + pj1) * aij + 1.;
   const double Dij = sqrt(Qij * Qij - 4. * aij * bij * pi1 * pj1);
@@ -114,14 +168,30 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass2(const PairDev P, c
     for (int t = threadIdx.x; t < na1sq; t += blockDim.x) s_cutsq[t] = P.cutsq[t];
     if (LDS_TAB)
       for (int t = threadIdx.x; t < ntabent; t += blockDim.x) s_tab[t] = (FAST ? P.tab_fast : P.tab)[t];
-    __syncthreads();
   }
-
+  // the workgroup's own beads behind the tables, as in k_pair_gather; the 4th component carries
+  // the bead's prior p1 (lambda is not used by this style)
   const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
-  const int k = chunk * PAIR_BLOCK + threadIdx.x;
+  const int k0 = chunk * PAIR_BLOCK;
+  const bool stage_own = P.stage_own != 0;
+  double4 *s_ownpos = s_tab + (LDS_TAB ? ntabent : 0);
+  int *s_ownmeta = reinterpret_cast<int *>(s_ownpos + PAIR_BLOCK);
+  if (stage_own) {
+    for (int t = threadIdx.x; t < PAIR_BLOCK; t += blockDim.x)
+      if (k0 + t < A.nlocal) {
+        double4 p = A.pos4[k0 + t];
+        p.w = prior[k0 + t].y;
+        s_ownpos[t] = p;
+        s_ownmeta[t] = A.meta[k0 + t];
+      }
+  }
+  __syncthreads();
+  const unsigned nown = stage_own ? (unsigned) max(0, min(PAIR_BLOCK, A.nlocal - k0)) : 0u;
+
+  const int k = k0 + threadIdx.x;
   const int nlocal = A.nlocal;
   const int na1 = P.n_actual + 1;
-  const double kT = P.kT;
+  const double kT = P.kT, rkT = P.rkT;
   double ev[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int err = 0;
 
@@ -132,6 +202,18 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass2(const PairDev P, c
     const int *rp = Lst.neigh + k;
     const size_t pitch = (size_t) Lst.pitch;
     const double2 prk = prior[k];
+    auto gather = [&](const int entw, double4 &p, int &mt) {
+      const int m1 = entw & 0x1FFFFFFF;
+      const unsigned ml = (unsigned) (m1 - k0);
+      if (ml < nown) {
+        p = s_ownpos[ml];
+        mt = s_ownmeta[ml];
+      } else {
+        p = A.pos4[m1];
+        p.w = prior[m1].y;
+        mt = A.meta[m1];
+      }
+    };
     const bool dens_k = P.dens_flags[tk * 2 + 0] == 1;
 
     double fx = 0.0, fy = 0.0, fz = 0.0, s0 = 0.0, s1 = 0.0, G0 = 0.0, G1 = 0.0;
@@ -149,16 +231,24 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass2(const PairDev P, c
       s1 -= mu1 / kT;
     }
 
-    for (int e = 0; e < n; e++, rp += pitch) {
-      const int ent = rp[0];
+    // one-deep software pipeline: the next entry's bead is in flight while this one is evaluated
+    int ent = n > 0 ? rp[0] : 0, ent_n = n > 1 ? rp[pitch] : ent;
+    double4 pm;
+    int mm;
+    gather(ent, pm, mm);
+    rp += pitch;
+    for (int e = 0; e < n; e++) {
+      rp += pitch;
+      const int ent_nn = (e + 2 < n) ? rp[0] : ent_n;
+      double4 pm_n;
+      int mm_n;
+      gather(ent_n, pm_n, mm_n);
       const int m = ent & 0x1FFFFFFF;
       double factor_lj = 1.0;
       if (!FAST) {
         const int sb = (ent >> 30) & 3;
         factor_lj = sb == 0 ? P.special_lj[0] : sb == 1 ? P.special_lj[1] : sb == 2 ? P.special_lj[2] : P.special_lj[3];
       }
-      const double4 pm = A.pos4[m];
-      const int mm = A.meta[m];
       const int tm = UCG_META_TYPE(mm);
       const int sm = UCG_META_STATE(mm);
       const double dx = pk.x - pm.x, dy = pk.y - pm.y, dz = pk.z - pm.z;
@@ -169,11 +259,16 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass2(const PairDev P, c
         if (LDS_TAB) eval_quad<TS, FAST>(s_tab, s_par, pt, P.tablength, P.tlm1, P.fast_stride, rsq, factor_lj, q, err);
         else eval_quad<TS, FAST>(FAST ? P.tab_fast : P.tab, s_par, pt, P.tablength, P.tlm1, P.fast_stride, rsq, factor_lj, q, err);
         // scores: only the row owner's (:597-603)
-        s0 -= (sm ? q.u01 : q.u00) / kT;
-        s1 -= (sm ? q.u11 : q.u10) / kT;
-        const double pm1 = prior[m].y;
+        if (FAST) {
+          s0 -= div_by_const(sm ? q.u01 : q.u00, kT, rkT);
+          s1 -= div_by_const(sm ? q.u11 : q.u10, kT, rkT);
+        } else {
+          s0 -= (sm ? q.u01 : q.u00) / kT;
+          s1 -= (sm ? q.u11 : q.u10) / kT;
+        }
+        const double pm1 = pm.w;
         double p00, p01, p10, p11;
-        closure_shipped(kT, q.u00, q.u01, q.u10, q.u11, prk.y, pm1, p00, p01, p10, p11);
+        closure_shipped<FAST>(kT, rkT, q.u00, q.u01, q.u10, q.u11, prk.y, pm1, p00, p01, p10, p11);
         double evdwl = p00 * q.u00 + p01 * q.u01 + p10 * q.u10 + p11 * q.u11;
         double fpair = p00 * q.f00 + p01 * q.f01 + p10 * q.f10 + p11 * q.f11;
         const bool m_owned = m < nlocal;
@@ -187,7 +282,7 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass2(const PairDev P, c
         if (m_owned) {
           // what m's own visit of this pair sends to k: roles swapped (its u[a][b] is our u[b][a])
           double t00, t01, t10, t11;
-          closure_shipped(kT, q.u00, q.u10, q.u01, q.u11, pm1, prk.y, t00, t01, t10, t11);
+          closure_shipped<FAST>(kT, rkT, q.u00, q.u10, q.u01, q.u11, pm1, prk.y, t00, t01, t10, t11);
           double fpj = t00 * q.f00 + t01 * q.f10 + t10 * q.f01 + t11 * q.f11;
           fpj = fpj * 0.5;
           const double djx = pm.x - pk.x, djy = pm.y - pk.y, djz = pm.z - pk.z;
@@ -210,6 +305,10 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass2(const PairDev P, c
           G1 -= (q.u11 - q.u01 + kT * ucg_log(p11 / p01));
         }
       }
+      ent = ent_n;
+      ent_n = ent_nn;
+      pm = pm_n;
+      mm = mm_n;
     }
     A.frc4[k] = make_double4(fx, fy, fz, 0.0);
     A.scores[k] = make_double2(s0, s1);
@@ -235,62 +334,105 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass2(const PairDev P, c
 }
 
 template <bool EV>
-__global__ __launch_bounds__(DENS_BLOCK) void k_density_pass3(const PairDev P, const AtomsDev A, const ListDev Lst,
+__global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass3(const PairDev P, const AtomsDev A, const ListDev Lst,
                                                              const double2 *cv, double *evpart)
 {
-  __shared__ double s_red[(DENS_BLOCK / 64) * 8];
-  const int k = blockIdx.x * DENS_BLOCK + threadIdx.x;
+  __shared__ double s_red[(PAIR_BLOCK / 64) * 8];
+  __shared__ double4 s_pos[PAIR_BLOCK];
+  __shared__ int s_meta[PAIR_BLOCK];
+  __shared__ double2 s_cv[PAIR_BLOCK];
+  const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
+  const int k0 = chunk * PAIR_BLOCK;
+  if (k0 + (int) threadIdx.x < A.nlocal) s_cv[threadIdx.x] = cv[k0 + threadIdx.x];
+  stage_own_block(A, k0, s_pos, s_meta);
+  OwnBlock O{s_pos, s_meta, k0, (unsigned) max(0, min(PAIR_BLOCK, A.nlocal - k0))};
+  const int k = k0 + threadIdx.x;
   const int na1 = P.n_actual + 1;
   double ev[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (k < A.nlocal) {
-    const double4 pk = A.pos4[k];
-    const int tk = UCG_META_TYPE(A.meta[k]);
+    const double4 pk = s_pos[threadIdx.x];
+    const int tk = UCG_META_TYPE(s_meta[threadIdx.x]);
     const bool dens_k = P.dens_flags[tk * 2 + 0] == 1;
     const double rth_k = P.dens_par[tk * 2 + 1];
-    const double2 cvk = cv[k];
+    const double w_k = 0.1 * rth_k, rw_k = 1.0 / w_k;
+    const bool wok_k = recip_ok(w_k);
+    const bool onetype = P.n_actual == 1;
+    const double cut11 = P.cutsq[na1 + 1];
+    const double2 cvk = s_cv[threadIdx.x];
     double4 f = A.frc4[k];
     const int n = Lst.numneigh[k];
     const int *rp = Lst.neigh + k;
-    for (int e = 0; e < n; e++, rp += Lst.pitch) {
-      const int m = rp[0] & 0x1FFFFFFF;
-      const double4 pm = A.pos4[m];
-      const int tm = UCG_META_TYPE(A.meta[m]);
+    const size_t pitch = (size_t) Lst.pitch;
+    int ent = n > 0 ? rp[0] : 0, ent_n = n > 1 ? rp[pitch] : ent;
+    double4 pm;
+    int mm;
+    gather_bead(A, O, ent & 0x1FFFFFFF, pm, mm);
+    rp += pitch;
+    for (int e = 0; e < n; e++) {
+      rp += pitch;
+      const int ent_nn = (e + 2 < n) ? rp[0] : ent_n;
+      double4 pm_n;
+      int mm_n;
+      gather_bead(A, O, ent_n & 0x1FFFFFFF, pm_n, mm_n);
+      const int m = ent & 0x1FFFFFFF;
+      const int tm = UCG_META_TYPE(mm);
       const double dx = pk.x - pm.x, dy = pk.y - pm.y, dz = pk.z - pm.z;
       const double rsq = dx * dx + dy * dy + dz * dz;
-      const bool in_k = dens_k && rsq < P.cutsq[tk * na1 + tm];
-      const bool dens_m = P.dens_flags[tm * 2 + 0] == 1;
-      const bool in_m = dens_m && rsq < P.cutsq[tm * na1 + tk];
-      if (!(in_k || in_m)) continue;
-      const double distance = sqrt(rsq);
-      if (in_k) {
-        const double w = P.dens_as_shipped ? prox_fn(rth_k, distance) : prox_der(rth_k, distance);
-        for (int s = 0; s < 2; s++) {
-          const double fpair = (s ? cvk.y : cvk.x) * w / distance;
-          f.x += fpair * dx;
-          f.y += fpair * dy;
-          f.z += fpair * dz;
-          if (EV) {
-            ev[1] += dx * dx * fpair;
-            ev[2] += dy * dy * fpair;
-            ev[3] += dz * dz * fpair;
-            ev[4] += dx * dy * fpair;
-            ev[5] += dx * dz * fpair;
-            ev[6] += dy * dz * fpair;
+      const bool in_k = dens_k && rsq < (onetype ? cut11 : P.cutsq[tk * na1 + tm]);
+      const bool dens_m = onetype ? dens_k : (P.dens_flags[tm * 2 + 0] == 1);
+      const bool in_m = dens_m && rsq < (onetype ? cut11 : P.cutsq[tm * na1 + tk]);
+      if (in_k || in_m) {
+        const double distance = sqrt(rsq);
+        // the four quotients (cv * w) / distance share the divisor: its reciprocal + two FMA residual
+        // steps give the IEEE quotient (div_by_const); other divisors keep the hardware division
+        const double rdist = 1.0 / distance;
+        const bool dok = recip_ok(distance);
+        double w_own = 0.0;
+        if (in_k) {
+          const double t = ucg_tanh(prox_arg(distance, rth_k, w_k, rw_k, wok_k));
+          w_own = P.dens_as_shipped ? prox_fn_t(t) : prox_der_t(t, w_k);
+          for (int s = 0; s < 2; s++) {
+            const double num = (s ? cvk.y : cvk.x) * w_own;
+            const double fpair = dok ? div_by_const(num, distance, rdist) : num / distance;
+            f.x += fpair * dx;
+            f.y += fpair * dy;
+            f.z += fpair * dz;
+            if (EV) {
+              ev[1] += dx * dx * fpair;
+              ev[2] += dy * dy * fpair;
+              ev[3] += dz * dz * fpair;
+              ev[4] += dx * dy * fpair;
+              ev[5] += dx * dz * fpair;
+              ev[6] += dy * dz * fpair;
+            }
+          }
+        }
+        if (in_m) {
+          double w;
+          if (onetype && in_k) {
+            w = w_own;  // same type: same threshold radius, same value
+          } else {
+            const double rth_m = P.dens_par[tm * 2 + 1];
+            const double w_m = 0.1 * rth_m;
+            const double t = ucg_tanh((distance - rth_m) / w_m);
+            w = P.dens_as_shipped ? prox_fn_t(t) : prox_der_t(t, w_m);
+          }
+          const unsigned ml = (unsigned) (m - k0);
+          const double2 cvm = ml < O.nown ? s_cv[ml] : cv[m];
+          const double djx = pm.x - pk.x, djy = pm.y - pk.y, djz = pm.z - pk.z;
+          for (int s = 0; s < 2; s++) {
+            const double num = (s ? cvm.y : cvm.x) * w;
+            const double fpair = dok ? div_by_const(num, distance, rdist) : num / distance;
+            f.x -= fpair * djx;
+            f.y -= fpair * djy;
+            f.z -= fpair * djz;
           }
         }
       }
-      if (in_m) {
-        const double rth_m = P.dens_par[tm * 2 + 1];
-        const double w = P.dens_as_shipped ? prox_fn(rth_m, distance) : prox_der(rth_m, distance);
-        const double2 cvm = cv[m];
-        const double djx = pm.x - pk.x, djy = pm.y - pk.y, djz = pm.z - pk.z;
-        for (int s = 0; s < 2; s++) {
-          const double fpair = (s ? cvm.y : cvm.x) * w / distance;
-          f.x -= fpair * djx;
-          f.y -= fpair * djy;
-          f.z -= fpair * djz;
-        }
-      }
+      ent = ent_n;
+      ent_n = ent_nn;
+      pm = pm_n;
+      mm = mm_n;
     }
     A.frc4[k] = f;
   }
@@ -309,12 +451,22 @@ __global__ void k_ev_final2(const double *part, int nb1, const double *part3, in
 }
 
 template <int TS>
-hipError_t launch_pass2(const PairDev &P, const AtomsDev &A, const ListDev &L, bool ev, const double2 *prior,
+hipError_t launch_pass2(const PairDev &Pin, const AtomsDev &A, const ListDev &L, bool ev, const double2 *prior,
                         const double *partial0, double2 *cv, double *evpart, int *errflag, hipStream_t st, int nblocks)
 {
+  PairDev P = Pin;
+  {
+    // own-bead staging needs the full 1024-bead block behind the tables (the gather kernels may run with
+    // fewer beads per block)
+    const size_t tb = P.fast ? ((size_t) (P.tablength * P.fast_stride + 1) / 2) * sizeof(double4)
+                             : (size_t) P.ntab * P.tablength * sizeof(double4);
+    const size_t used = (P.tab_in_lds ? tb : 0) + (size_t) PAIR_BLOCK * (sizeof(double4) + sizeof(int)) + 6 * 1024;
+    P.stage_own = (Pin.stage_own_allowed && used <= 160 * 1024) ? 1 : 0;
+  }
   const size_t tabbytes = P.fast ? ((size_t) (P.tablength * P.fast_stride + 1) / 2) * sizeof(double4)
                                  : (size_t) P.ntab * P.tablength * sizeof(double4);
-  const size_t ldsbytes = P.tab_in_lds ? tabbytes : 0;
+  const size_t ownbytes = P.stage_own ? (size_t) PAIR_BLOCK * (sizeof(double4) + sizeof(int)) : 0;
+  const size_t ldsbytes = (P.tab_in_lds ? tabbytes : 0) + ownbytes;
 #define UCG_LAUNCH(EVF, LDSF, FASTF)                                                                     \
   do {                                                                                                   \
     auto kern = k_density_pass2<TS, EVF, LDSF, FASTF>;                                                   \
@@ -350,10 +502,9 @@ hipError_t launch_density(const PairDev &P, const AtomsDev &A, const ListDev &L,
 {
   const int n = A.nlocal;
   if (n == 0) return hipSuccess;
-  const int nb = (n + DENS_BLOCK - 1) / DENS_BLOCK;
   const int nb2 = (n + PAIR_BLOCK - 1) / PAIR_BLOCK;
   const int ngb = (A.nghost + DENS_BLOCK - 1) / DENS_BLOCK;
-  hipLaunchKernelGGL(k_density_pass1, dim3(nb), dim3(DENS_BLOCK), 0, st, P, A, L, prior, partial0);
+  hipLaunchKernelGGL(k_density_pass1, dim3(nb2), dim3(PAIR_BLOCK), 0, st, P, A, L, prior, partial0);
   if (A.nghost > 0) hipLaunchKernelGGL(k_ghost_copy2, dim3(ngb), dim3(DENS_BLOCK), 0, st, A.nghost, n, ghost_src, prior);
   hipError_t e;
   switch (P.tabstyle) {
@@ -365,10 +516,10 @@ hipError_t launch_density(const PairDev &P, const AtomsDev &A, const ListDev &L,
   if (A.nghost > 0) hipLaunchKernelGGL(k_ghost_copy2, dim3(ngb), dim3(DENS_BLOCK), 0, st, A.nghost, n, ghost_src, cv);
   double *evpart3 = evpart + (size_t) nb2 * 8;
   if (ev) {
-    hipLaunchKernelGGL(k_density_pass3<true>, dim3(nb), dim3(DENS_BLOCK), 0, st, P, A, L, cv, evpart3);
-    hipLaunchKernelGGL(k_ev_final2, dim3(1), dim3(64), 0, st, evpart, nb2, evpart3, nb, evout);
+    hipLaunchKernelGGL(k_density_pass3<true>, dim3(nb2), dim3(PAIR_BLOCK), 0, st, P, A, L, cv, evpart3);
+    hipLaunchKernelGGL(k_ev_final2, dim3(1), dim3(64), 0, st, evpart, nb2, evpart3, nb2, evout);
   } else {
-    hipLaunchKernelGGL(k_density_pass3<false>, dim3(nb), dim3(DENS_BLOCK), 0, st, P, A, L, cv, evpart3);
+    hipLaunchKernelGGL(k_density_pass3<false>, dim3(nb2), dim3(PAIR_BLOCK), 0, st, P, A, L, cv, evpart3);
   }
   return hipGetLastError();
 }
@@ -381,10 +532,9 @@ hipError_t launch_density_phase(const PairDev &P, const AtomsDev &A, const ListD
 {
   const int n = A.nlocal;
   if (n == 0) return hipSuccess;
-  const int nb = (n + DENS_BLOCK - 1) / DENS_BLOCK;
   const int nb2 = (n + PAIR_BLOCK - 1) / PAIR_BLOCK;
   if (phase == 1) {
-    hipLaunchKernelGGL(k_density_pass1, dim3(nb), dim3(DENS_BLOCK), 0, st, P, A, L, prior, partial0);
+    hipLaunchKernelGGL(k_density_pass1, dim3(nb2), dim3(PAIR_BLOCK), 0, st, P, A, L, prior, partial0);
   } else if (phase == 2) {
     hipError_t e;
     switch (P.tabstyle) {
@@ -396,10 +546,10 @@ hipError_t launch_density_phase(const PairDev &P, const AtomsDev &A, const ListD
   } else {
     double *evpart3 = evpart + (size_t) nb2 * 8;
     if (ev) {
-      hipLaunchKernelGGL(k_density_pass3<true>, dim3(nb), dim3(DENS_BLOCK), 0, st, P, A, L, cv, evpart3);
-      hipLaunchKernelGGL(k_ev_final2, dim3(1), dim3(64), 0, st, evpart, nb2, evpart3, nb, evout);
+      hipLaunchKernelGGL(k_density_pass3<true>, dim3(nb2), dim3(PAIR_BLOCK), 0, st, P, A, L, cv, evpart3);
+      hipLaunchKernelGGL(k_ev_final2, dim3(1), dim3(64), 0, st, evpart, nb2, evpart3, nb2, evout);
     } else {
-      hipLaunchKernelGGL(k_density_pass3<false>, dim3(nb), dim3(DENS_BLOCK), 0, st, P, A, L, cv, evpart3);
+      hipLaunchKernelGGL(k_density_pass3<false>, dim3(nb2), dim3(PAIR_BLOCK), 0, st, P, A, L, cv, evpart3);
     }
   }
   return hipGetLastError();

@@ -43,6 +43,7 @@ struct PairDev {
   double rkT;          // RN(1/kT), used by the FAST kernels' exact division
   int gather_slots;    // lanes per bead in k_pair_gather (1, 4, 8 or 16): part of the canonical order
   int stage_own;       // 1: k_pair_gather keeps its workgroup's own beads in LDS behind the tables
+  int stage_own_allowed;  // the context option "stage_own" (kernels with other block shapes decide the fit themselves)
   int fast;            // 1: one shared r^2 grid, all special_lj == 1, kT usable for div_by_const
   double special_lj[4];
 };
