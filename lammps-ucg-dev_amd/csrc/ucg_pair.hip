@@ -158,22 +158,41 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
     const int pt11_0 = s_pairtab[(na1 + 1) * 4 + 0], pt11_1 = s_pairtab[(na1 + 1) * 4 + 1];
     const int pt11_2 = s_pairtab[(na1 + 1) * 4 + 2], pt11_3 = s_pairtab[(na1 + 1) * 4 + 3];
 
-    // Two-stage software pipeline: while entry e is evaluated, the gather of entry e+SLOTS is in
-    // flight and the list word of entry e+2*SLOTS is being fetched (no exposed index-load latency).
-    // The loop is unrolled by two with ping-pong operand sets (A, B), so that no registers have to
-    // be rotated between iterations.
-    auto gather = [&](const int entw, double4 &p, int &mt) {
-      const int m1 = entw & 0x1FFFFFFF;
-      const unsigned ml = (unsigned) (m1 - k0);
+    // two-stage software pipeline: while entry e is evaluated, the gather of entry e+SLOTS is in
+    // flight and the list word of entry e+2*SLOTS is being fetched (no exposed index-load latency)
+    int ent = (slot < n) ? rp[0] : 0;
+    int ent_n = (slot + SLOTS < n) ? rp[rstep] : ent;
+    double4 pm;
+    int mm;
+    {
+      const int m0 = ent & 0x1FFFFFFF;
+      const unsigned ml = (unsigned) (m0 - k0);
       if (ml < nown) {
-        p = s_ownpos[ml];
-        mt = s_ownmeta[ml];
+        pm = s_ownpos[ml];
+        mm = s_ownmeta[ml];
       } else {
-        p = A.pos4[m1];
-        mt = A.meta[m1];
+        pm = A.pos4[m0];
+        mm = A.meta[m0];
       }
-    };
-    auto evaluate = [&](const int ent, const double4 &pm, const int mm) {
+    }
+    rp += rstep;
+    for (int e = slot; e < n; e += SLOTS) {
+      rp += rstep;
+      const int ent_nn = (e + 2 * SLOTS < n) ? rp[0] : ent_n;
+      double4 pm_n;
+      int mm_n;
+      {
+        const int m1 = ent_n & 0x1FFFFFFF;
+        const unsigned ml = (unsigned) (m1 - k0);
+        if (ml < nown) {
+          pm_n = s_ownpos[ml];
+          mm_n = s_ownmeta[ml];
+        } else {
+          pm_n = A.pos4[m1];
+          mm_n = A.meta[m1];
+        }
+      }
+
       const int m = ent & 0x1FFFFFFF;
       const bool k_is_i = (ent >> 29) & 1;
       double factor_lj = 1.0;
@@ -326,25 +345,10 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
           ev[6] += 0.5 * (dy * dz * fpair);
         }
       }
-    };
-    int entA = (slot < n) ? rp[0] : 0;
-    int entB = (slot + SLOTS < n) ? rp[rstep] : entA;
-    double4 pmA, pmB;
-    int mmA, mmB;
-    gather(entA, pmA, mmA);
-    rp += 2 * rstep;
-    for (int e = slot; e < n; e += 2 * SLOTS) {
-      // A is evaluated; B's operands are fetched; A's next list word is fetched
-      const int entA2 = (e + 2 * SLOTS < n) ? rp[0] : entB;
-      gather(entB, pmB, mmB);
-      evaluate(entA, pmA, mmA);
-      if (e + SLOTS >= n) break;
-      const int entB2 = (e + 3 * SLOTS < n) ? rp[rstep] : entA2;
-      rp += 2 * rstep;
-      gather(entA2, pmA, mmA);
-      evaluate(entB, pmB, mmB);
-      entA = entA2;
-      entB = entB2;
+      ent = ent_n;
+      ent_n = ent_nn;
+      pm = pm_n;
+      mm = mm_n;
     }
     if (SLOTS > 1) {
       // fixed tree over the bead's lanes: s[l] += s[l + off], off = SLOTS/2 ... 1
