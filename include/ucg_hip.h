@@ -129,6 +129,11 @@ int ucg_pair_tabindex(const ucg_pair *p, int *out, int cap);
 int ucg_pair_compute(ucg_pair *p, int eflag, int vflag, double *eng_vdwl, double *virial);
 /* device-side table-range violations of the last compute (0 = none); the glue
  * turns a nonzero return into error->one() like UCG/pair_table_ucgld.cpp:437-444 */
+/* the same compute() in two launches for decomposed runs (table_ucgld / table_ucg_bethe, no
+ * energy/virial): part 1 = the workgroups none of whose beads has a ghost neighbour -- they can run
+ * while the halo is in flight --, part 2 = the rest, after ucg_halo_unpack.  Together they write
+ * exactly what ucg_pair_compute writes. */
+int ucg_pair_compute_part(ucg_pair *p, int part);
 int ucg_pair_check_errors(ucg_pair *p);
 /* table_ucg_bethe_density on a decomposed run: the three passes of compute() one at a time
  * (phase 1 :219-274 local densities and priors, 2 :284-664 pair forces and CV force accumulators,

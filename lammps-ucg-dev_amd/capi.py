@@ -42,7 +42,7 @@ SYMBOLS = [
     "ucg_fix_nve_initial", "ucg_fix_nve_final",
     "ucg_fix_nve_wall_hard_set", "ucg_fix_nve_wall_hard_initial", "ucg_fix_nve_wall_hard_final",
     "ucg_fix_nve_wall_hard_post_force",
-    "ucg_pair_density_phase", "ucg_pair_density_buffer", "ucg_halo_aux_pack", "ucg_halo_aux_unpack",
+    "ucg_pair_compute_part", "ucg_pair_density_phase", "ucg_pair_density_buffer", "ucg_halo_aux_pack", "ucg_halo_aux_unpack",
     "ucg_atoms_upload_molecule", "ucg_atoms_download_molecule", "ucg_fix_cluster_switch_create",
     "ucg_fix_cluster_switch_check_cluster", "ucg_fix_cluster_switch_attempt_switch", "ucg_fix_cluster_switch_maxmol",
     "ucg_fix_cluster_switch_array", "ucg_fix_cluster_switch_vector",
@@ -130,6 +130,7 @@ def lib():
     L.ucg_fix_nve_wall_hard_final.argtypes = [vp, C.c_int]
     L.ucg_fix_nve_wall_hard_post_force.argtypes = [vp, C.c_int]
     L.ucg_atoms_upload_molecule.argtypes = [vp, c_int_p]
+    L.ucg_pair_compute_part.argtypes = [vp, C.c_int]
     L.ucg_pair_density_phase.argtypes = [vp, C.c_int, C.c_int, C.c_int, c_double_p, c_double_p]
     L.ucg_pair_density_buffer.argtypes = [vp, C.c_int]
     L.ucg_pair_density_buffer.restype = C.c_void_p
@@ -617,6 +618,10 @@ class Pair:
         v = np.zeros(6)
         self.ctx.chk(self.ctx.L.ucg_pair_compute(self.h, eflag, vflag, C.byref(e), _dp(v)))
         return e.value, v
+
+    def compute_part(self, part):
+        """1: the workgroups without ghost neighbours (before the halo arrives), 2: the rest"""
+        self.ctx.chk(self.ctx.L.ucg_pair_compute_part(self.h, part))
 
     def check_errors(self):
         self.ctx.chk(self.ctx.L.ucg_pair_check_errors(self.h))

@@ -97,6 +97,8 @@ ListDev ucg_ctx::list_dev() const
   L.maxrow = list_maxrow;
   L.neigh = neigh.get();
   L.numneigh = numneigh.get();
+  L.blockflag = nullptr;
+  L.blockwant = 0;
   return L;
 }
 
@@ -483,7 +485,22 @@ int ucg_pair_tabindex(const ucg_pair *p, int *out, int cap)
   return n;
 }
 
+static int pair_compute_impl(ucg_pair *p, int eflag, int vflag, double *eng_vdwl, double *virial, int part);
+
 int ucg_pair_compute(ucg_pair *p, int eflag, int vflag, double *eng_vdwl, double *virial)
+{
+  return pair_compute_impl(p, eflag, vflag, eng_vdwl, virial, 0);
+}
+
+int ucg_pair_compute_part(ucg_pair *p, int part)
+{
+  if (part != 1 && part != 2) return UCG_ERR_INVALID;
+  return pair_compute_impl(p, 0, 0, nullptr, nullptr, part);
+}
+
+// part 0: all beads; 1: only the workgroups none of whose beads has a ghost neighbour (they need no
+// halo); 2: the others.  1 then 2 write exactly what 0 writes.
+static int pair_compute_impl(ucg_pair *p, int eflag, int vflag, double *eng_vdwl, double *virial, int part)
 {
   if (!p || !p->ctx) return UCG_ERR_INVALID;
   ucg_ctx *ctx = p->ctx;
@@ -508,6 +525,8 @@ int ucg_pair_compute(ucg_pair *p, int eflag, int vflag, double *eng_vdwl, double
       UCG_HIP(hipEventCreate(&e1));
       UCG_HIP(hipEventRecord(e0, ctx->stream));
     }
+    if (part != 0 && p->model.style == STYLE_BETHE_DENSITY)
+      return fail(ctx, UCG_ERR_INVALID, "ucg_pair_compute_part covers the gather styles (table_ucgld, table_ucg_bethe)");
     if (p->model.style == STYLE_BETHE_DENSITY) {
       if (ctx->nghost > 0 && !ctx->ghost_src_valid)
         return fail(ctx, UCG_ERR_UNSUPPORTED,
@@ -522,8 +541,19 @@ int ucg_pair_compute(ucg_pair *p, int eflag, int vflag, double *eng_vdwl, double
                              p->d_partial.get(), p->d_cv.get(), p->d_evpart.get(), p->d_evout.get(), p->d_err.get(),
                              ctx->stream));
     } else {
-      UCG_HIP(launch_pair_gather(p->dev, ctx->atoms_dev(), ctx->list_dev(), ev, p->d_evpart.get(), p->d_evout.get(),
-                                 p->d_err.get(), ctx->stream));
+      ListDev L = ctx->list_dev();
+      if (part != 0) {
+        if (p->blockflag_build != ctx->nrebuild || p->blockflag_slots != p->dev.gather_slots) {
+          p->d_blockflag.reserve((size_t) nb + 1);
+          UCG_HIP(launch_block_classify(ctx->atoms_dev(), L, p->dev.gather_slots, p->d_blockflag.get(), ctx->stream));
+          p->blockflag_build = ctx->nrebuild;
+          p->blockflag_slots = p->dev.gather_slots;
+        }
+        L.blockflag = p->d_blockflag.get();
+        L.blockwant = part == 1 ? 0 : 1;
+      }
+      UCG_HIP(launch_pair_gather(p->dev, ctx->atoms_dev(), L, ev, p->d_evpart.get(), p->d_evout.get(), p->d_err.get(),
+                                 ctx->stream));
     }
     if (ctx->prof_on) {
       UCG_HIP(hipEventRecord(e1, ctx->stream));

@@ -157,6 +157,9 @@ struct ucg_pair {
   ucg::DevBuf<int> d_pairtab;
   ucg::DevBuf<double> d_cutsq, d_mu, d_prior_type;
   ucg::DevBuf<int> d_err;
+  ucg::DevBuf<int> d_blockflag;  // per workgroup of the gather kernel: 1 = some bead has a ghost neighbour
+  long long blockflag_build = -1;
+  int blockflag_slots = 0;
   ucg::DevBuf<double> d_evpart, d_evout;
   // table_ucg_bethe_density
   ucg::DevBuf<double2> d_prior, d_cv;

@@ -69,6 +69,10 @@ struct ListDev {
   int maxrow;
   const int *neigh;
   const int *numneigh;
+  // optional workgroup filter of the gather kernels (decomposed runs overlap the halo with the
+  // workgroups that touch no ghost): run only workgroups with blockflag[chunk] == blockwant
+  const int *blockflag;
+  int blockwant;
 };
 
 }  // namespace ucg

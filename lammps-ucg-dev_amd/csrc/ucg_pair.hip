@@ -44,6 +44,10 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
   __shared__ int s_pairtab[(UCG_MAX_ACTUAL + 1) * (UCG_MAX_ACTUAL + 1) * 4];
   __shared__ double s_cutsq[(UCG_MAX_ACTUAL + 1) * (UCG_MAX_ACTUAL + 1)];
 
+  // filtered launches map workgroups round-robin (their live workgroups are neighbours in Morton order and
+  // would otherwise pile up on few XCDs)
+  const int chunk_id = Lst.blockflag ? (int) blockIdx.x : xcd_chunk(blockIdx.x, gridDim.x);
+  if (Lst.blockflag && Lst.blockflag[chunk_id] != Lst.blockwant) return;  // whole workgroup
   // in double4 units; the FAST layout is tablength * (2*ntab+1) 16-byte slots
   const int ntabent = FAST ? (P.tablength * P.fast_stride + 1) / 2 : P.ntab * P.tablength;
   // the workgroup's own beads, staged in LDS behind the tables (when they fit): beads are sorted
@@ -53,7 +57,7 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
   const bool stage_own = P.stage_own != 0;
   double4 *s_ownpos = s_tab + (LDS_TAB ? ntabent : 0);
   int *s_ownmeta = reinterpret_cast<int *>(s_ownpos + PAIR_BLOCK / SLOTS);
-  const int k0 = xcd_chunk(blockIdx.x, gridDim.x) * (PAIR_BLOCK / SLOTS);
+  const int k0 = chunk_id * (PAIR_BLOCK / SLOTS);
   if (stage_own) {
     for (int t = threadIdx.x; t < PAIR_BLOCK / SLOTS; t += blockDim.x) {
       if (k0 + t < A.nlocal) {
@@ -76,7 +80,7 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
   // SLOTS lanes share one bead: lane `slot` takes the row entries e = slot, slot+SLOTS, ...;
   // adjacent lanes then gather adjacent list entries (mostly adjacent beads: shared cache lines),
   // and the SLOTS partial sums are combined by a fixed shuffle tree (the canonical order).
-  const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
+  const int chunk = chunk_id;
   const int gtid = chunk * PAIR_BLOCK + threadIdx.x;
   const int k = gtid / SLOTS;
   const int slot = gtid % SLOTS;
@@ -377,6 +381,18 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
   if (EV) block_sum_store<8>(ev, s_red, evpart);
 }
 
+// per workgroup of the gather kernel: does any of its beads have a ghost among its neighbours?
+__global__ __launch_bounds__(256) void k_block_classify(int nlocal, int beads_per_block, int pitch, const int *numneigh,
+                                                       const int *neigh, int *flags)
+{
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= nlocal) return;
+  const int n = numneigh[k];
+  bool ghost = false;
+  for (int e = 0; e < n; e++) ghost |= (neigh[(size_t) e * pitch + k] & 0x1FFFFFFF) >= nlocal;
+  if (ghost) flags[k / beads_per_block] = 1;
+}
+
 __global__ void k_ev_final(const double *part, int nblocks, double *out)
 {
   // fixed-order sum of the per-block partials
@@ -481,6 +497,17 @@ hipError_t launch_pair_gather(const PairDev &P, const AtomsDev &A, const ListDev
     e = hipGetLastError();
   }
   return e;
+}
+
+hipError_t launch_block_classify(const AtomsDev &A, const ListDev &L, int slots, int *flags, hipStream_t st)
+{
+  const int nblocks = pair_gather_blocks(A.nlocal, slots);
+  if (nblocks == 0) return hipSuccess;
+  hipError_t e = hipMemsetAsync(flags, 0, (size_t) nblocks * sizeof(int), st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_block_classify, dim3((A.nlocal + 255) / 256), dim3(256), 0, st, A.nlocal, PAIR_BLOCK / slots, L.pitch,
+                     L.numneigh, L.neigh, flags);
+  return hipGetLastError();
 }
 
 hipError_t launch_selftest_div(double b, unsigned long long seed, int n, unsigned long long *d_mismatches, hipStream_t st)

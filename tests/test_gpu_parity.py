@@ -352,3 +352,34 @@ def test_gather_slots_define_the_canonical_order(fresh_ctx, pkg, orc, slots, sty
     for k in ("f", "ucgforce", "scores"):
         assert util.bits_equal(G[k], O[k]), k
     assert abs(eng - sim.ev()["eng_vdwl"]) <= 1e-12 * abs(eng)
+
+
+@pytest.mark.parametrize("style", ["table_ucgld", "table_ucg_bethe"])
+@pytest.mark.parametrize("slots", [1, 4, 16])
+def test_interior_and_boundary_launches_add_up(fresh_ctx, pkg, style, slots):
+    """ucg_pair_compute_part 1 (workgroups without ghost neighbours) + 2 (the rest) == ucg_pair_compute"""
+    ctx = fresh_ctx
+    deck = util.make_deck("spline", 1024)
+    beads = pkg.synth.make_beads(30, seed=4)
+    beads.ucgp = np.clip(np.random.default_rng(1).uniform(size=beads.n), 1e-6, 1 - 1e-6)
+    ctx.set_units(1.0, 1.0, 1.0, 0.002)
+    ctx.set_option("gather_slots", slots)
+    ctx.upload_beads(beads)
+    ctx.domain_set(beads.boxlo, beads.boxhi, 2.5, 0.3, every=1, delay=0, check=1)
+    ctx.neigh_rebuild()
+    gp = util.gpu_pair(ctx, style, deck)
+    gp.compute(0, 0)
+    full = ctx.atoms_download()
+    ctx.force_clear()
+    gp.compute_part(1)
+    part1 = ctx.atoms_download()
+    interior = np.any(part1["f"] != 0.0, axis=1)
+    assert interior.sum() < beads.n
+    if slots >= 4:
+        assert interior.sum() > 0  # some workgroups are interior (at 1024 beads per workgroup none is, at this size)
+    gp.compute_part(2)
+    both = ctx.atoms_download()
+    for k in ("f", "scores", "ucgforce"):
+        assert util.bits_equal(both[k], full[k]), k
+    # interior beads were final after part 1
+    assert util.bits_equal(part1["f"][interior], full["f"][interior])
