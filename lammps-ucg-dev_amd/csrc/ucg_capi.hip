@@ -381,6 +381,7 @@ int ucg_pair_init(ucg_pair *p, int ntypes, double T)
       const unsigned long long mant = kb & 0xFFFFFFFFFFFFFull, ex = (kb >> 52) & 0x7FF;
       if (mant == 0xFFFFFFFFFFFFFull || ex < 1023 - 200 || ex > 1023 + 200 || (kb >> 63)) fast = false;
       if (ctx->force_generic_kernels) fast = false;
+      D.kT_pow2 = (mant == 0 && ex > 1023 - 200 && ex < 1023 + 200 && !(kb >> 63)) ? 1 : 0;
       D.fast = fast ? 1 : 0;
       D.fast_stride = 2 * ntab + 1;
       const size_t nslots = (size_t) tl * D.fast_stride;

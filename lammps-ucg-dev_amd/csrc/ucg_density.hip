@@ -134,12 +134,12 @@ __global__ __launch_bounds__(DENS_BLOCK) void k_ghost_copy2(int ng, int nlocal, 
 
 // closure as shipped (:608-622): a = b - 1, no guards
 template <bool FAST>
-__device__ __forceinline__ void closure_shipped(const double kT, const double rkT, const double u00, const double u01,
+__device__ __forceinline__ void closure_shipped(const double kT, const double rkT, const int kTp2, const double u00, const double u01,
                                                 const double u10, const double u11, const double pi1, const double pj1,
                                                 double &p00, double &p01, double &p10, double &p11)
 {
   const double Jij = u11 + u00 - u01 - u10;
-  const double bij = ucg_exp(FAST ? div_by_const(-Jij, kT, rkT) : -Jij / kT);
+  const double bij = ucg_exp(FAST ? div_kT(-Jij, kT, rkT, kTp2) : -Jij / kT);
   const double aij = bij - 1.;
   const double Qij = (pi1 + pj1) * aij + 1.;
   const double Dij = sqrt(Qij * Qij - 4. * aij * bij * pi1 * pj1);
@@ -192,6 +192,7 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass2(const PairDev P, c
   const int nlocal = A.nlocal;
   const int na1 = P.n_actual + 1;
   const double kT = P.kT, rkT = P.rkT;
+  const int kTp2 = P.kT_pow2;
   double ev[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int err = 0;
 
@@ -260,15 +261,15 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass2(const PairDev P, c
         else eval_quad<TS, FAST>(FAST ? P.tab_fast : P.tab, s_par, pt, P.tablength, P.tlm1, P.fast_stride, rsq, factor_lj, q, err);
         // scores: only the row owner's (:597-603)
         if (FAST) {
-          s0 -= div_by_const(sm ? q.u01 : q.u00, kT, rkT);
-          s1 -= div_by_const(sm ? q.u11 : q.u10, kT, rkT);
+          s0 -= div_kT(sm ? q.u01 : q.u00, kT, rkT, kTp2);
+          s1 -= div_kT(sm ? q.u11 : q.u10, kT, rkT, kTp2);
         } else {
           s0 -= (sm ? q.u01 : q.u00) / kT;
           s1 -= (sm ? q.u11 : q.u10) / kT;
         }
         const double pm1 = pm.w;
         double p00, p01, p10, p11;
-        closure_shipped<FAST>(kT, rkT, q.u00, q.u01, q.u10, q.u11, prk.y, pm1, p00, p01, p10, p11);
+        closure_shipped<FAST>(kT, rkT, kTp2, q.u00, q.u01, q.u10, q.u11, prk.y, pm1, p00, p01, p10, p11);
         double evdwl = p00 * q.u00 + p01 * q.u01 + p10 * q.u10 + p11 * q.u11;
         double fpair = p00 * q.f00 + p01 * q.f01 + p10 * q.f10 + p11 * q.f11;
         const bool m_owned = m < nlocal;
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass2(const PairDev P, c
         if (m_owned) {
           // what m's own visit of this pair sends to k: roles swapped (its u[a][b] is our u[b][a])
           double t00, t01, t10, t11;
-          closure_shipped<FAST>(kT, rkT, q.u00, q.u10, q.u01, q.u11, pm1, prk.y, t00, t01, t10, t11);
+          closure_shipped<FAST>(kT, rkT, kTp2, q.u00, q.u10, q.u01, q.u11, pm1, prk.y, t00, t01, t10, t11);
           double fpj = t00 * q.f00 + t01 * q.f10 + t10 * q.f01 + t11 * q.f11;
           fpj = fpj * 0.5;
           const double djx = pm.x - pk.x, djy = pm.y - pk.y, djz = pm.z - pk.z;

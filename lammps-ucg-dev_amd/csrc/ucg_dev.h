@@ -41,6 +41,7 @@ struct PairDev {
   int dens_as_shipped;      // 1: back-force uses the proximity function itself (App. B #12)
   double kT;
   double rkT;          // RN(1/kT), used by the FAST kernels' exact division
+  int kT_pow2;         // kT is a power of two: a * rkT is the exact quotient
   int gather_slots;    // lanes per bead in k_pair_gather (1, 4, 8 or 16): part of the canonical order
   int stage_own;       // 1: k_pair_gather keeps its workgroup's own beads in LDS behind the tables
   int stage_own_allowed;  // the context option "stage_own" (kernels with other block shapes decide the fit themselves)

@@ -87,6 +87,7 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
   const int nlocal = A.nlocal;
   const int na1 = P.n_actual + 1;
   const double kT = P.kT, rkT = P.rkT;
+  const int kTp2 = P.kT_pow2;
   double ev[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int err = 0;
 
@@ -229,8 +230,8 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
           // pseudo-likelihood scores (:492-502): S[k][a] -= u[a][state of the neighbour] / kT
           const double ua = sm ? q.u01 : q.u00, ub = sm ? q.u11 : q.u10;
           if (FAST) {
-            s0 -= div_by_const(ua, kT, rkT);
-            s1 -= div_by_const(ub, kT, rkT);
+            s0 -= div_kT(ua, kT, rkT, kTp2);
+            s1 -= div_kT(ub, kT, rkT, kTp2);
           } else {
             s0 -= ua / kT;
             s1 -= ub / kT;
@@ -289,8 +290,8 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
           const double pj0 = k_is_i ? pm_as_j0 : kj0, pj1 = k_is_i ? pm_as_j1 : kj1;
 
           double Jij = q.u11 + q.u00 - cu01 - cu10;
-          if ((FAST ? div_by_const(Jij, kT, rkT) : Jij / kT) < -709.0) Jij = -700.0 * kT;
-          const double mJkT = FAST ? div_by_const(-Jij, kT, rkT) : -Jij / kT;
+          if ((FAST ? div_kT(Jij, kT, rkT, kTp2) : Jij / kT) < -709.0) Jij = -700.0 * kT;
+          const double mJkT = FAST ? div_kT(-Jij, kT, rkT, kTp2) : -Jij / kT;
           const double bij = ucg_exp(mJkT);
           const double aij = ucg_expm1(mJkT);
           const double Qij = (pi1 + pj1) * aij + 1.;
@@ -317,11 +318,11 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
               const double qa = div_by_const(pij00, d0, r0), qb = div_by_const(n01, d0, r0);
               const double qc = div_by_const(n10, d1, r1), qd = div_by_const(pij11, d1, r1);
               if (k_is_i) {
-                s0 -= div_by_const(qa * q.u00 + qc * cu01, kT, rkT);
-                s1 -= div_by_const(qb * cu10 + qd * q.u11, kT, rkT);
+                s0 -= div_kT(qa * q.u00 + qc * cu01, kT, rkT, kTp2);
+                s1 -= div_kT(qb * cu10 + qd * q.u11, kT, rkT, kTp2);
               } else {
-                s0 -= div_by_const(qa * q.u00 + qb * cu01, kT, rkT);
-                s1 -= div_by_const(qc * cu10 + qd * q.u11, kT, rkT);
+                s0 -= div_kT(qa * q.u00 + qb * cu01, kT, rkT, kTp2);
+                s1 -= div_kT(qc * cu10 + qd * q.u11, kT, rkT, kTp2);
               }
             } else if (k_is_i) {
               const double pj0i0 = pij00 / pi0, pj0i1 = pij01 / pi0, pj1i0 = pij10 / pi1, pj1i1 = pij11 / pi1;

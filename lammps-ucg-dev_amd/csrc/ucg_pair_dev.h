@@ -31,6 +31,13 @@ __device__ __forceinline__ double div_by_const(const double a, const double b, c
   return fma(r, y, q);
 }
 
+// a / kT in the FAST kernels.  When kT is a power of two (kT = 1 in reduced units at T* = 1) its reciprocal
+// is exact and a * (1/kT) IS the correctly rounded quotient; otherwise div_by_const.  `pow2` is uniform.
+__device__ __forceinline__ double div_kT(const double a, const double kT, const double rkT, const int pow2)
+{
+  return pow2 ? a * rkT : div_by_const(a, kT, rkT);
+}
+
 // is b a denominator div_by_const is exact for?  (normal, mid-range exponent, significand not all ones)
 __device__ __forceinline__ bool recip_ok(const double b)
 {

@@ -222,7 +222,7 @@ def test_exact_division_by_constant(gpu_ctx, kT):
 
 
 @pytest.mark.parametrize("style", ["table_ucgld", "table_ucg_bethe"])
-@pytest.mark.parametrize("tabstyle,tablength,T", [("spline", 1024, 0.7), ("linear", 2048, 1.3), ("lookup", 3000, 1.0)])
+@pytest.mark.parametrize("tabstyle,tablength,T", [("spline", 1024, 0.7), ("linear", 2048, 1.3), ("lookup", 3000, 1.0), ("spline", 512, 0.25)])
 def test_fast_and_generic_kernels_give_the_same_bits(fresh_ctx, pkg, orc, style, tabstyle, tablength, T):
     ctx = fresh_ctx
     deck = util.make_deck(tabstyle, tablength)
