@@ -553,8 +553,12 @@ static int pair_compute_impl(ucg_pair *p, int eflag, int vflag, double *eng_vdwl
         L.blockflag = p->d_blockflag.get();
         L.blockwant = part == 1 ? 0 : 1;
       }
-      UCG_HIP(launch_pair_gather(p->dev, ctx->atoms_dev(), L, ev, p->d_evpart.get(), p->d_evout.get(), p->d_err.get(),
-                                 ctx->stream));
+      if (ctx->fma_contract)
+        UCG_HIP(launch_pair_gather_fused(p->dev, ctx->atoms_dev(), L, ev, p->d_evpart.get(), p->d_evout.get(),
+                                         p->d_err.get(), ctx->stream));
+      else
+        UCG_HIP(launch_pair_gather(p->dev, ctx->atoms_dev(), L, ev, p->d_evpart.get(), p->d_evout.get(), p->d_err.get(),
+                                   ctx->stream));
     }
     if (ctx->prof_on) {
       UCG_HIP(hipEventRecord(e1, ctx->stream));
@@ -1219,6 +1223,10 @@ int ucg_ctx_set_option(ucg_ctx *ctx, const char *name, int value)
   }
   if (std::strcmp(name, "md_no_fuse") == 0) {
     ctx->md_no_fuse = value != 0;
+    return UCG_OK;
+  }
+  if (std::strcmp(name, "fma_contract") == 0) {
+    ctx->fma_contract = value != 0;
     return UCG_OK;
   }
   if (std::strcmp(name, "rows_untiled") == 0) {

@@ -97,6 +97,7 @@ struct ucg_ctx {
   bool stage_own = true;  // option "stage_own": LDS staging of the workgroup's own beads in k_pair_gather
   int gather_slots = 1;  // option "gather_slots": lanes per bead of the ucgld / bethe gather kernels
   bool force_generic_kernels = false;  // option "generic_kernels": never pick the FAST variants
+  bool fma_contract = false;           // option "fma_contract": gather kernels compiled with FMA contraction (not bit-exact)
   bool rows_untiled = false;           // option "rows_untiled": build rows with the one-lane-per-bead kernels
 
   // atoms

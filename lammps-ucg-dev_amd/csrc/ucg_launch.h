@@ -14,6 +14,8 @@ namespace ucg {
 int pair_gather_blocks(int nlocal, int slots);
 hipError_t launch_pair_gather(const PairDev &P, const AtomsDev &A, const ListDev &L, bool ev,
                               double *evpart, double *evout, int *errflag, hipStream_t st);
+hipError_t launch_pair_gather_fused(const PairDev &P, const AtomsDev &A, const ListDev &L, bool ev,
+                              double *evpart, double *evout, int *errflag, hipStream_t st);
 hipError_t launch_block_classify(const AtomsDev &A, const ListDev &L, int slots, int *flags, hipStream_t st);
 
 hipError_t launch_selftest_div(double b, unsigned long long seed, int n, unsigned long long *d_mismatches, hipStream_t st);

@@ -479,10 +479,16 @@ hipError_t launch_style(const PairDev &P, const AtomsDev &A, const ListDev &L, b
 
 }  // namespace
 
+#ifdef UCG_FUSED
+#define launch_pair_gather launch_pair_gather_fused
+#endif
+
+#ifndef UCG_FUSED
 int pair_gather_blocks(int nlocal, int slots)
 {
   return (int) (((long long) nlocal * slots + PAIR_BLOCK - 1) / PAIR_BLOCK);
 }
+#endif
 
 hipError_t launch_pair_gather(const PairDev &P, const AtomsDev &A, const ListDev &L, bool ev,
                               double *evpart, double *evout, int *errflag, hipStream_t st)
@@ -500,6 +506,7 @@ hipError_t launch_pair_gather(const PairDev &P, const AtomsDev &A, const ListDev
   return e;
 }
 
+#ifndef UCG_FUSED
 hipError_t launch_block_classify(const AtomsDev &A, const ListDev &L, int slots, int *flags, hipStream_t st)
 {
   const int nblocks = pair_gather_blocks(A.nlocal, slots);
@@ -516,5 +523,7 @@ hipError_t launch_selftest_div(double b, unsigned long long seed, int n, unsigne
   hipLaunchKernelGGL(k_selftest_div, dim3((n + 255) / 256), dim3(256), 0, st, b, 1.0 / b, seed, n, d_mismatches);
   return hipGetLastError();
 }
+
+#endif  // !UCG_FUSED
 
 }  // namespace ucg

@@ -383,3 +383,34 @@ def test_interior_and_boundary_launches_add_up(fresh_ctx, pkg, style, slots):
         assert util.bits_equal(both[k], full[k]), k
     # interior beads were final after part 1
     assert util.bits_equal(part1["f"][interior], full["f"][interior])
+
+
+@pytest.mark.parametrize("style", ["table_ucgld", "table_ucg_bethe"])
+def test_fma_contracted_kernels_within_tolerance(fresh_ctx, pkg, orc, style):
+    """option "fma_contract": the gather kernels compiled with FMA contraction.  NOT bit-identical to the scalar
+    reference (each fused multiply-add rounds once instead of twice); stated tolerance: 1e-12 of the largest
+    component, per quantity."""
+    ctx = fresh_ctx
+    deck = util.make_deck("spline", 1024)
+    beads = pkg.synth.make_beads(12, seed=19)
+    beads.ucgp = np.clip(np.random.default_rng(5).uniform(size=beads.n), 1e-6, 1 - 1e-6)
+    op = util.oracle_pair(style, deck)
+    sim = util.oracle_sim(beads, op, mode=1)
+    sim.rebuild()
+    assert sim.compute_forces(0, 0) == 0
+    O = sim.arrays()
+    ctx.set_units(1.0, 1.0, 1.0, 0.002)
+    ctx.set_option("fma_contract", 1)
+    ctx.upload_beads(beads)
+    ctx.domain_set(beads.boxlo, beads.boxhi, 2.5, 0.3, every=1, delay=0, check=1)
+    ctx.neigh_rebuild()
+    gp = util.gpu_pair(ctx, style, deck)
+    gp.compute(0, 0)
+    gp.check_errors()
+    G = ctx.atoms_download()
+    differs = False
+    for k in ("f", "scores") + (("ucgforce",) if style == "table_ucgld" else ()):
+        scale = np.max(np.abs(O[k]))
+        assert np.max(np.abs(G[k] - O[k])) <= 1e-12 * scale, k
+        differs |= not util.bits_equal(G[k], O[k])
+    assert differs  # it really is a different rounding, not the exact kernels
