@@ -610,11 +610,15 @@ __global__ __launch_bounds__(NB) void k_check_distance(const DomainDev D, int n,
 {
   // Neighbor::check_distance: any bead moved more than skin/2 since the last build
   const int i = blockIdx.x * NB + threadIdx.x;
-  if (i >= n) return;
-  const double4 p = pos4[i], h = xhold[i];
-  const double delx = p.x - h.x, dely = p.y - h.y, delz = p.z - h.z;
-  const double rsq = delx * delx + dely * dely + delz * delz;
-  if (rsq > D.triggersq) atomicOr(flag, 1);
+  bool moved = false;
+  if (i < n) {
+    const double4 p = pos4[i], h = xhold[i];
+    const double delx = p.x - h.x, dely = p.y - h.y, delz = p.z - h.z;
+    const double rsq = delx * delx + dely * dely + delz * delz;
+    moved = rsq > D.triggersq;
+  }
+  // one atomic per wavefront at most (thousands of beads cross the threshold on the same step)
+  if (__any(moved) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
 
 void setup_bins(Domain &D)
