@@ -17,6 +17,7 @@
 #include "ucg_hip.h"
 
 #include <cstring>
+#include <string>
 #include <vector>
 
 using namespace LAMMPS_NS;
@@ -276,4 +277,51 @@ void FixUCGStateGPU::post_force(int)
   to_device(SCORES | NSTATES | STATE | L);
   check(ucg_fix_ucgstate_post_force(ctx));
   from_device(P | (ld_flag ? 0 : (STATE | L)));
+}
+
+/* ------------------------------------------------------------------ fix cluster_switch */
+
+FixClusterSwitchGPU::FixClusterSwitchGPU(LAMMPS *lmp, int narg, char **arg) : FixUCGGPUBase(lmp, narg, arg)
+{
+  // UCG/fix_cluster_switch.cpp:37-60: arg[3] molID_seed, [4] mol_offset, [5] cutoff, [6] seed,
+  // [7] "rateFreq" [8] N, [9] "rateFile" [10] file, [11] "contactFile" [12] file
+  if (narg < 13) error->all(FLERR, "Illegal cluster_switch command");
+  mol_seed = utils::inumeric(FLERR, arg[3], false, lmp);
+  mol_offset = utils::inumeric(FLERR, arg[4], false, lmp);
+  cutoff = utils::numeric(FLERR, arg[5], false, lmp);
+  seed = utils::inumeric(FLERR, arg[6], false, lmp);
+  switchFreq = utils::inumeric(FLERR, arg[8], false, lmp);
+  rateFile = arg[10];
+  contactFile = arg[12];
+  if (atom->molecule_flag == 0) error->all(FLERR, "fix cluster_switch requires that atoms have molecule attributes");
+  vector_flag = 1;
+  size_vector = 7;
+  global_freq = 1;
+  extvector = 0;
+  force_reneighbor = 1;
+}
+
+int FixClusterSwitchGPU::setmask()
+{
+  return PRE_EXCHANGE;    // :347-352; the work itself runs inside the resident loop (ucg_md_run)
+}
+
+void FixClusterSwitchGPU::init()
+{
+  FixUCGGPUBase::init();
+  if (comm->nprocs > 1) error->all(FLERR, "USER-UCG/GPU fix cluster_switch is single-rank in this build");
+  // molecule ids in the order of the last ucg_atoms_upload (the pair style's), then the fix itself
+  std::vector<int> mol((size_t) atom->nlocal);
+  for (int i = 0; i < atom->nlocal; i++) mol[(size_t) i] = (int) atom->molecule[i];
+  check(ucg_atoms_upload_molecule(ctx, mol.data()));
+  check(ucg_fix_cluster_switch_create(ctx, groupbit, mol_seed, mol_offset, cutoff, seed, switchFreq, rateFile.c_str(),
+                                      contactFile.c_str()));
+}
+
+double FixClusterSwitchGPU::compute_vector(int n)
+{
+  // :887-897
+  double v[7];
+  check(ucg_fix_cluster_switch_vector(ctx, v));
+  return (n >= 0 && n < 7) ? v[n] : 0.0;
 }

@@ -6,6 +6,8 @@
      fix ID group nve/ucgld/wall/hard [bias_potential [H]]   (UCG/fix_nve_ucgld_wall_hard.h:12)
      fix ID group ucgld/langevin Tstart Tstop damp seed      (UCG/fix_ucgld_langevin.h:14-17)
      fix ID group ucgstate [ld | mc seed rate]               (UCG/fix_ucgstate.h:1-3)
+     fix ID group cluster_switch molSeed molOffset cutoff seed rateFreq N rateFile F contactFile F
+                                                             (UCG/fix_cluster_switch.cpp:37-60)
 
    Drop-in mode: LAMMPS owns the host arrays, so every hook refreshes what it reads
    (ucg_atoms_upload_owned), launches the kernel and copies back what it wrote
@@ -21,12 +23,15 @@ FixStyle(nve/ucgld,FixNVEUCGLDGPU);
 FixStyle(nve/ucgld/wall/hard,FixNVEUCGLDWallHardGPU);
 FixStyle(ucgld/langevin,FixUCGLDLangevinGPU);
 FixStyle(ucgstate,FixUCGStateGPU);
+FixStyle(cluster_switch,FixClusterSwitchGPU);
 // clang-format on
 #else
 #ifndef LMP_FIX_UCG_GPU_H
 #define LMP_FIX_UCG_GPU_H
 
 #include "fix.h"
+
+#include <string>
 
 struct ucg_ctx;
 
@@ -100,6 +105,23 @@ class FixUCGStateGPU : public FixUCGGPUBase {
   int ld_flag = 0, mc_flag = 0, mc_seed = 0;
   double mc_rate = 0.01;
   bool created = false;
+};
+
+// fix cluster_switch needs the RESIDENT lists (the device-built full list and ghosts): it is offered for the
+// resident loop only, where ucg_md_run calls its pre_exchange work at the forced re-neighbour steps.  In a
+// drop-in run the reference's own CPU fix cluster_switch keeps working unchanged on LAMMPS' arrays (it only
+// changes atom->type, which the pair style uploads at the next re-neighbour step).
+class FixClusterSwitchGPU : public FixUCGGPUBase {
+ public:
+  FixClusterSwitchGPU(class LAMMPS *, int, char **);
+  int setmask() override;
+  void init() override;
+  double compute_vector(int) override;
+
+ protected:
+  int mol_seed, mol_offset, seed, switchFreq;
+  double cutoff;
+  std::string rateFile, contactFile;
 };
 
 }    // namespace LAMMPS_NS
