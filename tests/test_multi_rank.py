@@ -73,8 +73,10 @@ def test_world2_gloo_exchange_protocol():
 
 
 @pytest.mark.gpu
-def test_world2_decomposed_run_matches_single_rank(fresh_ctx, pkg):
-    res = _launch("gpu")
+@pytest.mark.parametrize("world", [2, 4])
+def test_world2_decomposed_run_matches_single_rank(fresh_ctx, pkg, world):
+    """2 x 1 x 1 and 2 x 2 x 1 bricks (four ranks share the one GPU of the test box)"""
+    res = _launch("gpu", world=world)
     assert all(r["inside"] for r in res)
     assert all(r["nrebuild"] >= 2 and r["nghost"] > 0 for r in res)
     # single-rank GPU run of the same beads, same settings
