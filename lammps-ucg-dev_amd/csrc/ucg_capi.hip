@@ -510,10 +510,19 @@ static int pair_compute_impl(ucg_pair *p, int eflag, int vflag, double *eng_vdwl
     if (ctx->list_inum != ctx->nlocal) return fail(ctx, UCG_ERR_INVALID, "neighbour list does not match the resident atoms");
     const bool ev = (eflag || vflag);
     if (ctx->gather_slots == 0) {
-      // auto: one lane per bead while that still gives every CU a workgroup (measured on MI355X: best
-      // down to ~250 k beads per GPU); below that, 4, 8, 16 lanes per bead (125 k beads: 4)
+      // auto: the kernel's time is (rounds of workgroups over the 256 CUs) x (lifetime of one workgroup),
+      // the latter ~ row length / lanes per bead + a fixed part; pick the lanes per bead that minimise it
+      // (matches the measured order at 125 k / 250 k / 500 k / 1 M beads per GPU)
       int slots = 1;
-      while (slots < 16 && (long long) ctx->nlocal * slots < 230000) slots = (slots == 1) ? 4 : slots * 2;
+      double best = 1e300;
+      for (int s2 : {1, 2, 4, 8, 16}) {
+        const long long blocks = ((long long) ctx->nlocal * s2 + 1023) / 1024;
+        const double cost = (double) ((blocks + 255) / 256) * (73.0 / s2 + 8.0);
+        if (cost < best - 1e-9) {
+          best = cost;
+          slots = s2;
+        }
+      }
       p->dev.gather_slots = slots;
       const size_t own = (size_t) (1024 / slots) * 36;
       p->dev.stage_own = (ctx->stage_own && (p->dev.tab_in_lds ? p->tab_lds_bytes : 0) + own + 6 * 1024 <= 160 * 1024) ? 1 : 0;
@@ -1238,8 +1247,8 @@ int ucg_ctx_set_option(ucg_ctx *ctx, const char *name, int value)
     return UCG_OK;
   }
   if (std::strcmp(name, "gather_slots") == 0) {
-    if (value != 0 && value != 1 && value != 4 && value != 8 && value != 16) {
-      ctx->err = "gather_slots must be 0 (auto), 1, 4, 8 or 16";
+    if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 16) {
+      ctx->err = "gather_slots must be 0 (auto), 1, 2, 4, 8 or 16";
       return UCG_ERR_INVALID;
     }
     ctx->gather_slots = value;

@@ -469,6 +469,7 @@ hipError_t launch_style(const PairDev &P, const AtomsDev &A, const ListDev &L, b
     default: return launch_style_ts<STYLE, 2, SL>(P, A, L, ev, evpart, errflag, st, nblocks);      \
   }
   switch (P.gather_slots) {
+    case 2: UCG_TS(2)
     case 4: UCG_TS(4)
     case 8: UCG_TS(8)
     case 16: UCG_TS(16)

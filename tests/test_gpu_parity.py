@@ -329,7 +329,7 @@ def test_pair_bethe_density_parity(fresh_ctx, pkg, orc, tabstyle, tablength, ent
     assert np.abs(G["f"] - R["f"]).max() <= 1e-10 * np.abs(R["f"]).max()
 
 
-@pytest.mark.parametrize("slots", [1, 4, 8, 16])
+@pytest.mark.parametrize("slots", [1, 2, 4, 8, 16])
 @pytest.mark.parametrize("style", ["table_ucgld", "table_ucg_bethe"])
 def test_gather_slots_define_the_canonical_order(fresh_ctx, pkg, orc, slots, style):
     """lanes per bead of the gather kernel = interleaved partial sums + fixed tree in the oracle"""
