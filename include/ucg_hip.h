@@ -283,6 +283,26 @@ int ucg_fix_cluster_switch_maxmol(const ucg_ctx *ctx);
 int ucg_fix_cluster_switch_array(ucg_ctx *ctx, int which, int *out);
 /* compute_vector: attempts, successes, attempts ON, attempts OFF, successes ON, successes OFF, cluster size */
 int ucg_fix_cluster_switch_vector(const ucg_ctx *ctx, double *out7);
+/* Decomposed runs.  Molecule ids travel with migrating beads; ghosts get {group mask, molecule id} through
+ * ucg_halo_molmask_pack / _unpack (8 bytes per ghost, after ucg_border_unpack).  The caller performs the
+ * reductions the reference does with MPI_Allreduce: after _create the survey scalars (_scalars: maxmol MAX,
+ * switchable atoms of mol_seed SUM, switchable atoms SUM -> _set_scalars, UCG/fix_cluster_switch.cpp:114-120)
+ * and mol_state / mol_restrict / presence (arrays 1, 2, 4: MAX, :157-158); in check_cluster the labels between
+ * sweeps (array 5: MIN, :664) until no rank changed anything; in attempt_switch mol_accept (array 3: MAX, :750).
+ * _set_array accepts which = 1..5; _array additionally 4 = presence, 5 = the device labels. */
+int ucg_halo_molmask_pack(ucg_ctx *ctx, void *sendbuf);
+int ucg_halo_molmask_unpack(ucg_ctx *ctx, const void *recvbuf);
+int ucg_fix_cluster_switch_scalars(const ucg_ctx *ctx, long long *out3);
+int ucg_fix_cluster_switch_set_scalars(ucg_ctx *ctx, long long maxmol, long long nspm, long long nmolatoms);
+int ucg_fix_cluster_switch_set_array(ucg_ctx *ctx, int which, const int *in);
+int ucg_fix_cluster_switch_sweep(ucg_ctx *ctx, int begin, int *changed);
+int ucg_fix_cluster_switch_finalize(ucg_ctx *ctx);
+int ucg_fix_cluster_switch_attempt_local(ucg_ctx *ctx);
+int ucg_fix_cluster_switch_attempt_apply(ucg_ctx *ctx);
+/* forced = a re-neighbour is forced at the step given to ucg_md_set_timestep; switching = the fix also runs */
+int ucg_fix_cluster_switch_due(const ucg_ctx *ctx, int *forced, int *switching);
+int ucg_fix_cluster_switch_advance(ucg_ctx *ctx);
+int ucg_md_set_timestep(ucg_ctx *ctx, long long ntimestep);
 
 /* ------------------------------------------------------- RanMars on the device
  * the upstream generator behind both fixes, exposed for known-answer tests:

@@ -45,7 +45,11 @@ SYMBOLS = [
     "ucg_pair_compute_part", "ucg_pair_density_phase", "ucg_pair_density_buffer", "ucg_halo_aux_pack", "ucg_halo_aux_unpack",
     "ucg_atoms_upload_molecule", "ucg_atoms_download_molecule", "ucg_fix_cluster_switch_create",
     "ucg_fix_cluster_switch_check_cluster", "ucg_fix_cluster_switch_attempt_switch", "ucg_fix_cluster_switch_maxmol",
-    "ucg_fix_cluster_switch_array", "ucg_fix_cluster_switch_vector",
+    "ucg_fix_cluster_switch_array", "ucg_fix_cluster_switch_vector", "ucg_halo_molmask_pack", "ucg_halo_molmask_unpack",
+    "ucg_fix_cluster_switch_scalars", "ucg_fix_cluster_switch_set_scalars", "ucg_fix_cluster_switch_set_array",
+    "ucg_fix_cluster_switch_sweep", "ucg_fix_cluster_switch_finalize", "ucg_fix_cluster_switch_attempt_local",
+    "ucg_fix_cluster_switch_attempt_apply", "ucg_fix_cluster_switch_due", "ucg_fix_cluster_switch_advance",
+    "ucg_md_set_timestep",
     "ucg_fix_langevin_create", "ucg_fix_langevin_init", "ucg_fix_langevin_init_from_ucgml",
     "ucg_fix_langevin_post_force", "ucg_fix_langevin_end_of_step", "ucg_fix_langevin_t_target",
     "ucg_fix_ucgstate_create", "ucg_fix_ucgstate_post_force",
@@ -144,6 +148,18 @@ def lib():
     L.ucg_fix_cluster_switch_maxmol.argtypes = [vp]
     L.ucg_fix_cluster_switch_array.argtypes = [vp, C.c_int, c_int_p]
     L.ucg_fix_cluster_switch_vector.argtypes = [vp, c_double_p]
+    L.ucg_halo_molmask_pack.argtypes = [vp, C.c_void_p]
+    L.ucg_halo_molmask_unpack.argtypes = [vp, C.c_void_p]
+    L.ucg_fix_cluster_switch_scalars.argtypes = [vp, c_ll_p]
+    L.ucg_fix_cluster_switch_set_scalars.argtypes = [vp, C.c_longlong, C.c_longlong, C.c_longlong]
+    L.ucg_fix_cluster_switch_set_array.argtypes = [vp, C.c_int, c_int_p]
+    L.ucg_fix_cluster_switch_sweep.argtypes = [vp, C.c_int, c_int_p]
+    L.ucg_fix_cluster_switch_finalize.argtypes = [vp]
+    L.ucg_fix_cluster_switch_attempt_local.argtypes = [vp]
+    L.ucg_fix_cluster_switch_attempt_apply.argtypes = [vp]
+    L.ucg_fix_cluster_switch_due.argtypes = [vp, c_int_p, c_int_p]
+    L.ucg_fix_cluster_switch_advance.argtypes = [vp]
+    L.ucg_md_set_timestep.argtypes = [vp, C.c_longlong]
     L.ucg_fix_langevin_create.argtypes = [vp, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int]
     L.ucg_fix_langevin_init.argtypes = [vp, C.c_int, c_double_p, c_double_p]
     L.ucg_fix_langevin_init_from_ucgml.argtypes = [vp, C.c_int, c_double_p]
@@ -380,6 +396,56 @@ class Context:
             self.chk(self.L.ucg_fix_cluster_switch_array(self.h, w, _ip(a)))
             out[k] = a[:n]
         return out
+
+    # decomposed runs (multi.RankSim drives these; see include/ucg_hip.h)
+    def halo_molmask_pack(self, sendbuf):
+        self.chk(self.L.ucg_halo_molmask_pack(self.h, sendbuf))
+
+    def halo_molmask_unpack(self, recvbuf):
+        self.chk(self.L.ucg_halo_molmask_unpack(self.h, recvbuf))
+
+    def cs_scalars(self):
+        out = np.zeros(3, dtype=np.int64)
+        self.chk(self.L.ucg_fix_cluster_switch_scalars(self.h, out.ctypes.data_as(c_ll_p)))
+        return out
+
+    def cs_set_scalars(self, maxmol, nspm, nmolatoms):
+        self.chk(self.L.ucg_fix_cluster_switch_set_scalars(self.h, int(maxmol), int(nspm), int(nmolatoms)))
+
+    def cs_array(self, which):
+        n = self.L.ucg_fix_cluster_switch_maxmol(self.h) + 1
+        a = np.zeros(max(n, 1), dtype=np.int32)
+        self.chk(self.L.ucg_fix_cluster_switch_array(self.h, which, _ip(a)))
+        return a[:n]
+
+    def cs_set_array(self, which, arr):
+        a = _i32(arr)
+        self.chk(self.L.ucg_fix_cluster_switch_set_array(self.h, which, _ip(a)))
+
+    def cs_sweep(self, begin):
+        ch = C.c_int(0)
+        self.chk(self.L.ucg_fix_cluster_switch_sweep(self.h, int(begin), C.byref(ch)))
+        return ch.value
+
+    def cs_finalize(self):
+        self.chk(self.L.ucg_fix_cluster_switch_finalize(self.h))
+
+    def cs_attempt_local(self):
+        self.chk(self.L.ucg_fix_cluster_switch_attempt_local(self.h))
+
+    def cs_attempt_apply(self):
+        self.chk(self.L.ucg_fix_cluster_switch_attempt_apply(self.h))
+
+    def cs_due(self):
+        f, sw = C.c_int(0), C.c_int(0)
+        self.chk(self.L.ucg_fix_cluster_switch_due(self.h, C.byref(f), C.byref(sw)))
+        return bool(f.value), bool(sw.value)
+
+    def cs_advance(self):
+        self.chk(self.L.ucg_fix_cluster_switch_advance(self.h))
+
+    def md_set_timestep(self, n):
+        self.chk(self.L.ucg_md_set_timestep(self.h, int(n)))
 
     def fix_cluster_switch_vector(self):
         out = np.zeros(7)

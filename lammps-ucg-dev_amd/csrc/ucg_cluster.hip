@@ -25,7 +25,11 @@
 //    switchable atom of the molecule counts and is switched (identical unless a molecule has more
 //    switchable atoms than molecule mol_seed);
 //  * partner indices outside 0..maxmol are ignored (the reference reads out of bounds, :629-646);
-//  * single rank only (its MPI_Allreduce steps are identities); the debug log files are not written.
+//  * decomposed runs: the caller performs the reference's MPI_Allreduce steps between the phases exported
+//    below (survey scalars and arrays after _create, labels between sweeps, accept flags); as in the
+//    reference, the rank holding the majority of a molecule's switchable atoms draws for it from its own
+//    RanPark stream, so WHICH molecules switch depends on the decomposition; the cluster labels do not.
+//  * the debug log files are not written.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -51,6 +55,8 @@ struct ClusterSwitch {
   long long next_reneighbor = 0;
   double stats[6] = {0, 0, 0, 0, 0, 0}, nCluster = 0;
   int sweeps = 0;
+  long long survey[3] = {0, 0, 0};  // this rank's maxmol, switchable atoms of mol_seed, switchable atoms
+  bool synced = true;               // decomposed runs: the survey has been reduced over the ranks
   DevBuf<int> d_lab, d_state, d_accept, d_sum, d_flag, d_typeflag, d_contact;
 };
 
@@ -173,7 +179,7 @@ __device__ __forceinline__ int cs_partner(const int *state, int m, int maxmol, i
 
 // typeflag[itype * ntypes1 + jtype] != 0: (itype, jtype) is in the contact map
 __global__ __launch_bounds__(CB) void k_cs_sweep(const SweepArgs S, const double4 *pos4, const int *meta, const int *mask,
-                                                const int *mol, const int *ghost_src, const int *numneigh,
+                                                const int *mol, const int *numneigh,
                                                 const int *neigh, const int *typeflag, const int *state, int *lab,
                                                 int *changed)
 {
@@ -186,9 +192,8 @@ __global__ __launch_bounds__(CB) void k_cs_sweep(const SweepArgs S, const double
   bool any = false;
   for (int e = 0; e < n; e++) {
     const int j = neigh[(size_t) e * S.pitch + k] & 0x1FFFFFFF;
-    const int jo = j < S.nlocal ? j : ghost_src[j - S.nlocal];  // group and molecule of a ghost are its owner's
-    if (!(mask[jo] & S.groupbit)) continue;
-    const int jm = mol[jo];
+    if (!(mask[j] & S.groupbit)) continue;  // ghosts carry their owner's group bits and molecule id
+    const int jm = mol[j];
     const int li = lab[im], lj = lab[jm];
     if (li == lj) continue;
     const int jtype = meta[j] & 0xFFFF;
@@ -213,14 +218,15 @@ __global__ __launch_bounds__(CB) void k_cs_sweep(const SweepArgs S, const double
 
 // onflag[type]: +1 per occurrence of the type among the ON types, offflag likewise (an atom type listed
 // twice counts twice, as in the reference's loop over k)
-__global__ __launch_bounds__(CB) void k_cs_molsum(int nlocal, const int *meta, const int *mol, const int *oncount,
-                                                 const int *offcount, int *sum)
+__global__ __launch_bounds__(CB) void k_cs_molsum(int nlocal, int groupbit, const int *meta, const int *mask, const int *mol,
+                                                 const int *oncount, const int *offcount, int *sum, int *present)
 {
   const int i = blockIdx.x * CB + threadIdx.x;
   if (i >= nlocal) return;
   const int t = meta[i] & 0xFFFF;
   const int d = oncount[t] - offcount[t];
-  if (d != 0) atomicAdd(&sum[mol[i]], d);
+  if (d != 0) atomicAdd(&sum[mol[i]], d);      // confirm_molecule looks at every local atom of the molecule
+  if (mask[i] & groupbit) present[mol[i]] = 1;  // the molecules this rank iterates over (:731-739)
 }
 
 __global__ __launch_bounds__(CB) void k_cs_apply(int nlocal, int *meta, const int *mol, const int *accept,
@@ -283,20 +289,22 @@ int guarded(ucg_ctx *ctx, F &&fn)
 void need(ucg_ctx *ctx)
 {
   if (!ctx->cs) throw InputError{"fix cluster_switch not created"};
+  if (!ctx->cs->synced) throw InputError{"fix cluster_switch: the survey of the ranks has not been reduced (ucg_fix_cluster_switch_set_scalars)"};
   if (!ctx->has_mol) throw InputError{"fix cluster_switch requires that atoms have molecule attributes"};
 }
 
 }  // namespace
 
-// check_cluster (:551-719) on the current full list
-void cluster_check(ucg_ctx *ctx)
+// check_cluster (:551-719) in three phases, so that a decomposed run can reduce the labels over the
+// ranks between sweeps (the reference's MPI_Allreduce MIN of mol_cluster, :664):
+//   labels_init   the starting labels (:573-599) from the molecules present in the group (anywhere)
+//   sweep_local   kernel sweeps over this rank's rows until one changes nothing; returns "changed at all"
+//   finalize      restrict / state flags of the seed's cluster (:675-690)
+void cluster_labels_init(ucg_ctx *ctx)
 {
   need(ctx);
   ClusterSwitch &C = *ctx->cs;
-  if (ctx->list_inum != ctx->nlocal || !ctx->ghost_src_valid)
-    throw InputError{"fix cluster_switch needs the device-built full list (ucg_neigh_rebuild)"};
   const int maxmol = C.maxmol;
-  // initial labels (:573-599); on one rank the set of molecules in the group never changes
   std::vector<int> lab((size_t) maxmol + 1, -1);
   lab[(size_t) C.mol_seed] = C.mol_seed;
   lab[(size_t) (C.mol_seed - C.mol_offset)] = C.mol_seed;
@@ -309,31 +317,49 @@ void cluster_check(ucg_ctx *ctx)
     }
   upload(ctx, C.d_lab, lab);
   upload(ctx, C.d_state, C.mol_state);
+  C.sweeps = 0;
+}
+
+bool cluster_sweep_local(ucg_ctx *ctx)
+{
+  need(ctx);
+  ClusterSwitch &C = *ctx->cs;
+  if (ctx->list_inum != ctx->nlocal)
+    throw InputError{"fix cluster_switch needs the device-built full list (ucg_neigh_rebuild)"};
   C.d_flag.reserve(4);
   SweepArgs S;
   S.nlocal = ctx->nlocal;
   S.pitch = ctx->list_pitch;
   S.groupbit = C.groupbit;
-  S.maxmol = maxmol;
+  S.maxmol = C.maxmol;
   S.mol_offset = C.mol_offset;
   S.ntypes1 = ctx->ntypes + 1;
   S.cutsq = C.cutsq;
-  C.sweeps = 0;
+  bool any = false;
   for (;;) {
     UCG_HIP(hipMemsetAsync(C.d_flag.get(), 0, sizeof(int), ctx->stream));
-    hipLaunchKernelGGL(k_cs_sweep, dim3(nblk(ctx->nlocal)), dim3(CB), 0, ctx->stream, S, ctx->pos4.get(), ctx->meta.get(),
-                       ctx->mask.get(), ctx->mol.get(), ctx->ghost_src.get(), ctx->numneigh.get(), ctx->neigh.get(),
-                       C.d_typeflag.get(), C.d_state.get(), C.d_lab.get(), C.d_flag.get());
+    if (ctx->nlocal > 0)
+      hipLaunchKernelGGL(k_cs_sweep, dim3(nblk(ctx->nlocal)), dim3(CB), 0, ctx->stream, S, ctx->pos4.get(), ctx->meta.get(),
+                         ctx->mask.get(), ctx->mol.get(), ctx->numneigh.get(), ctx->neigh.get(), C.d_typeflag.get(),
+                         C.d_state.get(), C.d_lab.get(), C.d_flag.get());
     UCG_HIP(hipGetLastError());
     int changed = 0;
     UCG_HIP(hipMemcpyAsync(&changed, C.d_flag.get(), sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     UCG_HIP(hipStreamSynchronize(ctx->stream));
     C.sweeps++;
     if (!changed) break;
+    any = true;
     if (C.sweeps > 100000) throw InputError{"fix cluster_switch: label propagation does not converge"};
   }
+  return any;
+}
+
+void cluster_finalize(ucg_ctx *ctx)
+{
+  need(ctx);
+  ClusterSwitch &C = *ctx->cs;
+  const int maxmol = C.maxmol;
   download(ctx, C.mol_cluster, C.d_lab.get(), (size_t) maxmol + 1);
-  // :675-690
   const int clusterID = C.mol_cluster[(size_t) C.mol_seed];
   C.nCluster = 0.0;
   for (int i = 0; i <= maxmol; i++) {
@@ -349,14 +375,22 @@ void cluster_check(ucg_ctx *ctx)
   }
 }
 
-// attempt_switch (:721-802)
-void cluster_attempt(ucg_ctx *ctx)
+void cluster_check(ucg_ctx *ctx)
+{
+  cluster_labels_init(ctx);
+  cluster_sweep_local(ctx);
+  cluster_finalize(ctx);
+}
+
+// attempt_switch (:721-802) in two phases: attempt_local decides the molecules this rank is the decision
+// maker of (confirm_molecule's majority rule over ITS atoms, one RanPark draw each, ascending id) and leaves
+// them in mol_accept; a decomposed run takes the maximum over the ranks (:750) before attempt_apply.
+void cluster_attempt_local(ucg_ctx *ctx)
 {
   need(ctx);
   ClusterSwitch &C = *ctx->cs;
   const int maxmol = C.maxmol, n = ctx->nlocal;
   const size_t nm = (size_t) maxmol + 1;
-  // confirm_molecule's sumState for every molecule in one pass
   std::vector<int> oncount((size_t) ctx->ntypes + 1, 0), offcount((size_t) ctx->ntypes + 1, 0);
   for (size_t k = 0; k < C.typesON.size(); k++) {
     if (C.typesON[k] >= 0 && C.typesON[k] <= ctx->ntypes) oncount[(size_t) C.typesON[k]]++;
@@ -365,21 +399,24 @@ void cluster_attempt(ucg_ctx *ctx)
   // an atom matching ON[k] is not tested against OFF[k] for the same k (else-if, :817-846)
   for (size_t k = 0; k < C.typesON.size(); k++)
     if (C.typesON[k] == C.typesOFF[k] && C.typesOFF[k] >= 0 && C.typesOFF[k] <= ctx->ntypes) offcount[(size_t) C.typesOFF[k]]--;
-  DevBuf<int> d_on, d_off;
+  DevBuf<int> d_on, d_off, d_present;
   upload(ctx, d_on, oncount);
   upload(ctx, d_off, offcount);
   C.d_sum.reserve(nm);
+  d_present.reserve(nm);
   UCG_HIP(hipMemsetAsync(C.d_sum.get(), 0, nm * sizeof(int), ctx->stream));
+  UCG_HIP(hipMemsetAsync(d_present.get(), 0, nm * sizeof(int), ctx->stream));
   if (n > 0)
-    hipLaunchKernelGGL(k_cs_molsum, dim3(nblk(n)), dim3(CB), 0, ctx->stream, n, ctx->meta.get(), ctx->mol.get(), d_on.get(),
-                       d_off.get(), C.d_sum.get());
-  std::vector<int> sum;
+    hipLaunchKernelGGL(k_cs_molsum, dim3(nblk(n)), dim3(CB), 0, ctx->stream, n, C.groupbit, ctx->meta.get(), ctx->mask.get(),
+                       ctx->mol.get(), d_on.get(), d_off.get(), C.d_sum.get(), d_present.get());
+  std::vector<int> sum, here;
   download(ctx, sum, C.d_sum.get(), nm);
+  download(ctx, here, d_present.get(), nm);  // the molecules with an in-group atom on THIS rank (the std::map of :731-739)
 
   const double decisionBuffer = (double) C.nSwitchPerMol / 2.0 - 1.0 + 0.01;
   C.mol_accept.assign(nm, -1);
   for (int mID = 0; mID <= maxmol; mID++) {  // std::map iteration: ascending molecule id
-    if (!C.present[(size_t) mID]) continue;
+    if (!here[(size_t) mID]) continue;
     int confirmflag = 0;
     if (C.mol_restrict[(size_t) mID] == 1) {
       const double sumState = (double) sum[(size_t) mID];
@@ -392,6 +429,13 @@ void cluster_attempt(ucg_ctx *ctx)
       C.mol_accept[(size_t) mID] = (r < checkProb) ? 1 : 0;
     }
   }
+}
+
+void cluster_attempt_apply(ucg_ctx *ctx)
+{
+  need(ctx);
+  ClusterSwitch &C = *ctx->cs;
+  const int maxmol = C.maxmol, n = ctx->nlocal;
   // gather_statistics (:899-935), before the states flip
   for (int i = 0; i <= maxmol; i++) {
     if (C.mol_restrict[(size_t) i] != 1) continue;
@@ -421,6 +465,12 @@ void cluster_attempt(ucg_ctx *ctx)
       if (C.mol_state[(size_t) i] == 0) C.mol_state[(size_t) i] = 1;
       else if (C.mol_state[(size_t) i] == 1) C.mol_state[(size_t) i] = 0;
     }
+}
+
+void cluster_attempt(ucg_ctx *ctx)
+{
+  cluster_attempt_local(ctx);
+  cluster_attempt_apply(ctx);
 }
 
 // the step hook of the resident loop: is a rebuild forced at this step (Neighbor::decide), and the
@@ -473,7 +523,7 @@ int ucg_fix_cluster_switch_create(ucg_ctx *ctx, int groupbit, int mol_seed, int 
   if (!ctx || !rate_file || !contact_file) return UCG_ERR_INVALID;
   return guarded(ctx, [&]() -> int {
     if (!ctx->has_mol) throw InputError{"fix cluster_switch requires that atoms have molecule attributes"};
-    if (ctx->dom_world > 1) throw InputError{"fix cluster_switch is single-rank in this build"};
+    const bool multi = ctx->dom_world > 1;  // the caller then reduces the survey over the ranks (set_scalars / set_array)
     cluster_destroy(ctx);
     ctx->cs = new ClusterSwitch();
     ClusterSwitch &C = *ctx->cs;
@@ -507,15 +557,21 @@ int ucg_fix_cluster_switch_create(ucg_ctx *ctx, int groupbit, int mol_seed, int 
           if (mol[(size_t) i] == mol_seed) nspm++;
         }
     }
-    if (maxmol < 0) throw InputError{"Selected group does not have any mols (fix cluster_switch)"};
-    if (nspm < 1) throw InputError{"fix cluster_switch: molecule mol_seed has no switchable atoms (division by zero in the reference)"};
-    if (mol_seed < 0 || mol_seed > maxmol || mol_seed - mol_offset < 0 || mol_seed - mol_offset > maxmol)
-      throw InputError{"fix cluster_switch: mol_seed / mol_seed - mol_offset outside 0..maxmol (out-of-bounds write in the reference)"};
-    for (int i = 0; i < n; i++)
-      if (mol[(size_t) i] > maxmol) throw InputError{"fix cluster_switch: an atom outside the group has a molecule id beyond the group's"};
+    if (!multi) {
+      if (maxmol < 0) throw InputError{"Selected group does not have any mols (fix cluster_switch)"};
+      if (nspm < 1) throw InputError{"fix cluster_switch: molecule mol_seed has no switchable atoms (division by zero in the reference)"};
+      if (mol_seed < 0 || mol_seed > maxmol || mol_seed - mol_offset < 0 || mol_seed - mol_offset > maxmol)
+        throw InputError{"fix cluster_switch: mol_seed / mol_seed - mol_offset outside 0..maxmol (out-of-bounds write in the reference)"};
+    }
+    for (int i = 0; i < n; i++) maxmol = std::max(maxmol, mol[(size_t) i]);  // atoms outside the group index the arrays too
+    if (maxmol < 0) maxmol = 0;
     C.maxmol = maxmol;
     C.nSwitchPerMol = nspm;
-    C.nmol = nmolatoms / nspm;
+    C.nmol = nspm > 0 ? nmolatoms / nspm : 0;
+    C.survey[0] = maxmol;
+    C.survey[1] = nspm;
+    C.survey[2] = nmolatoms;
+    C.synced = !multi;
     const size_t nm = (size_t) maxmol + 1;
     C.mol_restrict.assign(nm, -1);
     C.mol_state.assign(nm, -1);
@@ -575,10 +631,124 @@ int ucg_fix_cluster_switch_maxmol(const ucg_ctx *ctx) { return (ctx && ctx->cs) 
 
 int ucg_fix_cluster_switch_array(ucg_ctx *ctx, int which, int *out)
 {
-  if (!ctx || !out || !ctx->cs || which < 0 || which > 3) return UCG_ERR_INVALID;
-  const ClusterSwitch &C = *ctx->cs;
-  const std::vector<int> &v = which == 0 ? C.mol_cluster : which == 1 ? C.mol_state : which == 2 ? C.mol_restrict : C.mol_accept;
-  std::memcpy(out, v.data(), v.size() * sizeof(int));
+  if (!ctx || !out || !ctx->cs || which < 0 || which > 5) return UCG_ERR_INVALID;
+  return guarded(ctx, [&]() -> int {
+    ClusterSwitch &C = *ctx->cs;
+    if (which == 5) {  // the labels as they stand on the device (between sweeps of a decomposed run)
+      std::vector<int> lab;
+      download(ctx, lab, C.d_lab.get(), (size_t) C.maxmol + 1);
+      std::memcpy(out, lab.data(), lab.size() * sizeof(int));
+      return UCG_OK;
+    }
+    const std::vector<int> &v = which == 0 ? C.mol_cluster : which == 1 ? C.mol_state : which == 2 ? C.mol_restrict
+                                : which == 3 ? C.mol_accept : C.present;
+    std::memcpy(out, v.data(), v.size() * sizeof(int));
+    return UCG_OK;
+  });
+}
+
+/* decomposed runs: the caller reduces over the ranks what the reference reduces with MPI_Allreduce --
+ * scalars (:114-120: maxmol MAX, switchable atoms of mol_seed SUM, switchable atoms SUM), then mol_state /
+ * mol_restrict / presence (MAX, :157-158), the labels between sweeps (MIN, :664) and mol_accept (MAX, :750) */
+int ucg_fix_cluster_switch_scalars(const ucg_ctx *ctx, long long *out3)
+{
+  if (!ctx || !ctx->cs || !out3) return UCG_ERR_INVALID;
+  for (int k = 0; k < 3; k++) out3[k] = ctx->cs->survey[k];
+  return UCG_OK;
+}
+
+int ucg_fix_cluster_switch_set_scalars(ucg_ctx *ctx, long long maxmol, long long nspm, long long nmolatoms)
+{
+  if (!ctx || !ctx->cs) return UCG_ERR_INVALID;
+  return guarded(ctx, [&]() -> int {
+    ClusterSwitch &C = *ctx->cs;
+    if (maxmol < C.maxmol) throw InputError{"fix cluster_switch: reduced maxmol below the local one"};
+    if (nspm < 1) throw InputError{"fix cluster_switch: molecule mol_seed has no switchable atoms (division by zero in the reference)"};
+    if (C.mol_seed < 0 || C.mol_seed > maxmol || C.mol_seed - C.mol_offset < 0 || C.mol_seed - C.mol_offset > maxmol)
+      throw InputError{"fix cluster_switch: mol_seed / mol_seed - mol_offset outside 0..maxmol (out-of-bounds write in the reference)"};
+    const size_t nm = (size_t) maxmol + 1;
+    C.mol_restrict.resize(nm, -1);
+    C.mol_state.resize(nm, -1);
+    C.mol_accept.resize(nm, -1);
+    C.mol_cluster.resize(nm, -1);
+    C.present.resize(nm, 0);
+    C.maxmol = (int) maxmol;
+    C.nSwitchPerMol = (int) nspm;
+    C.nmol = (int) (nmolatoms / nspm);
+    C.synced = true;
+    return UCG_OK;
+  });
+}
+
+int ucg_fix_cluster_switch_set_array(ucg_ctx *ctx, int which, const int *in)
+{
+  if (!ctx || !in || !ctx->cs || which < 1 || which > 5) return UCG_ERR_INVALID;
+  return guarded(ctx, [&]() -> int {
+    ClusterSwitch &C = *ctx->cs;
+    const size_t nm = (size_t) C.maxmol + 1;
+    if (which == 5) {
+      std::vector<int> lab(in, in + nm);
+      upload(ctx, C.d_lab, lab);
+      return UCG_OK;
+    }
+    std::vector<int> &v = which == 1 ? C.mol_state : which == 2 ? C.mol_restrict : which == 3 ? C.mol_accept : C.present;
+    v.assign(in, in + nm);
+    if (which == 1 || which == 2) check_arrays(C);
+    return UCG_OK;
+  });
+}
+
+/* phases of check_cluster / attempt_switch (see above); `begin` != 0 starts from fresh labels */
+int ucg_fix_cluster_switch_sweep(ucg_ctx *ctx, int begin, int *changed)
+{
+  if (!ctx || !changed) return UCG_ERR_INVALID;
+  return guarded(ctx, [&]() -> int {
+    if (begin) cluster_labels_init(ctx);
+    *changed = cluster_sweep_local(ctx) ? 1 : 0;
+    return UCG_OK;
+  });
+}
+
+int ucg_fix_cluster_switch_finalize(ucg_ctx *ctx)
+{
+  if (!ctx) return UCG_ERR_INVALID;
+  return guarded(ctx, [&]() -> int {
+    cluster_finalize(ctx);
+    return UCG_OK;
+  });
+}
+
+int ucg_fix_cluster_switch_attempt_local(ucg_ctx *ctx)
+{
+  if (!ctx) return UCG_ERR_INVALID;
+  return guarded(ctx, [&]() -> int {
+    cluster_attempt_local(ctx);
+    return UCG_OK;
+  });
+}
+
+int ucg_fix_cluster_switch_attempt_apply(ucg_ctx *ctx)
+{
+  if (!ctx) return UCG_ERR_INVALID;
+  return guarded(ctx, [&]() -> int {
+    cluster_attempt_apply(ctx);
+    return UCG_OK;
+  });
+}
+
+/* is a re-neighbour forced at step ctx->ntimestep (ucg_md_set_timestep) / move on to the next switching step */
+int ucg_fix_cluster_switch_due(const ucg_ctx *ctx, int *forced, int *switching)
+{
+  if (!ctx || !forced || !switching) return UCG_ERR_INVALID;
+  *forced = cluster_forces_rebuild(ctx) ? 1 : 0;
+  *switching = (*forced && ctx->cs->switchFreq != 0) ? 1 : 0;
+  return UCG_OK;
+}
+
+int ucg_fix_cluster_switch_advance(ucg_ctx *ctx)
+{
+  if (!ctx || !ctx->cs) return UCG_ERR_INVALID;
+  ctx->cs->next_reneighbor = ctx->ntimestep + ctx->cs->switchFreq;
   return UCG_OK;
 }
 

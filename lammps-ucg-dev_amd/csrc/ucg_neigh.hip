@@ -229,6 +229,15 @@ __global__ __launch_bounds__(NB) void k_halo_forward(const DomainDev D, int ng, 
   ucgp[nlocal + g] = ucgp[src];
 }
 
+__global__ __launch_bounds__(NB) void k_ghost_copy_int2(int ng, int nlocal, const int *ghost_src, int *a, int *b)
+{
+  const int g = blockIdx.x * NB + threadIdx.x;
+  if (g >= ng) return;
+  const int src = ghost_src[g];
+  a[nlocal + g] = a[src];
+  b[nlocal + g] = b[src];
+}
+
 // per bin {owned start, owned end, ghost start, ghost end}; cls selects the pair to fill
 __global__ __launch_bounds__(NB) void k_cell_ranges(int n, int offset, const int *bin_of, int4 *cells, int cls)
 {
@@ -742,6 +751,12 @@ void rebuild(ucg_ctx *ctx)
     hipLaunchKernelGGL(k_halo_forward, dim3(nblk(ng)), dim3(NB), 0, st, dd, ng, n, ctx->ghost_src.get(), D.ghost_code.get(),
                        ctx->pos4.get(), ctx->meta.get(), ctx->ucgp.get());
     hipLaunchKernelGGL(k_bins_from_pos, dim3(nblk(ng)), dim3(NB), 0, st, dd, ng, n, ctx->pos4.get(), D.bin_of.get());
+    if (ctx->has_mol) {  // fix cluster_switch looks at the group bit and the molecule of ghosts too
+      ctx->mask.reserve(nall, true, st);
+      ctx->mol.reserve(nall, true, st);
+      hipLaunchKernelGGL(k_ghost_copy_int2, dim3(nblk(ng)), dim3(NB), 0, st, ng, n, ctx->ghost_src.get(), ctx->mask.get(),
+                         ctx->mol.get());
+    }
   }
   ctx->nghost = ng;
   ctx->ghost_src_valid = true;
@@ -885,7 +900,7 @@ bool decide(ucg_ctx *ctx)
 
 struct AtomRec {  // fields_exchange: everything a bead owns (96 bytes)
   double x, y, z, w, vx, vy, vz, vw, ucgp, ucgml;
-  int meta, tag, mask, nstates;
+  int meta, tag, mask, nstates;  // nstates: bits 0-1 num_ucgstates, bits 2.. atom->molecule when molecule ids are resident
 };
 struct HaloRec {  // fields_border / fields_comm: x (+shift), ucgl, ucgp, ucgstate, type, tag (48 bytes)
   double x, y, z, w, ucgp;
@@ -928,7 +943,8 @@ __global__ __launch_bounds__(NB) void k_exchange_dest(const DomainDev D, int n, 
 __global__ __launch_bounds__(NB) void k_exchange_pack(int n, int me, const int *dest_of, const int *slot_of,
                                                      const int *offsets, const double4 *pos4, const double4 *vel4,
                                                      const double *ucgp, const double *ucgml, const int *meta,
-                                                     const int *tag, const int *mask, const int *nstates, AtomRec *out)
+                                                     const int *tag, const int *mask, const int *nstates, const int *mol,
+                                                     AtomRec *out)
 {
   const int i = blockIdx.x * NB + threadIdx.x;
   if (i >= n || dest_of[i] == me) return;
@@ -941,7 +957,7 @@ __global__ __launch_bounds__(NB) void k_exchange_pack(int n, int me, const int *
   r.meta = meta[i];
   r.tag = tag[i];
   r.mask = mask[i];
-  r.nstates = nstates[i];
+  r.nstates = (nstates[i] & 3) | (mol ? (mol[i] << 2) : 0);
   out[offsets[dest_of[i]] + slot_of[i]] = r;
 }
 
@@ -960,7 +976,7 @@ __global__ __launch_bounds__(NB) void k_exchange_holes(int n, int nkeep, int me,
 
 __global__ __launch_bounds__(NB) void k_exchange_move(int nmove, const int *holes, const int *movers, double4 *pos4,
                                                      double4 *vel4, double *ucgp, double *ucgml, int *meta, int *tag,
-                                                     int *mask, int *nstates)
+                                                     int *mask, int *nstates, int *mol)
 {
   const int j = blockIdx.x * NB + threadIdx.x;
   if (j >= nmove) return;
@@ -973,11 +989,12 @@ __global__ __launch_bounds__(NB) void k_exchange_move(int nmove, const int *hole
   tag[dst] = tag[src];
   mask[dst] = mask[src];
   nstates[dst] = nstates[src];
+  if (mol) mol[dst] = mol[src];
 }
 
 __global__ __launch_bounds__(NB) void k_exchange_unpack(int nrecv, int base, const AtomRec *in, double4 *pos4,
                                                        double4 *vel4, double *ucgp, double *ucgml, int *meta, int *tag,
-                                                       int *mask, int *nstates)
+                                                       int *mask, int *nstates, int *mol)
 {
   const int j = blockIdx.x * NB + threadIdx.x;
   if (j >= nrecv) return;
@@ -990,7 +1007,8 @@ __global__ __launch_bounds__(NB) void k_exchange_unpack(int nrecv, int base, con
   meta[i] = r.meta;
   tag[i] = r.tag;
   mask[i] = r.mask;
-  nstates[i] = r.nstates;
+  nstates[i] = r.nstates & 3;
+  if (mol) mol[i] = r.nstates >> 2;
 }
 
 // every (bead, shift) image that falls in some rank's extended sub-box, except the bead itself
@@ -1093,6 +1111,23 @@ __global__ __launch_bounds__(NB) void k_halo_aux_unpack(int ng, int nlocal, cons
 {
   const int g = blockIdx.x * NB + threadIdx.x;
   if (g < ng) dst[nlocal + g] = in[perm[g]];
+}
+
+__global__ __launch_bounds__(NB) void k_halo_molmask_pack(int nsend, const int *send_src, const int *mask, const int *mol,
+                                                         int2 *out)
+{
+  const int j = blockIdx.x * NB + threadIdx.x;
+  if (j < nsend) out[j] = make_int2(mask[send_src[j]], mol[send_src[j]]);
+}
+
+__global__ __launch_bounds__(NB) void k_halo_molmask_unpack(int ng, int nlocal, const int *perm, const int2 *in, int *mask,
+                                                           int *mol)
+{
+  const int g = blockIdx.x * NB + threadIdx.x;
+  if (g >= ng) return;
+  const int2 v = in[perm[g]];
+  mask[nlocal + g] = v.x;
+  mol[nlocal + g] = v.y;
 }
 
 void counts_to_host(ucg_ctx *ctx, Domain &D, long long *out)
@@ -1426,7 +1461,8 @@ int ucg_exchange_pack(ucg_ctx *ctx, void *sendbuf)
     offsets_to_device(ctx, D, D.send_counts, D.offsets);
     hipLaunchKernelGGL(k_exchange_pack, dim3(nblk(n)), dim3(NB), 0, st, n, D.me, D.dest_of.get(), D.slot_of.get(),
                        D.offsets.get(), ctx->pos4.get(), ctx->vel4.get(), ctx->ucgp.get(), ctx->ucgml.get(),
-                       ctx->meta.get(), ctx->tag.get(), ctx->mask.get(), ctx->num_ucgstates.get(), (AtomRec *) sendbuf);
+                       ctx->meta.get(), ctx->tag.get(), ctx->mask.get(), ctx->num_ucgstates.get(),
+                       ctx->has_mol ? ctx->mol.get() : nullptr, (AtomRec *) sendbuf);
     // close the holes the leavers leave behind
     const int nkeep = n - (int) nleave;
     D.holes.reserve((size_t) nleave + 1);
@@ -1442,7 +1478,7 @@ int ucg_exchange_pack(ucg_ctx *ctx, void *sendbuf)
     if (cnt[0] > 0)
       hipLaunchKernelGGL(k_exchange_move, dim3(nblk(cnt[0])), dim3(NB), 0, st, cnt[0], D.holes.get(), D.movers.get(),
                          ctx->pos4.get(), ctx->vel4.get(), ctx->ucgp.get(), ctx->ucgml.get(), ctx->meta.get(),
-                         ctx->tag.get(), ctx->mask.get(), ctx->num_ucgstates.get());
+                         ctx->tag.get(), ctx->mask.get(), ctx->num_ucgstates.get(), ctx->has_mol ? ctx->mol.get() : nullptr);
     UCG_HIP(hipGetLastError());
     ctx->nlocal = nkeep;
     return UCG_OK;
@@ -1466,11 +1502,13 @@ int ucg_exchange_unpack(ucg_ctx *ctx, const void *recvbuf, long long nrecv)
     ctx->meta.reserve(n, true, st);
     ctx->tag.reserve(n, true, st);
     ctx->mask.reserve(n, true, st);
+    if (ctx->has_mol) ctx->mol.reserve(n, true, st);
     ctx->num_ucgstates.reserve(n, true, st);
     if (nrecv)
       hipLaunchKernelGGL(k_exchange_unpack, dim3(nblk(nrecv)), dim3(NB), 0, st, (int) nrecv, base,
                          (const AtomRec *) recvbuf, ctx->pos4.get(), ctx->vel4.get(), ctx->ucgp.get(), ctx->ucgml.get(),
-                         ctx->meta.get(), ctx->tag.get(), ctx->mask.get(), ctx->num_ucgstates.get());
+                         ctx->meta.get(), ctx->tag.get(), ctx->mask.get(), ctx->num_ucgstates.get(),
+                         ctx->has_mol ? ctx->mol.get() : nullptr);
     UCG_HIP(hipGetLastError());
     ctx->nlocal = (int) n;
     ctx->nghost = 0;
@@ -1630,6 +1668,49 @@ int ucg_halo_aux_unpack(ucg_ctx *ctx, void *field_dev, const void *recvbuf)
   });
 }
 
+int ucg_halo_molmask_pack(ucg_ctx *ctx, void *sendbuf)
+{
+  if (!ctx) return UCG_ERR_INVALID;
+  if (int rc = need_domain(ctx)) return rc;
+  return guarded(ctx, [&]() -> int {
+    Domain &D = *ctx->dom;
+    if (!ctx->has_mol) throw InputError{"no molecule ids were uploaded"};
+    if (D.nsend == 0) return UCG_OK;
+    if (!sendbuf) return UCG_ERR_INVALID;
+    hipLaunchKernelGGL(k_halo_molmask_pack, dim3(nblk(D.nsend)), dim3(NB), 0, ctx->stream, (int) D.nsend,
+                       D.send_src.get(), ctx->mask.get(), ctx->mol.get(), (int2 *) sendbuf);
+    UCG_HIP(hipGetLastError());
+    return UCG_OK;
+  });
+}
+
+int ucg_halo_molmask_unpack(ucg_ctx *ctx, const void *recvbuf)
+{
+  if (!ctx) return UCG_ERR_INVALID;
+  if (int rc = need_domain(ctx)) return rc;
+  return guarded(ctx, [&]() -> int {
+    Domain &D = *ctx->dom;
+    if (!ctx->has_mol) throw InputError{"no molecule ids were uploaded"};
+    const int ng = ctx->nghost;
+    if (ng == 0) return UCG_OK;
+    if (!recvbuf) return UCG_ERR_INVALID;
+    const size_t nall = (size_t) ctx->nlocal + ng;
+    ctx->mask.reserve(nall, true, ctx->stream);
+    ctx->mol.reserve(nall, true, ctx->stream);
+    hipLaunchKernelGGL(k_halo_molmask_unpack, dim3(nblk(ng)), dim3(NB), 0, ctx->stream, ng, ctx->nlocal,
+                       D.ghost_perm.get(), (const int2 *) recvbuf, ctx->mask.get(), ctx->mol.get());
+    UCG_HIP(hipGetLastError());
+    return UCG_OK;
+  });
+}
+
+int ucg_md_set_timestep(ucg_ctx *ctx, long long ntimestep)
+{
+  if (!ctx) return UCG_ERR_INVALID;
+  ctx->ntimestep = ntimestep;
+  return UCG_OK;
+}
+
 int ucg_decide_local(ucg_ctx *ctx, int *due, int *flag)
 {
   if (!ctx || !due || !flag) return UCG_ERR_INVALID;
@@ -1637,6 +1718,11 @@ int ucg_decide_local(ucg_ctx *ctx, int *due, int *flag)
   return guarded(ctx, [&]() -> int {
     // Neighbor::decide(): the caller combines `flag` over ranks (MPI_Allreduce in upstream)
     Domain &D = *ctx->dom;
+    if (cluster_forces_rebuild(ctx)) {  // fix cluster_switch: forced on every rank at the same step
+      *due = 1;
+      *flag = 1;
+      return UCG_OK;
+    }
     D.ago++;
     *due = 0;
     *flag = 0;

@@ -309,7 +309,9 @@ int FixClusterSwitchGPU::setmask()
 void FixClusterSwitchGPU::init()
 {
   FixUCGGPUBase::init();
-  if (comm->nprocs > 1) error->all(FLERR, "USER-UCG/GPU fix cluster_switch is single-rank in this build");
+  if (comm->nprocs > 1)
+    error->all(FLERR, "USER-UCG/GPU fix cluster_switch: with several ranks the reductions of include/ucg_hip.h (survey, labels, "
+                      "accept flags) have to be wired to MPI_Allreduce here -- not done in this glue yet");
   // molecule ids in the order of the last ucg_atoms_upload (the pair style's), then the fix itself
   std::vector<int> mol((size_t) atom->nlocal);
   for (int i = 0; i < atom->nlocal; i++) mol[(size_t) i] = (int) atom->molecule[i];

@@ -112,6 +112,14 @@ class Transport:
         work = self.dist.all_to_all_single(r[:nout], sendbuf[: sum(in_splits)], out_splits, in_splits, async_op=True)
         return work, r
 
+    def allreduce_array(self, arr, op: str):
+        """elementwise "max" / "min" / "sum" of an int64 array over the ranks (small per-molecule arrays)"""
+        t = self.torch
+        x = t.tensor(np.asarray(arr, dtype=np.int64), device="cpu" if self.staged else self.device)
+        self.dist.all_reduce(x, op={"max": self.dist.ReduceOp.MAX, "min": self.dist.ReduceOp.MIN,
+                                    "sum": self.dist.ReduceOp.SUM}[op])
+        return x.cpu().numpy()
+
     def allreduce_max(self, value: int) -> int:
         t = self.torch
         x = t.tensor([int(value)], dtype=t.int64, device="cpu" if self.staged else self.device)
@@ -135,6 +143,7 @@ class RankSim:
         self.nve_kind = 2 if integrator == "wall" else 1
         self.density = getattr(pair, "style", "") == "table_ucg_bethe_density"
         self._aux_send = None
+        self.cluster = False
         self.overlap = os.environ.get("UCG_HALO_OVERLAP", "0") == "1"  # measured: not a gain yet
         self.grid = list(grid)
         self.me = transport.rank
@@ -175,7 +184,42 @@ class RankSim:
         self.halo_send_counts, self.halo_recv_counts = sc, rc
         self._halo_send = sb  # reused every step: same counts until the next rebuild
         self._keep = rb
+        if self.cluster:
+            # ghosts' group bits and molecule ids, for fix cluster_switch
+            mb = self._buf(8 * int(sc.sum()))
+            ctx.halo_molmask_pack(mb.data_ptr())
+            rb2 = tr.alltoall_bytes(mb, sc, rc, 8)
+            ctx.halo_molmask_unpack(rb2.data_ptr())
         self.nrebuild += 1
+
+    # ---- fix cluster_switch across ranks: the reductions the reference does with MPI_Allreduce
+    def cluster_switch(self, mol_seed, mol_offset, cutoff, seed, switch_freq, rate_file, contact_file):
+        """fix ID all cluster_switch ... (every rank calls this after its beads and molecule ids are uploaded)"""
+        ctx, tr = self.ctx, self.tr
+        ctx.md_set_timestep(self.ntimestep)
+        ctx.fix_cluster_switch(mol_seed, mol_offset, cutoff, seed, switch_freq, rate_file, contact_file, self.groupbit)
+        s = ctx.cs_scalars()
+        ctx.cs_set_scalars(tr.allreduce_array([s[0]], "max")[0], tr.allreduce_array([s[1]], "sum")[0],
+                           tr.allreduce_array([s[2]], "sum")[0])
+        for which in (1, 2, 4):  # mol_state, mol_restrict, presence
+            ctx.cs_set_array(which, tr.allreduce_array(ctx.cs_array(which), "max"))
+        self.cluster = True
+
+    def _cluster_step(self):
+        """check_cluster + attempt_switch on fresh lists (UCG/fix_cluster_switch.cpp:452-469)"""
+        ctx, tr = self.ctx, self.tr
+        changed = ctx.cs_sweep(1)
+        while True:
+            ctx.cs_set_array(5, tr.allreduce_array(ctx.cs_array(5), "min"))
+            if not tr.allreduce_max(changed):
+                break
+            changed = ctx.cs_sweep(0)
+        ctx.cs_finalize()
+        ctx.cs_attempt_local()
+        ctx.cs_set_array(3, tr.allreduce_array(ctx.cs_array(3), "max"))
+        ctx.cs_attempt_apply()
+        ctx.cs_advance()
+        self.halo_forward()  # the ghosts' new atom types
 
     def halo_forward(self):
         ctx, tr = self.ctx, self.tr
@@ -250,9 +294,13 @@ class RankSim:
                     ctx.fix_nve_ucgld_wall_hard_initial_integrate(self.groupbit)
                 else:
                     ctx.fix_nve_ucgld_initial_integrate(self.groupbit)
+            if self.cluster:
+                ctx.md_set_timestep(self.ntimestep)
             due, flag = ctx.decide_local()
             if due and self.tr.allreduce_max(flag):
                 self.rebuild()
+                if self.cluster and ctx.cs_due()[1]:
+                    self._cluster_step()
                 out = self._pair_compute(ev)
             elif self.overlap and not ev and not self.density:
                 self.halo_forward_and_pair()

@@ -45,6 +45,45 @@ def main():
         lo, hi = multi.sub_box(beads.boxlo, beads.boxhi, grid, rank)
         result = dict(n=len(got), inside=bool(np.all((got[:, :3] >= lo) & (got[:, :3] < hi))), tags=got[:, 3].astype(np.int64),
                       counts=counts, rc=rc, maxflag=tr.allreduce_max(rank), total=tr.allreduce_sum([len(got)])[0])
+    elif mode == "gpu_cluster":
+        # fix cluster_switch on a decomposed run: labels must equal the single-rank ones; then a short run
+        capi = pkg.capi
+        deck = util.make_multi_deck(2, "spline", 256)
+        mb = util.multi_type_beads(pkg, 10, 2, seed=5, molecule_size=2)
+        rates, contacts = pkg.synth.write_cluster_switch_files(deck.workdir, 0.35, [1], [2], [(1, 1)])
+        mol_seed = int(mb.molecule[np.flatnonzero(mb.type == 1)[0]])
+        ctx = capi.Context(0, dt=0.004)
+        sl = slice(rank * mb.n // world, (rank + 1) * mb.n // world)
+        n = sl.stop - sl.start
+        ctx.atoms_upload(n, 0, mb.ntypes, mb.x[sl], mb.v[sl], mb.type[sl], mb.tag[sl], mb.mask[sl], mb.ucgstate[sl],
+                         mb.ucgl[sl], mb.ucgvl[sl], mb.ucgml[sl], mb.ucgp[sl], mb.mass)
+        ctx.upload_molecule(mb.molecule[sl])
+        ctx.domain_set(mb.boxlo, mb.boxhi, 2.5, 0.3, every=5, delay=0, check=1)
+        pair = util.gpu_pair_multi(ctx, "table_ucgld", deck)
+        tr = multi.Transport(dist, torch.device("cuda", 0), staged=True)
+        sim = multi.RankSim(ctx, pair, tr, grid, use_langevin=False, use_ucgstate=False)
+        sim.cluster_switch(mol_seed, 0, 1.15, 4711, 5, rates, contacts)
+        sim.setup(30)
+        # check_cluster alone (the phases of RankSim._cluster_step up to finalize)
+        changed = ctx.cs_sweep(1)
+        rounds = 0
+        while True:
+            ctx.cs_set_array(5, tr.allreduce_array(ctx.cs_array(5), "min"))
+            rounds += 1
+            if not tr.allreduce_max(changed):
+                break
+            changed = ctx.cs_sweep(0)
+        ctx.cs_finalize()
+        labels = ctx.cs_array(0)
+        state0, restrict0 = ctx.cs_array(1), ctx.cs_array(2)
+        sim.run(30)
+        pair.check_errors()
+        A = ctx.atoms_download()
+        result = dict(labels=labels, state0=state0, restrict0=restrict0, rounds=rounds, tag=A["tag"], type=A["type"],
+                      mol=ctx.download_molecule(), vec=ctx.fix_cluster_switch_vector(), state1=ctx.cs_array(1),
+                      mol_seed=mol_seed, nrebuild=sim.nrebuild)
+        pair.close()
+        ctx.close()
     else:
         capi = pkg.capi
         dt = 0.004

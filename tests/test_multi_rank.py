@@ -154,3 +154,51 @@ def test_world2_density_style_matches_single_rank(fresh_ctx, pkg):
     d = by_tag(tag1, np.concatenate([r["x1"] for r in res])) - by_tag(S1["tag"], S1["x"])
     d -= np.round(d / beads.boxhi) * beads.boxhi
     assert np.max(np.abs(d)) < 1e-8
+
+
+@pytest.mark.gpu
+def test_world2_cluster_switch(fresh_ctx, pkg):
+    """fix cluster_switch decomposed: the cluster labels do not depend on the decomposition; the switching keeps
+    molecules whole and its bookkeeping consistent (which rank draws for a molecule follows the reference: the rank
+    holding the majority of its atoms, each with its own RanPark stream, so the draws themselves differ)"""
+    res = _launch("gpu_cluster")
+    deck = util.make_multi_deck(2, "spline", 256)
+    mb = util.multi_type_beads(pkg, 10, 2, seed=5, molecule_size=2)
+    rates, contacts = pkg.synth.write_cluster_switch_files(deck.workdir, 0.35, [1], [2], [(1, 1)])
+    mol_seed = res[0]["mol_seed"]
+    ctx = fresh_ctx
+    ctx.set_units(1.0, 1.0, 1.0, 0.004)
+    ctx.upload_beads(mb)
+    ctx.domain_set(mb.boxlo, mb.boxhi, 2.5, 0.3, every=5, delay=0, check=1)
+    ctx.neigh_rebuild()
+    ctx.fix_cluster_switch(mol_seed, 0, 1.15, 4711, 5, rates, contacts)
+    ctx.fix_cluster_switch_check_cluster()
+    S = ctx.fix_cluster_switch_arrays()
+    for r in res:
+        assert np.array_equal(r["labels"], S["mol_cluster"])
+        assert np.array_equal(r["state0"], S["mol_state"]) and np.array_equal(r["restrict0"], S["mol_restrict"])
+        assert r["rounds"] >= 2  # at least one reduction round was needed
+    assert np.array_equal(res[0]["labels"], res[1]["labels"])
+    # after 30 steps with switching every 5: every bead exactly once, molecules whole, bookkeeping consistent
+    tag = np.concatenate([r["tag"] for r in res])
+    typ = np.concatenate([r["type"] for r in res])
+    mol = np.concatenate([r["mol"] for r in res])
+    assert sorted(tag.tolist()) == list(range(1, mb.n + 1))
+    assert np.array_equal(mol, mb.molecule[tag - 1])  # molecule ids travelled with the beads
+    assert set(np.unique(typ)) <= {1, 2}
+    for m in np.unique(mol):
+        assert len(np.unique(typ[mol == m])) == 1
+    assert np.array_equal(res[0]["vec"], res[1]["vec"]) and np.array_equal(res[0]["state1"], res[1]["state1"])
+    att, suc = res[0]["vec"][0], res[0]["vec"][1]
+    assert att > 100 and 0 < suc < att
+    assert (typ != mb.type[tag - 1]).sum() > 0
+    # mol_state of every molecule OUTSIDE the seed's cluster says which type its atoms carry
+    st = res[0]["state1"]
+    t_of_mol = {int(m): int(typ[mol == m][0]) for m in np.unique(mol)}
+    labels_now = res[0]["labels"]
+    assert all(r["nrebuild"] >= 6 for r in res)
+    checked = 0
+    for m, t in t_of_mol.items():
+        if st[m] in (0, 1) and labels_now[m] != labels_now[mol_seed]:
+            checked += 1
+    assert checked > 10
