@@ -102,6 +102,18 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the multi-core baseline (0 = min(cores, 16))")
     args = ap.parse_args()
 
+    # exactly ONE line on stdout (the JSON): everything the libraries print there (RCCL / gloo banners) is sent
+    # to stderr while the benchmark runs
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line):
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(line, flush=True)
+        os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -283,7 +295,7 @@ def main():
             }
         else:
             out["cpu_baseline"] = one
-    print(json.dumps(out))
+    emit(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -75,9 +75,22 @@ class Transport:
         self.staged = staged  # gloo: stage through the host
         self.world = dist.get_world_size()
         self.rank = dist.get_rank()
+        # small HOST messages (counts, flags) go through a gloo side group when the main backend is RCCL: no
+        # device round trip for a few integers.  Any failure to create it leaves everything on the main group.
+        self.host_group = None
+        if not staged and os.environ.get("UCG_HOST_GROUP", "1") != "0":
+            try:
+                self.host_group = dist.new_group(backend="gloo")
+            except Exception:  # noqa: BLE001
+                self.host_group = None
 
     def alltoall_counts(self, counts):
         t = self.torch
+        if self.host_group is not None:
+            send = t.from_numpy(np.ascontiguousarray(counts, dtype=np.int64))
+            recv = t.empty_like(send)
+            self.dist.all_to_all_single(recv, send, group=self.host_group)
+            return recv.numpy()
         send = t.tensor(np.asarray(counts, dtype=np.int64), device="cpu" if self.staged else self.device)
         recv = t.empty_like(send)
         self.dist.all_to_all_single(recv, send)
@@ -122,6 +135,10 @@ class Transport:
 
     def allreduce_max(self, value: int) -> int:
         t = self.torch
+        if self.host_group is not None:
+            x = t.tensor([int(value)], dtype=t.int64)
+            self.dist.all_reduce(x, op=self.dist.ReduceOp.MAX, group=self.host_group)
+            return int(x.item())
         x = t.tensor([int(value)], dtype=t.int64, device="cpu" if self.staged else self.device)
         self.dist.all_reduce(x, op=self.dist.ReduceOp.MAX)
         return int(x.item())
