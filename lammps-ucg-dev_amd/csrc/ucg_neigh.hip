@@ -408,12 +408,12 @@ struct __attribute__((aligned(16))) TileCand {
 __device__ __forceinline__ void tile_walk(const DomainDev &D, const double3 &binsize, const int k, const double4 &pk,
                                           const int tk, const int bx, const int by, const int bz, const int r0x,
                                           const int r0y, const int r0z, const int *s_start, const TileCand *s_cand,
-                                          int &c0, int &c1, int &c2, int &c3, int *neigh, int *skin, const int pitch,
-                                          const int cap, const int capskin)
+                                          int &c0, int &ns, int *neigh, int *skin, const int pitch, const int cap,
+                                          const int capskin)
 {
   const double prune = D.cutneighsq * (1.0 + 1.0e-9) + 1.0e-12;
-  c0 = c1 = c2 = c3 = 0;
-  int ns = 0;
+  c0 = 0;
+  ns = 0;
   const int xlo_bin = max(bx - D.sten[0], 0), xhi_bin = min(bx + D.sten[0], D.nbin[0] - 1);
   for (int dz = -D.sten[2]; dz <= D.sten[2]; dz++) {
     const int cz = bz + dz;
@@ -453,7 +453,8 @@ __device__ __forceinline__ void tile_walk(const DomainDev &D, const double3 &bin
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-          // branch-free bookkeeping (plain integer adds and selects: keeps the counters in registers)
+          // branch-free bookkeeping (plain integer adds and selects: keeps the counters in registers); the
+          // skin classes are only tagged here and counted when the side buffer is read back
           const bool ok = (j + u < j1) && (pm[u].idx != k) && (rsq[u] < D.cutneighsq);
           const int in0 = rsq[u] < D.cls_sq[0], in1 = rsq[u] < D.cls_sq[1], in2 = rsq[u] < D.cls_sq[2];
           const int cls = 3 - in0 - in1 - in2;
@@ -461,10 +462,7 @@ __device__ __forceinline__ void tile_walk(const DomainDev &D, const double3 &bin
           const int ent = pm[u].idx | (orient << UCG_ORIENT_BIT);
           if (ok && in0 && c0 < cap) neigh[(size_t) c0 * pitch + k] = ent;
           if (ok && !in0 && ns < capskin) skin[(size_t) ns * pitch + k] = ent | (cls << 30);
-          c0 += ok ? in0 : 0;
-          c1 += ok ? (in1 - in0) : 0;
-          c2 += ok ? (in2 - in1) : 0;
-          c3 += ok ? (1 - in2) : 0;
+          c0 += (ok && in0) ? 1 : 0;
           ns += (ok && !in0) ? 1 : 0;
         }
       }
@@ -563,12 +561,18 @@ __global__ __launch_bounds__(TILE_B) void k_rows_tile(const DomainDev D, const d
     const int tk = tag[k];
     const int b = bin_of[k];
     const int bx = b % D.nbin[0], by = (b / D.nbin[0]) % D.nbin[1], bz = b / (D.nbin[0] * D.nbin[1]);
-    int c0, c1, c2, c3;
-    tile_walk(D, binsize, k, pk, tk, bx, by, bz, r0x, r0y, r0z, s_start, s_cand, c0, c1, c2, c3, neigh, skin, pitch, cap,
-              capskin);
-    const int ns = c1 + c2 + c3, cnt = c0 + ns;
+    int c0, ns;
+    tile_walk(D, binsize, k, pk, tk, bx, by, bz, r0x, r0y, r0z, s_start, s_cand, c0, ns, neigh, skin, pitch, cap, capskin);
+    const int cnt = c0 + ns;
     if (cnt <= cap && ns <= capskin) {
-      // append the skin classes behind class 0, each in discovery order (the lane reads back its own writes)
+      // append the skin classes behind class 0, each in discovery order (the lane reads back its own writes):
+      // count the classes, then place the entries
+      int c1 = 0, c2 = 0;
+      for (int e = 0; e < ns; e++) {
+        const int cls = (skin[(size_t) e * pitch + k] >> 30) & 3;
+        c1 += cls == 1;
+        c2 += cls == 2;
+      }
       int p1 = c0, p2 = c0 + c1, p3 = c0 + c1 + c2;
       for (int e = 0; e < ns; e++) {
         const int ent = skin[(size_t) e * pitch + k];
