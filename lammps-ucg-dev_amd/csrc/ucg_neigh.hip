@@ -460,8 +460,10 @@ __device__ __forceinline__ void tile_walk(const DomainDev &D, const double3 &bin
           const int cls = 3 - in0 - in1 - in2;
           const int orient = (tk <= pm[u].tag) ? 1 : 0;
           const int ent = pm[u].idx | (orient << UCG_ORIENT_BIT);
-          if (ok && in0 && c0 < cap) neigh[(size_t) c0 * pitch + k] = ent;
-          if (ok && !in0 && ns < capskin) skin[(size_t) ns * pitch + k] = ent | (cls << 30);
+          // one store: class 0 to the row, the skin classes (tagged) to the side buffer
+          int *dst = in0 ? neigh + ((size_t) c0 * pitch + k) : skin + ((size_t) ns * pitch + k);
+          const bool room = in0 ? (c0 < cap) : (ns < capskin);
+          if (ok && room) *dst = in0 ? ent : (ent | (cls << 30));
           c0 += (ok && in0) ? 1 : 0;
           ns += (ok && !in0) ? 1 : 0;
         }
