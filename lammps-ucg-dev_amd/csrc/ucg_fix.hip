@@ -195,7 +195,8 @@ __global__ __launch_bounds__(FIX_BLOCK) void k_post_fused(const AtomsDev A, cons
     f.w += fdrag + fran;
     f_dirty = true;
   }
-  if (f_dirty) A.frc4[i] = f;
+  // with the next initial_integrate fused in, nothing reads ucgforce before the next pair kernel overwrites it
+  if (f_dirty && !(NVE && NEXT)) A.frc4[i] = f;
   if (UCGST) {
     double ucgp;
     if (A.num_ucgstates[i] == 1) {
