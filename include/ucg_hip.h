@@ -319,6 +319,10 @@ int ucg_md_attach(ucg_ctx *ctx, ucg_pair *pair, int use_nve, int use_langevin, i
 /* the per-bead hooks that follow the pair kernel as ONE launch, in the reference's order:
  * ucgld/langevin post_force -> ucgstate post_force -> nve/ucgld final_integrate [-> the next
  * step's initial_integrate].  Bit-identical to calling the hooks one by one. */
+/* ucg_pair_compute + ucg_md_post_fused(.., fuse_next_initial = 1) as ONE launch (the gather kernel's epilogue);
+ * UCG_ERR_UNSUPPORTED = not applicable here (table_ucg_bethe_density, no integrator, option off): use the two calls */
+int ucg_md_pair_post(ucg_ctx *ctx, ucg_pair *pair, int use_langevin, int use_ucgstate, int use_nve, int groupbit,
+                     long long ntimestep, long long beginstep, long long endstep);
 int ucg_md_post_fused(ucg_ctx *ctx, int use_langevin, int use_ucgstate, int use_nve, int fuse_next_initial,
                       int groupbit, long long ntimestep, long long beginstep, long long endstep);
 int ucg_md_setup(ucg_ctx *ctx, long long nsteps_planned);

@@ -56,7 +56,7 @@ SYMBOLS = [
     "ucg_decomp_set", "ucg_record_bytes", "ucg_exchange_count", "ucg_exchange_pack", "ucg_exchange_unpack",
     "ucg_border_count", "ucg_border_pack", "ucg_border_unpack", "ucg_halo_pack", "ucg_halo_unpack", "ucg_decide_local",
     "ucg_ranmars_fill",
-    "ucg_md_attach", "ucg_md_post_fused", "ucg_md_setup", "ucg_md_run", "ucg_md_info", "ucg_md_thermo",
+    "ucg_md_attach", "ucg_md_post_fused", "ucg_md_pair_post", "ucg_md_setup", "ucg_md_run", "ucg_md_info", "ucg_md_thermo",
     "ucg_profile_enable", "ucg_profile_read",
 ]
 
@@ -182,6 +182,7 @@ def lib():
     L.ucg_decide_local.argtypes = [vp, c_int_p, c_int_p]
     L.ucg_ranmars_fill.argtypes = [vp, C.c_int, C.c_longlong, C.c_int, c_double_p]
     L.ucg_md_attach.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int]
+    L.ucg_md_pair_post.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_longlong, C.c_longlong]
     L.ucg_md_post_fused.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_longlong, C.c_longlong]
     L.ucg_md_setup.argtypes = [vp, C.c_longlong]
     L.ucg_md_run.argtypes = [vp, C.c_longlong, C.c_int]
@@ -554,6 +555,16 @@ class Context:
         """nve: False | True (fix nve/ucgld) | "wall" (fix nve/ucgld/wall/hard, see fix_nve_ucgld_wall_hard)"""
         kind = 2 if nve == "wall" else int(bool(nve))
         self.chk(self.L.ucg_md_attach(self.h, pair.h, kind, int(langevin), int(ucgstate)))
+
+    def md_pair_post(self, pair, langevin, ucgstate, nve, ntimestep, beginstep, endstep, groupbit=1):
+        """pair force + the fused per-bead hooks (next initial_integrate included) in one launch; False where the
+        two-call form has to be used (UCG_ERR_UNSUPPORTED)"""
+        rc = self.L.ucg_md_pair_post(self.h, pair.h, int(langevin), int(ucgstate), int(nve), groupbit, int(ntimestep),
+                                     int(beginstep), int(endstep))
+        if rc == 6:  # UCG_ERR_UNSUPPORTED
+            return False
+        self.chk(rc)
+        return True
 
     def md_post_fused(self, langevin, ucgstate, nve, fuse_next, ntimestep, beginstep, endstep, groupbit=1):
         self.chk(self.L.ucg_md_post_fused(self.h, int(langevin), int(ucgstate), int(nve), int(fuse_next), groupbit,

@@ -99,6 +99,7 @@ ListDev ucg_ctx::list_dev() const
   L.numneigh = numneigh.get();
   L.blockflag = nullptr;
   L.blockwant = 0;
+  L.post = PostDev{};
   return L;
 }
 
@@ -486,7 +487,8 @@ int ucg_pair_tabindex(const ucg_pair *p, int *out, int cap)
   return n;
 }
 
-static int pair_compute_impl(ucg_pair *p, int eflag, int vflag, double *eng_vdwl, double *virial, int part);
+static int pair_compute_impl(ucg_pair *p, int eflag, int vflag, double *eng_vdwl, double *virial, int part,
+                             const PostDev *post = nullptr);
 
 int ucg_pair_compute(ucg_pair *p, int eflag, int vflag, double *eng_vdwl, double *virial)
 {
@@ -501,7 +503,8 @@ int ucg_pair_compute_part(ucg_pair *p, int part)
 
 // part 0: all beads; 1: only the workgroups none of whose beads has a ghost neighbour (they need no
 // halo); 2: the others.  1 then 2 write exactly what 0 writes.
-static int pair_compute_impl(ucg_pair *p, int eflag, int vflag, double *eng_vdwl, double *virial, int part)
+static int pair_compute_impl(ucg_pair *p, int eflag, int vflag, double *eng_vdwl, double *virial, int part,
+                             const PostDev *post)
 {
   if (!p || !p->ctx) return UCG_ERR_INVALID;
   ucg_ctx *ctx = p->ctx;
@@ -562,6 +565,7 @@ static int pair_compute_impl(ucg_pair *p, int eflag, int vflag, double *eng_vdwl
         L.blockflag = p->d_blockflag.get();
         L.blockwant = part == 1 ? 0 : 1;
       }
+      if (post) L.post = *post;
       if (ctx->fma_contract)
         UCG_HIP(launch_pair_gather_fused(p->dev, ctx->atoms_dev(), L, ev, p->d_evpart.get(), p->d_evout.get(),
                                          p->d_err.get(), ctx->stream));
@@ -1166,6 +1170,69 @@ int ucg_md_post_fused(ucg_ctx *ctx, int use_langevin, int use_ucgstate, int use_
   });
 }
 
+/* pair force + the per-bead hooks of a step whose next initial_integrate is fused in, as ONE launch of the
+ * gather kernel (its epilogue, PostDev): same statements, same order, same bits as ucg_pair_compute followed by
+ * ucg_md_post_fused(..., fuse_next_initial = 1).  Returns UCG_ERR_UNSUPPORTED (nothing done) where the two-launch
+ * form has to be used: table_ucg_bethe_density, or the option "post_in_pair" switched off. */
+int ucg_md_pair_post(ucg_ctx *ctx, ucg_pair *p, int use_langevin, int use_ucgstate, int use_nve, int groupbit,
+                     long long ntimestep, long long beginstep, long long endstep)
+{
+  if (!ctx || !p || p->ctx != ctx) return UCG_ERR_INVALID;
+  if (!ctx->post_in_pair || p->model.style == STYLE_BETHE_DENSITY || !use_nve) return UCG_ERR_UNSUPPORTED;
+  PostDev Q{};
+  int rc = guarded(ctx, [&]() -> int {
+    Q.enabled = 1;
+    Q.lang = use_langevin != 0;
+    Q.ucgst = use_ucgstate != 0;
+    Q.nve = use_nve >= 2 ? (ctx->wall_bias ? 3 : 2) : 1;
+    Q.groupbit = groupbit;
+    Q.dtv = ctx->dt;
+    Q.dtf = 0.5 * ctx->dt * ctx->ftm2v;
+    Q.barrier = ctx->wall_barrier;
+    if (use_langevin) {
+      FixLangevin &L = ctx->lang;
+      if (!L.active || !L.inited) return fail(ctx, UCG_ERR_INVALID, "fix ucgld/langevin not initialised");
+      double delta = (double) (ntimestep - beginstep);
+      if (delta != 0.0) delta /= (double) (endstep - beginstep);
+      L.t_target = L.t_start + delta * (L.t_stop - L.t_start);
+      L.tsqrt = std::sqrt(L.t_target);
+      rng_draw(ctx, L.rng, L.draws, ctx->nlocal);  // the draws do not depend on the forces: generated first
+      Q.gfactor1 = L.gf1.get();
+      Q.gfactor2 = L.gf2.get();
+      Q.tsqrt = L.tsqrt;
+      Q.lang_draws = L.draws.get();
+    }
+    FixUcgState &S = ctx->ucgst;
+    if (use_ucgstate) {
+      if (!S.active) return fail(ctx, UCG_ERR_INVALID, "fix ucgstate not created");
+      Q.ld_flag = S.ld_flag;
+      Q.mc_flag = S.mc_flag;
+      Q.mc_rate = S.mc_rate;
+      if (S.mc_flag && !S.ld_flag) {
+        rng_draw(ctx, S.rng, S.draws, ctx->nlocal);
+        Q.mc_draws = S.draws.get();
+      }
+    }
+    ctx->pos4_alt.reserve_exact(ctx->pos4.capacity());
+    ctx->meta_alt.reserve_exact(ctx->meta.capacity());
+    Q.pos_out = ctx->pos4_alt.get();
+    Q.meta_out = ctx->meta_alt.get();
+    if (Q.ucgst) {
+      ctx->ucgp_alt.reserve_exact(ctx->ucgp.capacity());
+      Q.ucgp_out = ctx->ucgp_alt.get();
+    }
+    return UCG_OK;
+  });
+  if (rc) return rc;
+  rc = pair_compute_impl(p, 0, 0, nullptr, nullptr, 0, &Q);
+  if (rc) return rc;
+  // the next step's positions / states become the current ones (ghost entries are refreshed by the halo)
+  ctx->pos4.swap(ctx->pos4_alt);
+  ctx->meta.swap(ctx->meta_alt);
+  if (Q.ucgst) ctx->ucgp.swap(ctx->ucgp_alt);
+  return UCG_OK;
+}
+
 int ucg_ranmars_fill(ucg_ctx *ctx, int seed, long long skip, int n, double *out)
 {
   if (!ctx || !out || n < 0 || skip < 0) return UCG_ERR_INVALID;
@@ -1236,6 +1303,10 @@ int ucg_ctx_set_option(ucg_ctx *ctx, const char *name, int value)
   }
   if (std::strcmp(name, "fma_contract") == 0) {
     ctx->fma_contract = value != 0;
+    return UCG_OK;
+  }
+  if (std::strcmp(name, "post_in_pair") == 0) {
+    ctx->post_in_pair = value != 0;
     return UCG_OK;
   }
   if (std::strcmp(name, "rows_untiled") == 0) {

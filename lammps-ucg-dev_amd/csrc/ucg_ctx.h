@@ -52,6 +52,25 @@ class DevBuf {
     cap_ = want;
   }
   T *get() const { return p_; }
+  // exactly n elements (no growth slack), contents dropped: for buffers that trade places with another one
+  void reserve_exact(size_t n)
+  {
+    if (n == cap_) return;
+    T *q = nullptr;
+    UCG_HIP(hipMalloc((void **) &q, (n ? n : 1) * sizeof(T)));
+    if (p_) (void) hipFree(p_);
+    p_ = q;
+    cap_ = n;
+  }
+  void swap(DevBuf &o)
+  {
+    T *p = p_;
+    p_ = o.p_;
+    o.p_ = p;
+    const size_t c = cap_;
+    cap_ = o.cap_;
+    o.cap_ = c;
+  }
   size_t capacity() const { return cap_; }
 
  private:
@@ -103,6 +122,10 @@ struct ucg_ctx {
   // atoms
   int nlocal = 0, nghost = 0, ntypes = 0;
   ucg::DevBuf<double4> pos4, vel4, frc4;
+  ucg::DevBuf<double4> pos4_alt;  // second position / meta buffers of the gather kernels' epilogue (PostDev)
+  ucg::DevBuf<int> meta_alt;
+  ucg::DevBuf<double> ucgp_alt;
+  bool post_in_pair = true;       // option "post_in_pair"
   ucg::DevBuf<double2> scores;
   ucg::DevBuf<int> meta, tag, mask, num_ucgstates;
   ucg::DevBuf<int> mol;  // atom->molecule of the owned beads (optional: ucg_atoms_upload_molecule)

@@ -64,6 +64,22 @@ struct AtomsDev {
   const double *mass;  // [ntypes+1]
 };
 
+// Optional epilogue of the gather kernels: the per-bead hooks that follow the pair force on a step whose
+// next initial_integrate is fused in (k_post_fused<.., NEXT = true>), done by the lane that has just summed
+// the bead's forces -- they never travel through HBM.  Positions / states of the next step go to a second
+// buffer (other workgroups are still reading the current ones); the host swaps the buffers afterwards.
+struct PostDev {
+  int enabled;
+  int lang, ucgst, nve;  // which hooks (nve: 0 none, 1 nve/ucgld, 2 nve/ucgld/wall/hard, 3 + bias_potential)
+  int ld_flag, mc_flag, groupbit;
+  double mc_rate, tsqrt, dtv, dtf, barrier;
+  const double *gfactor1, *gfactor2;
+  const unsigned int *lang_draws, *mc_draws;
+  double4 *pos_out;
+  int *meta_out;
+  double *ucgp_out;  // written (and swapped in by the host) only when ucgst is set
+};
+
 struct ListDev {
   int inum;
   int pitch;
@@ -74,6 +90,7 @@ struct ListDev {
   // workgroups that touch no ghost): run only workgroups with blockflag[chunk] == blockwant
   const int *blockflag;
   int blockwant;
+  PostDev post;
 };
 
 }  // namespace ucg

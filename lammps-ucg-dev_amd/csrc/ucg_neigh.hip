@@ -1365,11 +1365,17 @@ int ucg_md_run(ucg_ctx *ctx, long long nsteps, int thermo_every)
       return UCG_OK;
     });
     if (rc) return rc;
-    if ((rc = ucg_pair_compute(ctx->md_pair, ev, ev, nullptr, nullptr))) return rc;
     const bool fuse_next = ctx->md_nve && !ev && (s + 1 < nsteps) && !ctx->md_no_fuse;
-    if ((rc = ucg_md_post_fused(ctx, ctx->md_lang, ctx->md_ucgst, ctx->md_nve, fuse_next, ctx->groupbit, ctx->ntimestep,
-                                ctx->beginstep, ctx->endstep)))
-      return rc;
+    // a step whose next initial_integrate is fused in runs its per-bead hooks in the gather kernel's epilogue
+    rc = fuse_next ? ucg_md_pair_post(ctx, ctx->md_pair, ctx->md_lang, ctx->md_ucgst, ctx->md_nve, ctx->groupbit,
+                                      ctx->ntimestep, ctx->beginstep, ctx->endstep)
+                   : UCG_ERR_UNSUPPORTED;
+    if (rc == UCG_ERR_UNSUPPORTED) {
+      if ((rc = ucg_pair_compute(ctx->md_pair, ev, ev, nullptr, nullptr))) return rc;
+      rc = ucg_md_post_fused(ctx, ctx->md_lang, ctx->md_ucgst, ctx->md_nve, fuse_next, ctx->groupbit, ctx->ntimestep,
+                             ctx->beginstep, ctx->endstep);
+    }
+    if (rc) return rc;
     initial_done = fuse_next;
     // end_of_step: the lambda temperature is a diagnostic (compute_scalar); evaluated on thermo steps
     if (ev && ctx->md_lang && (rc = ucg_fix_langevin_end_of_step(ctx, ctx->groupbit, nullptr))) return rc;

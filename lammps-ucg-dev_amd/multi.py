@@ -314,23 +314,32 @@ class RankSim:
             if self.cluster:
                 ctx.md_set_timestep(self.ntimestep)
             due, flag = ctx.decide_local()
-            if due and self.tr.allreduce_max(flag):
+            fuse_next = (not ev) and (s + 1 < nsteps)
+            rebuilt = bool(due and self.tr.allreduce_max(flag))
+            if rebuilt:
                 self.rebuild()
                 if self.cluster and ctx.cs_due()[1]:
                     self._cluster_step()
-                out = self._pair_compute(ev)
             elif self.overlap and not ev and not self.density:
                 self.halo_forward_and_pair()
-                out = None
+                ctx.md_post_fused(self.use_langevin, self.use_ucgstate, self.nve_kind, fuse_next, self.ntimestep,
+                                  self.beginstep, self.endstep, self.groupbit)
+                initial_done = fuse_next
+                continue
             else:
                 self.halo_forward()
+            # pair force, then langevin -> ucgstate -> final_integrate (-> next initial_integrate): one launch (the
+            # gather kernel's epilogue) where that applies, else two
+            if fuse_next and not self.density and ctx.md_pair_post(self.pair, self.use_langevin, self.use_ucgstate,
+                                                                     self.nve_kind, self.ntimestep, self.beginstep,
+                                                                     self.endstep, self.groupbit):
+                pass
+            else:
                 out = self._pair_compute(ev)
-            if ev:
-                last = out
-            # langevin -> ucgstate -> final_integrate (-> next initial_integrate) as one launch
-            fuse_next = (not ev) and (s + 1 < nsteps)
-            ctx.md_post_fused(self.use_langevin, self.use_ucgstate, self.nve_kind, fuse_next, self.ntimestep, self.beginstep,
-                              self.endstep, self.groupbit)
+                if ev:
+                    last = out
+                ctx.md_post_fused(self.use_langevin, self.use_ucgstate, self.nve_kind, fuse_next, self.ntimestep,
+                                  self.beginstep, self.endstep, self.groupbit)
             initial_done = fuse_next
         return last
 
