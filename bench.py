@@ -160,6 +160,8 @@ def main():
             ctx.set_option("gather_slots", int(os.environ["UCG_GATHER_SLOTS"]))
         if os.environ.get("UCG_FMA_CONTRACT"):  # NOT the bit-exact path: see DESIGN.md 4.1; never the default
             ctx.set_option("fma_contract", int(os.environ["UCG_FMA_CONTRACT"]))
+        if os.environ.get("UCG_POST_IN_PAIR"):
+            ctx.set_option("post_in_pair", int(os.environ["UCG_POST_IN_PAIR"]))
         if os.environ.get("UCG_STAGE_OWN"):
             ctx.set_option("stage_own", int(os.environ["UCG_STAGE_OWN"]))
         ctx.upload_beads(beads)
