@@ -80,6 +80,8 @@ class Transport:
         self.host_group = None
         if not staged and os.environ.get("UCG_HOST_GROUP", "1") != "0":
             try:
+                # one node: the loopback interface is always there (the host name may not resolve)
+                os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
                 self.host_group = dist.new_group(backend="gloo")
             except Exception:  # noqa: BLE001
                 self.host_group = None
