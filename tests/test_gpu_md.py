@@ -123,3 +123,37 @@ def test_md_trajectory_bitwise(fresh_ctx, pkg, orc, style, extra, langevin, ucgs
         # lambda stays between the walls (up to one step's overshoot) and both states are populated
         assert np.all(G["ucgl"] > -0.3) and np.all(G["ucgl"] < 1.3)
         assert 0 < G["ucgstate"].sum() < beads.n
+
+
+@pytest.mark.parametrize("options", [dict(post_in_pair=0), dict(post_in_pair=0, md_no_fuse=1), dict(gather_slots=4)])
+@pytest.mark.parametrize("style,ucgstate", [("table_ucgld", "ld"), ("table_ucg_bethe", ("mc", 9127, 0.2))])
+def test_resident_loop_variants_give_the_same_bits(fresh_ctx, pkg, orc, style, ucgstate, options):
+    """the resident loop has three forms of an ordinary step -- hooks in the gather kernel's epilogue (default), pair
+    kernel + fused per-bead kernel (post_in_pair = 0), and that with initial_integrate as its own launch
+    (md_no_fuse = 1): all must reproduce the oracle bit for bit (the other trajectory tests run the default)"""
+    deck = util.make_deck("spline", 1024)
+    beads = pkg.synth.make_beads(8, seed=77)
+    lang = (1.0, 1.0, 1.0, 48279) if style == "table_ucgld" else None
+    slots = options.get("gather_slots", 1)
+    op = util.oracle_pair(style, deck, slots=slots)
+    sim = util.oracle_sim(beads, op, mode=1, dt=0.004, langevin=lang, nve=True, ucgstate=ucgstate, every=2)
+    assert sim.setup(50) == 0 and sim.run(50, 20) == 0
+    ctx = fresh_ctx
+    _setup_gpu(ctx, beads, 0.004, 2)
+    for k, v in options.items():
+        ctx.set_option(k, v)
+    gp = util.gpu_pair(ctx, style, deck)
+    if lang:
+        ctx.fix_ucgld_langevin(*lang)
+    if ucgstate == "ld":
+        ctx.fix_ucgstate("ld")
+    else:
+        ctx.fix_ucgstate("mc", ucgstate[1], ucgstate[2])
+    ctx.md_attach(gp, nve=True, langevin=lang is not None, ucgstate=True)
+    ctx.md_setup(50)
+    ctx.md_run(50, 20)
+    gp.check_errors()
+    G, O = ctx.atoms_download(), sim.arrays()
+    assert np.array_equal(G["tag"], O["tag"]) and np.array_equal(G["ucgstate"], O["ucgstate"])
+    for k in ("x", "v", "f", "ucgl", "ucgvl", "ucgforce", "scores", "ucgp"):
+        assert util.bits_equal(G[k], O[k]), k
