@@ -39,7 +39,7 @@ struct Domain {
   int nbin[3] = {1, 1, 1}, sten[3] = {0, 0, 0}, nbins = 1;
   double bboxlo[3], bboxhi[3], binsize[3], bininv[3];
   int ago = 0;
-  DevBuf<int> bin_of, ghost_code, counter, rowclass, blockflags;
+  DevBuf<int> bin_of, ghost_code, counter, rowclass, blockflags, blockoffset;
   DevBuf<int4> cells;     // per bin {owned start, owned end, ghost start, ghost end}
   DevBuf<double4> bpos;   // builder records {x, y, z, (double) tag}
   DevBuf<double4> xhold, tmp4;
@@ -164,36 +164,65 @@ __global__ __launch_bounds__(NB) void k_bins_from_pos(const DomainDev D, int n, 
   bin_of[offset + i] = coord2bin(D, p.x, p.y, p.z);
 }
 
-// periodic images of owned beads that fall inside the extended box; FILL=false counts only
+// periodic images of owned beads that fall inside the extended box.  No atomics: FILL=false writes the number of
+// images per workgroup, the host scans them, FILL=true writes the images at blockoffset + (wavefront, shift, lane)
+// rank -- the same ballots in both passes.  (Thousands of same-address atomics took 50 us per pass.)
 template <bool FILL>
 __global__ __launch_bounds__(NB) void k_ghost_candidates(const DomainDev D, int n, const double4 *pos4, const int *tag,
-                                                        int *counter, unsigned long long *keys, int *vals,
-                                                        int *cand_src, int *cand_code)
+                                                        int *blockcount, const int *blockoffset,
+                                                        unsigned long long *keys, int *vals, int *cand_src,
+                                                        int *cand_code)
 {
+  __shared__ int s_wave[NB / 64];
   const int i = blockIdx.x * NB + threadIdx.x;
-  if (i >= n) return;
-  const double4 p = pos4[i];
-  for (int sz = -1; sz <= 1; sz++) {
-    const double zs = p.z + sz * D.prd[2];
-    if (zs < D.bboxlo[2] || zs >= D.bboxhi[2]) continue;
-    for (int sy = -1; sy <= 1; sy++) {
-      const double ys = p.y + sy * D.prd[1];
-      if (ys < D.bboxlo[1] || ys >= D.bboxhi[1]) continue;
-      for (int sx = -1; sx <= 1; sx++) {
-        if (sx == 0 && sy == 0 && sz == 0) continue;
-        const double xs = p.x + sx * D.prd[0];
-        if (xs < D.bboxlo[0] || xs >= D.bboxhi[0]) continue;
-        const int slot = atomicAdd(counter, 1);
-        if (FILL) {
-          const int code = (sz + 1) * 9 + (sy + 1) * 3 + (sx + 1);
-          const unsigned long long b = morton_of_bin(D, coord2bin(D, xs, ys, zs));
-          keys[slot] = (b << 37) | ((unsigned long long) (unsigned int) tag[i] << 5) | (unsigned long long) code;
-          vals[slot] = slot;
-          cand_src[slot] = i;
-          cand_code[slot] = code;
-        }
-      }
+  const bool live = i < n;
+  const double4 p = live ? pos4[i] : make_double4(0, 0, 0, 0);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // most wavefronts hold interior beads only (Morton order): none of their beads has an image in the shell
+  const bool shell = live && (p.x + D.prd[0] < D.bboxhi[0] || p.x - D.prd[0] >= D.bboxlo[0] || p.y + D.prd[1] < D.bboxhi[1] ||
+                              p.y - D.prd[1] >= D.bboxlo[1] || p.z + D.prd[2] < D.bboxhi[2] || p.z - D.prd[2] >= D.bboxlo[2]);
+  const bool any_shell = __any(shell);
+  // pass over the 26 shifts: this wavefront's number of images
+  int mine = 0;
+  if (any_shell) {
+    for (int code = 0; code < 27; code++) {
+      if (code == 13) continue;
+      const int sx = code % 3 - 1, sy = (code / 3) % 3 - 1, sz = code / 9 - 1;
+      const double xs = p.x + sx * D.prd[0], ys = p.y + sy * D.prd[1], zs = p.z + sz * D.prd[2];
+      const bool hit = live && !(zs < D.bboxlo[2] || zs >= D.bboxhi[2]) && !(ys < D.bboxlo[1] || ys >= D.bboxhi[1]) &&
+                       !(xs < D.bboxlo[0] || xs >= D.bboxhi[0]);
+      mine += __popcll(__ballot(hit));
     }
+  }
+  if (lane == 0) s_wave[wave] = mine;
+  __syncthreads();
+  if (!FILL) {
+    if (threadIdx.x == 0) {
+      int tot = 0;
+      for (int w = 0; w < NB / 64; w++) tot += s_wave[w];
+      blockcount[blockIdx.x] = tot;
+    }
+    return;
+  }
+  if (!any_shell) return;
+  int base = blockoffset[blockIdx.x];
+  for (int w = 0; w < wave; w++) base += s_wave[w];
+  for (int code = 0; code < 27; code++) {
+    if (code == 13) continue;
+    const int sx = code % 3 - 1, sy = (code / 3) % 3 - 1, sz = code / 9 - 1;
+    const double xs = p.x + sx * D.prd[0], ys = p.y + sy * D.prd[1], zs = p.z + sz * D.prd[2];
+    const bool hit = live && !(zs < D.bboxlo[2] || zs >= D.bboxhi[2]) && !(ys < D.bboxlo[1] || ys >= D.bboxhi[1]) &&
+                     !(xs < D.bboxlo[0] || xs >= D.bboxhi[0]);
+    const unsigned long long mask = __ballot(hit);
+    if (hit) {
+      const int slot = base + __popcll(mask & ((1ull << lane) - 1ull));
+      const unsigned long long b = morton_of_bin(D, coord2bin(D, xs, ys, zs));
+      keys[slot] = (b << 37) | ((unsigned long long) (unsigned int) tag[i] << 5) | (unsigned long long) code;
+      vals[slot] = slot;
+      cand_src[slot] = i;
+      cand_code[slot] = code;
+    }
+    base += __popcll(mask);
   }
 }
 
@@ -741,14 +770,26 @@ void rebuild(ucg_ctx *ctx)
 
   sort_owned(ctx, true);
 
-  // (4) ghosts: count, fill, sort by (bin, tag, code)
-  D.counter.reserve(4);
-  UCG_HIP(hipMemsetAsync(D.counter.get(), 0, sizeof(int), st));
-  hipLaunchKernelGGL(k_ghost_candidates<false>, dim3(nblk(n)), dim3(NB), 0, st, dd, n, ctx->pos4.get(), ctx->tag.get(),
-                     D.counter.get(), nullptr, nullptr, nullptr, nullptr);
+  // (4) ghosts: count per workgroup, scan, fill, sort by (bin, tag, code)
+  const int nblocks = nblk(n);
+  D.counter.reserve((size_t) nblocks + 4);       // per-workgroup image counts
+  D.blockoffset.reserve((size_t) nblocks + 4);
+  hipLaunchKernelGGL(k_ghost_candidates<false>, dim3(nblocks), dim3(NB), 0, st, dd, n, ctx->pos4.get(), ctx->tag.get(),
+                     D.counter.get(), nullptr, nullptr, nullptr, nullptr, nullptr);
+  {
+    size_t bytes = 0;
+    UCG_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, D.counter.get(), D.blockoffset.get(), nblocks, st));
+    D.cub_tmp.reserve(bytes + 16);
+    UCG_HIP(hipcub::DeviceScan::ExclusiveSum(D.cub_tmp.get(), bytes, D.counter.get(), D.blockoffset.get(), nblocks, st));
+  }
   int ng = 0;
-  UCG_HIP(hipMemcpyAsync(&ng, D.counter.get(), sizeof(int), hipMemcpyDeviceToHost, st));
-  UCG_HIP(hipStreamSynchronize(st));
+  {
+    int last[2] = {0, 0};
+    UCG_HIP(hipMemcpyAsync(&last[0], D.counter.get() + (nblocks - 1), sizeof(int), hipMemcpyDeviceToHost, st));
+    UCG_HIP(hipMemcpyAsync(&last[1], D.blockoffset.get() + (nblocks - 1), sizeof(int), hipMemcpyDeviceToHost, st));
+    UCG_HIP(hipStreamSynchronize(st));
+    ng = last[0] + last[1];
+  }
   const size_t nall = (size_t) n + (size_t) ng;
   if (nall >= (size_t) UCG_NEIGHMASK) throw InputError{"too many beads + ghosts for 29-bit neighbour indices"};
   ctx->pos4.reserve(nall, true, st);
@@ -765,9 +806,8 @@ void rebuild(ucg_ctx *ctx)
     D.vals_out.reserve((size_t) ng);
     D.cand_src.reserve((size_t) ng);
     D.cand_code.reserve((size_t) ng);
-    UCG_HIP(hipMemsetAsync(D.counter.get(), 0, sizeof(int), st));
-    hipLaunchKernelGGL(k_ghost_candidates<true>, dim3(nblk(n)), dim3(NB), 0, st, dd, n, ctx->pos4.get(), ctx->tag.get(),
-                       D.counter.get(), D.keys_in.get(), D.vals_in.get(), D.cand_src.get(), D.cand_code.get());
+    hipLaunchKernelGGL(k_ghost_candidates<true>, dim3(nblocks), dim3(NB), 0, st, dd, n, ctx->pos4.get(), ctx->tag.get(),
+                       nullptr, D.blockoffset.get(), D.keys_in.get(), D.vals_in.get(), D.cand_src.get(), D.cand_code.get());
     sort_pairs(ctx, D, ng);
     hipLaunchKernelGGL(k_ghost_finalize, dim3(nblk(ng)), dim3(NB), 0, st, ng, n, D.vals_out.get(), D.keys_out.get(),
                        D.cand_src.get(), D.cand_code.get(), ctx->ghost_src.get(), D.ghost_code.get(), D.bin_of.get(),
