@@ -41,6 +41,7 @@ struct Domain {
   int ago = 0;
   DevBuf<int> bin_of, ghost_code, counter, rowclass, blockflags, blockoffset;
   DevBuf<int4> cells;     // per bin {owned start, owned end, ghost start, ghost end}
+  DevBuf<int4> blockstat; // per brick of the tiled row builder {max row, max skin, entries, -}
   DevBuf<double4> bpos;   // builder records {x, y, z, (double) tag}
   DevBuf<double4> xhold, tmp4;
   DevBuf<unsigned long long> keys_in, keys_out;
@@ -504,8 +505,7 @@ __device__ __forceinline__ void tile_walk(const DomainDev &D, const double3 &bin
 __global__ __launch_bounds__(TILE_B) void k_rows_tile(const DomainDev D, const double4 *pos4, const int *tag,
                                                       const int *bin_of, const int4 *cells, int *rowcount, int *neigh,
                                                       int *skin, int pitch, int cap, int capskin, const double3 binsize,
-                                                      const int3 nbrick, int *maxrow, unsigned long long *total,
-                                                      int *fallback, int *maxskin)
+                                                      const int3 nbrick, int4 *blockstat, int *fallback)
 {
   __shared__ TileCand s_cand[TILE_CAP];
   __shared__ int s_start[TILE_NREG + 1], s_cnt[TILE_NREG];
@@ -637,9 +637,44 @@ __global__ __launch_bounds__(TILE_B) void k_rows_tile(const DomainDev D, const d
       mxs = max(mxs, s_maxs[w]);
       tot += s_tot[w];
     }
-    atomicMax(maxrow, mx);
-    atomicMax(maxskin, mxs);
-    atomicAdd(total, tot);
+    // one record per brick (the fold kernel reduces them: same-address atomics from thousands of bricks serialise)
+    blockstat[blockIdx.x] = make_int4(mx, mxs, (int) tot, 0);
+  }
+}
+
+// maxima and total of the per-brick records -> rowstat {max row | total | (fallback flag, untouched) | max skin}
+__global__ __launch_bounds__(1024) void k_rowstat_fold(int nblocks, const int4 *blockstat, unsigned long long *rowstat)
+{
+  __shared__ int s_mx[16], s_ms[16];
+  __shared__ unsigned long long s_t[16];
+  int mx = 0, ms = 0;
+  unsigned long long tot = 0;
+  for (int b = threadIdx.x; b < nblocks; b += 1024) {
+    const int4 v = blockstat[b];
+    mx = max(mx, v.x);
+    ms = max(ms, v.y);
+    tot += (unsigned long long) v.z;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    mx = max(mx, __shfl_down(mx, off, 64));
+    ms = max(ms, __shfl_down(ms, off, 64));
+    tot += __shfl_down(tot, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    s_mx[threadIdx.x >> 6] = mx;
+    s_ms[threadIdx.x >> 6] = ms;
+    s_t[threadIdx.x >> 6] = tot;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; w++) {
+      mx = max(mx, s_mx[w]);
+      ms = max(ms, s_ms[w]);
+      tot += s_t[w];
+    }
+    rowstat[0] = (unsigned long long) mx;
+    rowstat[1] = tot;
+    rowstat[3] = (unsigned long long) ms;
   }
 }
 
@@ -859,10 +894,12 @@ void build_bins_and_rows(ucg_ctx *ctx)
       ctx->neigh.reserve((size_t) pitch * (size_t) cap);
       D.scratch.reserve((size_t) pitch * (size_t) capskin);
       UCG_HIP(hipMemsetAsync(D.rowstat.get(), 0, 4 * sizeof(unsigned long long), st));
+      D.blockstat.reserve((size_t) nblocks + 1);
+      UCG_HIP(hipMemsetAsync(D.blockstat.get(), 0, (size_t) nblocks * sizeof(int4), st));
       hipLaunchKernelGGL(k_rows_tile, dim3((unsigned) nblocks), dim3(TILE_B), 0, st, dd, ctx->pos4.get(), ctx->tag.get(),
                          D.bin_of.get(), D.cells.get(), ctx->numneigh.get(), ctx->neigh.get(), D.scratch.get(), pitch, cap,
-                         capskin, bs, nbrick, (int *) D.rowstat.get(), D.rowstat.get() + 1, (int *) (D.rowstat.get() + 2),
-                         (int *) (D.rowstat.get() + 3));
+                         capskin, bs, nbrick, D.blockstat.get(), (int *) (D.rowstat.get() + 2));
+      hipLaunchKernelGGL(k_rowstat_fold, dim3(1), dim3(1024), 0, st, (int) nblocks, D.blockstat.get(), D.rowstat.get());
       unsigned long long stat[4];
       UCG_HIP(hipMemcpyAsync(stat, D.rowstat.get(), sizeof stat, hipMemcpyDeviceToHost, st));
       UCG_HIP(hipStreamSynchronize(st));
