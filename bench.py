@@ -4,9 +4,11 @@
   python bench.py --gpus N --steps K --warmup W
 
 One "step" is one full Verlet step of the resident path on synthetic input:
-fix nve/ucgld initial_integrate -> re-neighbour decision (every 10 steps, rebuild when a
+fix nve/ucgld/wall/hard initial_integrate -> re-neighbour decision (every 10 steps, rebuild when a
 bead moved skin/2) / halo refresh -> pair_style table_ucgld (spline 1024, 2-state, the
 north-star neighbour loop) -> fix ucgld/langevin -> fix ucgstate ld -> final_integrate.
+(The hard-wall variant of the lambda integrator: plain fix nve/ucgld lets lambda drift without bound and the
+melt breaks down after ~1000 steps, in the reference as here -- see --integrator.)
 Workload (BASELINE.md config 4 at N GPUs, config-2 styles at 1 M beads): 100^3 beads at
 rho* = 0.8, rc = 2.5, skin = 0.3, dt = 0.002, fp64 throughout.  For N > 1 the SAME 1 M beads
 are split across the ranks (strong scaling).  Inputs are resident in HBM before timing.
@@ -33,7 +35,7 @@ import __graft_entry__ as entry  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 
 
-def cpu_baseline(pkg, deck, ncell, nsteps, dt):
+def cpu_baseline(pkg, deck, ncell, nsteps, dt, integrator="wall"):
     """oracle, reference order (sequential half list + scatter + reverse sum), 1 core"""
     orc = entry.load_oracle()
     beads = pkg.synth.make_beads(ncell, seed=12345)
@@ -43,7 +45,7 @@ def cpu_baseline(pkg, deck, ncell, nsteps, dt):
     op.init(2, 1.0, 1.0)
     sim = orc.Sim(beads)
     sim.set_run_params(dt=dt, every=10, delay=0, check=1, mode=0)
-    sim.attach(op, langevin=(1.0, 1.0, 1.0, 48279), nve=True, ucgstate="ld")
+    sim.attach(op, langevin=(1.0, 1.0, 1.0, 48279), nve="wall" if integrator == "wall" else True, ucgstate="ld")
     sim.setup(nsteps)
     t0 = time.perf_counter()
     sim.run(nsteps, 0)
@@ -54,7 +56,7 @@ def cpu_baseline(pkg, deck, ncell, nsteps, dt):
                 ns_per_entry=t / nsteps / max(info["nhalf"], 1) * 1e9)
 
 
-def cpu_baseline_threads(pkg, deck, ncell, nsteps, dt, nthreads):
+def cpu_baseline_threads(pkg, deck, ncell, nsteps, dt, nthreads, integrator="wall"):
     """P independent copies of the same scalar loop, one per host thread (the oracle is a C library:
     ctypes releases the GIL), each on its own periodic ncell^3 box -- what `mpirun -np P` of the
     reference does per rank, without the halo exchange (so an upper bound for it)."""
@@ -70,7 +72,7 @@ def cpu_baseline_threads(pkg, deck, ncell, nsteps, dt, nthreads):
         op.init(2, 1.0, 1.0)
         sim = orc.Sim(beads)
         sim.set_run_params(dt=dt, every=10, delay=0, check=1, mode=0)
-        sim.attach(op, langevin=(1.0, 1.0, 1.0, 48279 + t), nve=True, ucgstate="ld")
+        sim.attach(op, langevin=(1.0, 1.0, 1.0, 48279 + t), nve="wall" if integrator == "wall" else True, ucgstate="ld")
         sim.setup(nsteps)
         sims.append((sim, op, beads.n))
     threads = [threading.Thread(target=lambda s=s: s[0].run(nsteps, 0)) for s in sims]
@@ -96,6 +98,12 @@ def main():
                     choices=["table_ucgld", "table_ucg_bethe", "table_ucg_bethe_density"],
                     help="pair style of the 1-GPU leg (default: the headline table_ucgld workload; the others are "
                          "BASELINE.md configs 3 and 5 at 1 M beads, reported with their own algorithmic bytes)")
+    ap.add_argument("--integrator", default="wall", choices=["wall", "nve"],
+                    help="wall = fix nve/ucgld/wall/hard (default), nve = fix nve/ucgld.  The latter never clamps lambda "
+                         "(UCG/fix_nve_ucgld.cpp:44-153): with the linear-in-lambda mixing nothing confines it, and after "
+                         "~1000 steps of this melt it has drifted far enough outside [0, 1] for the mixed potentials to "
+                         "turn attractive at contact -- the reference stops there with 'Pair distance < table inner "
+                         "cutoff' (tools/stability.py).  The hard-wall variant of the same integrator is stable.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-ncell", type=int, default=64)
     ap.add_argument("--cpu-steps", type=int, default=10)
@@ -177,7 +185,10 @@ def main():
             ctx.fix_ucgstate(None)  # state = round(ucgp), ucgl = ucgp (the prior of the next step)
         else:
             ctx.fix_ucgstate("mc", 9127, 0.01)
-        ctx.md_attach(pair, nve=True, langevin=args.style == "table_ucgld", ucgstate=True)
+        wall = args.integrator == "wall"
+        if wall:
+            ctx.fix_nve_ucgld_wall_hard(False, 0.1)
+        ctx.md_attach(pair, nve="wall" if wall else True, langevin=args.style == "table_ucgld", ucgstate=True)
         ctx.md_setup(args.warmup + args.steps)
         ctx.md_run(args.warmup, 0)
         ctx.synchronize()
@@ -224,9 +235,10 @@ def main():
     achieved = alg_bytes / pair_avg_s / 1e9 if pair_avg_s > 0 else 0.0
     out = {
         "metric": "timesteps/sec at 1M UCG beads (" + {
-            "table_ucgld": "table_ucgld + nve/ucgld + ucgld/langevin + ucgstate ld",
-            "table_ucg_bethe": "table_ucg_bethe method bethe pseudo yes prior ucgl + nve/ucgld + ucgstate",
-            "table_ucg_bethe_density": "table_ucg_bethe_density + nve/ucgld + ucgstate mc 9127 0.01"}[args.style] + ")",
+            "table_ucgld": "table_ucgld + INTEG + ucgld/langevin + ucgstate ld",
+            "table_ucg_bethe": "table_ucg_bethe method bethe pseudo yes prior ucgl + INTEG + ucgstate",
+            "table_ucg_bethe_density": "table_ucg_bethe_density + INTEG + ucgstate mc 9127 0.01"}[args.style].replace(
+                "INTEG", "nve/ucgld/wall/hard" if args.integrator == "wall" else "nve/ucgld") + ")",
         "value": steps_per_s,
         "unit": "timesteps/s",
         "n_gpus": world,
@@ -242,10 +254,10 @@ def main():
         "config": {
             "workload": f"{n} beads (sc lattice {args.ncell}^3 + jitter), rho*=0.8, rc=2.5, skin=0.3, dt=0.002, "
                         f"pair_style {args.style} {args.tabstyle} {args.tablength} (2-state, 4 LJ-like tables) + " + {
-                            "table_ucgld": "fix nve/ucgld + fix ucgld/langevin 1.0 1.0 1.0 48279 + fix ucgstate ld; ",
-                            "table_ucg_bethe": "method bethe pseudo yes prior ucgl + fix nve/ucgld + fix ucgstate; ",
-                            "table_ucg_bethe_density": "density 11.3 1.5 + fix nve/ucgld + fix ucgstate mc 9127 0.01; ",
-                        }[args.style] +
+                            "table_ucgld": "fix INTEG + fix ucgld/langevin 1.0 1.0 1.0 48279 + fix ucgstate ld; ",
+                            "table_ucg_bethe": "method bethe pseudo yes prior ucgl + fix INTEG + fix ucgstate; ",
+                            "table_ucg_bethe_density": "density 11.3 1.5 + fix INTEG + fix ucgstate mc 9127 0.01; ",
+                        }[args.style].replace("INTEG", "nve/ucgld/wall/hard" if args.integrator == "wall" else "nve/ucgld") +
                         "neigh_modify every 10 check yes; rebuilds inside the timed region: "
                         f"{result['rebuilds']}",
             "beads": n,
@@ -281,7 +293,7 @@ def main():
             out["roofline"]["traffic"] = json.load(fh)["traffic_bytes_per_launch"]
         out["roofline"]["traffic_note"] = "HBM bytes per launch from rocprofv3 PMC (FETCH_SIZE x2 per the gfx950 calibration + WRITE_SIZE), profiles/r01_pair_traffic.json"
     if not args.no_cpu_baseline and args.style == "table_ucgld":
-        cb = cpu_baseline(pkg, deck, args.cpu_ncell, args.cpu_steps, dt)
+        cb = cpu_baseline(pkg, deck, args.cpu_ncell, args.cpu_steps, dt, args.integrator)
         one = {
             "value": cb["atom_steps_per_s"] / n,
             "unit": "timesteps/s",
@@ -294,7 +306,7 @@ def main():
         nthreads = args.cpu_threads or min(os.cpu_count() or 1, 16)
         if nthreads > 1:
             # the reference runs one MPI rank per core: P copies of the same scalar loop, one per thread
-            mt = cpu_baseline_threads(pkg, deck, 40, 2 * args.cpu_steps, dt, nthreads)
+            mt = cpu_baseline_threads(pkg, deck, 40, 2 * args.cpu_steps, dt, nthreads, args.integrator)
             out["cpu_baseline"] = {
                 "value": mt["atom_steps_per_s"] / n,
                 "unit": "timesteps/s",

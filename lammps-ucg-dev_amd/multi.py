@@ -374,7 +374,10 @@ def run_bench(args, deck, rank, world, local_rank, dist):
     ctx.fix_ucgld_langevin(1.0, 1.0, 1.0, 48279, me=rank)
     ctx.fix_ucgstate("ld", me=rank)
     tr = Transport(dist, device, staged=False)
-    sim = RankSim(ctx, pair, tr, grid)
+    wall = getattr(args, "integrator", "wall") == "wall"
+    if wall:
+        ctx.fix_nve_ucgld_wall_hard(False, 0.1)
+    sim = RankSim(ctx, pair, tr, grid, integrator="wall" if wall else "nve")
     sim.setup(args.warmup + args.steps)
     sim.run(args.warmup)
     ctx.synchronize()

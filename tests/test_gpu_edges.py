@@ -98,7 +98,8 @@ def test_full_size_properties_1M_beads(fresh_ctx, pkg):
         gp = util.gpu_pair(ctx, "table_ucgld", deck)
         ctx.fix_ucgld_langevin(1.0, 1.0, 1.0, 48279)
         ctx.fix_ucgstate("ld")
-        ctx.md_attach(gp, nve=True, langevin=True, ucgstate=True)
+        ctx.fix_nve_ucgld_wall_hard(False, 0.1)
+        ctx.md_attach(gp, nve="wall", langevin=True, ucgstate=True)
         ctx.md_setup(nsteps)
         first = ctx.atoms_download()
         lst = ctx.neigh_download() + (ctx.md_info()["list_entries"],)
@@ -137,5 +138,5 @@ def test_full_size_properties_1M_beads(fresh_ctx, pkg):
     for k in ("x", "v", "f", "ucgl", "ucgvl", "ucgp", "scores"):
         assert util.bits_equal(A1[k], B1[k]), k
     assert np.array_equal(A1["tag"], B1["tag"])
-    # lambda stays finite, posteriors stay inside the clamp of fix ucgstate
-    assert np.all(np.isfinite(A1["ucgl"])) and np.all((A1["ucgp"] >= 1e-6) & (A1["ucgp"] <= 1 - 1e-6))
+    # the hard walls keep lambda in [0, 1]; posteriors stay inside the clamp of fix ucgstate
+    assert np.all((A1["ucgl"] >= 0.0) & (A1["ucgl"] <= 1.0)) and np.all((A1["ucgp"] >= 1e-6) & (A1["ucgp"] <= 1 - 1e-6))
