@@ -338,6 +338,56 @@ int ucg_md_thermo(ucg_ctx *ctx, double *out9);
 int ucg_profile_enable(ucg_ctx *ctx, int on);
 int ucg_profile_read(ucg_ctx *ctx, long long *pair_launches, double *pair_ms, int reset);
 
+/* ------------------------------------------------------- on-disk formats (host)
+ * SURVEY.md section 8 row f4.  Host code on caller-owned arrays: no context, no GPU.
+ * Pointers of ucg_io_atoms that are NULL mean "field absent"; x, v, f are [n][3], image is int[n][3] (ix iy iz),
+ * mass is [ntypes+1] indexed by type.  err/errcap receive the message of a failing call (may be NULL/0).
+ *
+ * ucg_io_dump_write   one snapshot of `dump ID group custom N file <columns>` in the native text format, with
+ *                     the keywords ucgstate / ucgl / ucgp of dump_custom.cpp:1672-1688 (+ id mol type mass
+ *                     x y z xs ys zs xu yu zu xsu ysu zsu ix iy iz vx vy vz fx fy fz q, and ucgvl ucgml ucgforce =
+ *                     the remaining property_atom names of UCG/atom_vec_ucg.cpp:172-181).  `modify` holds
+ *                     dump_modify keyword groups, one per line: "thresh <attr> <op> <value>"
+ *                     (dump_custom.cpp:1182-1209, :2150-2155; op < <= > >= == !=), "sort id|off",
+ *                     "format line|int|float|<M> <fmt>", "boundary pp pp pp".
+ * ucg_io_dump_scan / _header / _load   list snapshots, read one header, read every column of one snapshot.
+ * ucg_io_read_dump    `read_dump file N <fields> [box|replace|trim|scaled|wrapped yes/no]` with the fields
+ *                     x y z vx vy vz q ix iy iz fx fy fz ucgstate ucgl ucgp (read_dump.cpp:1344-1349): atoms are
+ *                     matched by ID and overwritten (read_dump.cpp:823-921), trimmed like :925-942; purge/add are
+ *                     refused as in the reference (:954).  timestep < 0 = first snapshot of the file.
+ * ucg_io_write_data / _data_header / _read_data   data-file sections of atom style ucg: Atoms
+ *                     "id mol type q x y z ucgstate ucgl ucgml [ix iy iz]", Velocities "id vx vy vz ucgvl"
+ *                     (UCG/atom_vec_ucg.cpp:87-90); reading applies data_atom_post (:145-170).
+ * ucg_io_write_restart / _restart_header / _read_restart   binary container with the atom style's restart fields
+ *                     ucgstate ucgl ucgml ucgvl ucgp (UCG/atom_vec_ucg.cpp:85) next to id type x v q image mol. */
+typedef struct ucg_io_atoms {
+  long long n;         /* atoms (on input of the read calls: capacity of the arrays) */
+  int ntypes;
+  double boxlo[3], boxhi[3];
+  int *id, *type, *molecule, *ucgstate, *image;
+  double *x, *v, *f, *q, *ucgl, *ucgvl, *ucgml, *ucgp, *ucgforce, *mass;
+} ucg_io_atoms;
+
+int ucg_io_dump_write(const char *path, int append, long long timestep, const ucg_io_atoms *a, const char *columns,
+                      const char *modify, long long *nwritten, char *err, int errcap);
+int ucg_io_dump_scan(const char *path, long long *timesteps, long long *natoms, int cap, int *nfound, char *err,
+                     int errcap);
+int ucg_io_dump_header(const char *path, long long timestep, long long *found_timestep, long long *natoms,
+                       double *boxlo, double *boxhi, char *columns, int columns_cap, char *err, int errcap);
+int ucg_io_dump_load(const char *path, long long timestep, long long natoms, int ncolumns, double *values, char *err,
+                     int errcap);
+int ucg_io_read_dump(const char *path, long long timestep, const char *fields, const char *options, ucg_io_atoms *a,
+                     long long *stats4, char *err, int errcap);
+int ucg_io_write_data(const char *path, long long timestep, const char *units, const ucg_io_atoms *a, char *err,
+                      int errcap);
+int ucg_io_data_header(const char *path, long long *natoms, int *ntypes, double *boxlo, double *boxhi,
+                       int *has_velocities, char *err, int errcap);
+int ucg_io_read_data(const char *path, ucg_io_atoms *a, char *err, int errcap);
+int ucg_io_write_restart(const char *path, long long timestep, const ucg_io_atoms *a, char *err, int errcap);
+int ucg_io_restart_header(const char *path, long long *timestep, long long *natoms, int *ntypes, double *boxlo,
+                          double *boxhi, char *err, int errcap);
+int ucg_io_read_restart(const char *path, ucg_io_atoms *a, long long *timestep, char *err, int errcap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,3 +7,4 @@ tests/conftest.py, bench.py and __graft_entry__.py) under the module name
 from . import synth  # noqa: F401
 from . import capi  # noqa: F401
 from . import multi  # noqa: F401
+from . import ucgio  # noqa: F401
