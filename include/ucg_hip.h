@@ -34,7 +34,7 @@ enum {
   UCG_ERR_HIP = 3,          /* HIP runtime failure                                */
   UCG_ERR_TABLE_INNER = 4,  /* "Pair distance < table inner cutoff"  (ucgld.cpp:437-439) */
   UCG_ERR_TABLE_OUTER = 5,  /* "Pair distance > table outer cutoff"  (ucgld.cpp:442-444) */
-  UCG_ERR_UNSUPPORTED = 6,  /* feature the GPU path does not cover (e.g. BITMAP)  */
+  UCG_ERR_UNSUPPORTED = 6,  /* feature the GPU path does not cover (e.g. prior noise) */
   UCG_ERR_NEIGH_OVERFLOW = 7
 };
 

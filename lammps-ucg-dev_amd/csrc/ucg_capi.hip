@@ -286,11 +286,21 @@ int ucg_pair_init(ucg_pair *p, int ntypes, double T)
           }
     const int ntab = (int) order.size();
     if (ntab > UCG_MAX_TABLES) return fail(ctx, UCG_ERR_UNSUPPORTED, "more tables than the GPU kernels stage (UCG_MAX_TABLES)");
-    const int tl = M.tablength, tlm1 = tl - 1;
+    // BITMAP: two records per bin, {e, de, f, df} and {rsq, drsq, -, -}; the table parameters carry the bit masks
+    const bool bitmap = (M.tabstyle == BITMAP);
+    const int tl = bitmap ? 2 * (1 << M.tablength) : M.tablength, tlm1 = tl - 1;
     std::vector<double4> tab((size_t) ntab * tl), par((size_t) ntab);
     for (int d = 0; d < ntab; d++) {
       const Table &tb = M.tables[(size_t) order[(size_t) d]];
       par[(size_t) d] = make_double4(tb.innersq, tb.delta, tb.invdelta, tb.deltasq6);
+      if (bitmap) {
+        par[(size_t) d] = make_double4(tb.innersq, (double) tb.nmask, (double) tb.nshiftbits, 0.0);
+        for (int k = 0; k < tl / 2; k++) {
+          tab[(size_t) d * tl + 2 * k] = make_double4(tb.e[(size_t) k], tb.de[(size_t) k], tb.f[(size_t) k], tb.df[(size_t) k]);
+          tab[(size_t) d * tl + 2 * k + 1] = make_double4(tb.rsq[(size_t) k], tb.drsq[(size_t) k], 0.0, 0.0);
+        }
+        continue;
+      }
       for (int k = 0; k < tl; k++) {
         double4 v = make_double4(0, 0, 0, 0);
         if (M.tabstyle == LOOKUP) {
@@ -381,7 +391,7 @@ int ucg_pair_init(ucg_pair *p, int ntypes, double T)
       std::memcpy(&kb, &M.kT, sizeof kb);
       const unsigned long long mant = kb & 0xFFFFFFFFFFFFFull, ex = (kb >> 52) & 0x7FF;
       if (mant == 0xFFFFFFFFFFFFFull || ex < 1023 - 200 || ex > 1023 + 200 || (kb >> 63)) fast = false;
-      if (ctx->force_generic_kernels) fast = false;
+      if (ctx->force_generic_kernels || bitmap) fast = false;
       D.kT_pow2 = (mant == 0 && ex > 1023 - 200 && ex < 1023 + 200 && !(kb >> 63)) ? 1 : 0;
       D.fast = fast ? 1 : 0;
       D.fast_stride = 2 * ntab + 1;
@@ -398,8 +408,10 @@ int ucg_pair_init(ucg_pair *p, int ntypes, double T)
       sync(ctx);
       D.tab_fast = p->d_tab_fast.get();
       const size_t bytes = fast ? ((nslots + 1) / 2) * sizeof(double4) : (size_t) ntab * tl * sizeof(double4);
-      D.tab_in_lds = (bytes <= 152 * 1024) ? 1 : 0;
+      D.tab_in_lds = (bytes <= 152 * 1024 && !bitmap) ? 1 : 0;  // bitmapped bins: hundreds of KB, read through L2
       // own-bead staging: 36 bytes per bead of the workgroup behind the tables, if the 160 KB allow it
+      if (bitmap && ctx->gather_slots > 1)
+        return fail(ctx, UCG_ERR_UNSUPPORTED, "bitmap tables run with one lane per bead (option gather_slots 0 or 1)");
       const int slots0 = ctx->gather_slots > 0 ? ctx->gather_slots : 1;
       D.gather_slots = slots0;
       p->tab_lds_bytes = bytes;
@@ -468,6 +480,7 @@ int ucg_pair_table_array(const ucg_pair *p, int m, const char *which, double *ou
   else if (w == "df") v = &tb.df;
   else if (w == "e2") v = &tb.e2;
   else if (w == "f2") v = &tb.f2;
+  else if (w == "drsq") v = &tb.drsq;
   else if (w == "rfile") v = &tb.rfile;
   else if (w == "efile") v = &tb.efile;
   else if (w == "ffile") v = &tb.ffile;
@@ -512,7 +525,7 @@ static int pair_compute_impl(ucg_pair *p, int eflag, int vflag, double *eng_vdwl
     if (!p->uploaded) return fail(ctx, UCG_ERR_INVALID, "ucg_pair_compute before ucg_pair_init");
     if (ctx->list_inum != ctx->nlocal) return fail(ctx, UCG_ERR_INVALID, "neighbour list does not match the resident atoms");
     const bool ev = (eflag || vflag);
-    if (ctx->gather_slots == 0) {
+    if (ctx->gather_slots == 0 && p->dev.tabstyle != BITMAP) {
       // auto: the kernel's time is (rounds of workgroups over the 256 CUs) x (lifetime of one workgroup),
       // the latter ~ row length / lanes per bead + a fixed part; pick the lanes per bead that minimise it
       // (matches the measured order at 125 k / 250 k / 500 k / 1 M beads per GPU)

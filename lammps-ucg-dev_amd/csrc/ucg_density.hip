@@ -494,6 +494,19 @@ hipError_t launch_pass2(const PairDev &Pin, const AtomsDev &A, const ListDev &L,
   return hipGetLastError();
 }
 
+// BITMAP tables: generic path only (see launch_style_bitmap in ucg_pair.hip)
+hipError_t launch_pass2_bitmap(const PairDev &Pin, const AtomsDev &A, const ListDev &L, bool ev, const double2 *prior,
+                               const double *partial0, double2 *cv, double *evpart, int *errflag, hipStream_t st, int nblocks)
+{
+  if (Pin.tab_in_lds || Pin.fast) return hipErrorInvalidValue;
+  PairDev P = Pin;
+  P.stage_own = Pin.stage_own_allowed ? 1 : 0;
+  const size_t ldsbytes = P.stage_own ? (size_t) PAIR_BLOCK * (sizeof(double4) + sizeof(int)) : 0;
+  if (ev) hipLaunchKernelGGL((k_density_pass2<3, true, false, false>), dim3(nblocks), dim3(PAIR_BLOCK), ldsbytes, st, P, A, L, prior, partial0, cv, evpart, errflag);
+  else hipLaunchKernelGGL((k_density_pass2<3, false, false, false>), dim3(nblocks), dim3(PAIR_BLOCK), ldsbytes, st, P, A, L, prior, partial0, cv, evpart, errflag);
+  return hipGetLastError();
+}
+
 }  // namespace
 
 // prior / cv: [nlocal + nghost] double2; partial0: [nlocal]; evpart: 8 * (blocks2 + blocks3) doubles
@@ -511,6 +524,7 @@ hipError_t launch_density(const PairDev &P, const AtomsDev &A, const ListDev &L,
   switch (P.tabstyle) {
     case 0: e = launch_pass2<0>(P, A, L, ev, prior, partial0, cv, evpart, errflag, st, nb2); break;
     case 1: e = launch_pass2<1>(P, A, L, ev, prior, partial0, cv, evpart, errflag, st, nb2); break;
+    case 3: e = launch_pass2_bitmap(P, A, L, ev, prior, partial0, cv, evpart, errflag, st, nb2); break;
     default: e = launch_pass2<2>(P, A, L, ev, prior, partial0, cv, evpart, errflag, st, nb2); break;
   }
   if (e != hipSuccess) return e;
@@ -541,6 +555,7 @@ hipError_t launch_density_phase(const PairDev &P, const AtomsDev &A, const ListD
     switch (P.tabstyle) {
       case 0: e = launch_pass2<0>(P, A, L, ev, prior, partial0, cv, evpart, errflag, st, nb2); break;
       case 1: e = launch_pass2<1>(P, A, L, ev, prior, partial0, cv, evpart, errflag, st, nb2); break;
+      case 3: e = launch_pass2_bitmap(P, A, L, ev, prior, partial0, cv, evpart, errflag, st, nb2); break;
       default: e = launch_pass2<2>(P, A, L, ev, prior, partial0, cv, evpart, errflag, st, nb2); break;
     }
     if (e != hipSuccess) return e;

@@ -10,7 +10,7 @@
 //   init_style/init_one  :867-895, UCG/pair_table_ucg_bethe.cpp:1038-1088
 //   single               :1474-1520
 // Built with -ffp-contract=off: the reference is plain x86-64 code without FMA fusion.
-// BITMAP tables depend on upstream Pair::init_bitmap and are rejected.
+// BITMAP tables use upstream Pair::init_bitmap (absent from the reference tree), restated in init_bitmap().
 #include "ucg_model.h"
 
 #include <cmath>
@@ -103,6 +103,51 @@ double cubic_splint(const double *xa, const double *ya, const double *y2a, int n
       ((a * a * a - a) * y2a[klo] + (b * b * b - b) * y2a[khi]) * (h * h) / 6.0;
 }
 
+namespace {
+inline float int_as_float(int i)
+{
+  float f;
+  std::memcpy(&f, &i, sizeof f);
+  return f;
+}
+inline int float_as_int(float f)
+{
+  int i;
+  std::memcpy(&i, &f, sizeof i);
+  return i;
+}
+}  // namespace
+
+// The table index is made of the low `nexpbits` exponent bits and the top `nmantbits` mantissa bits of the float;
+// masklo / maskhi are the remaining high bits of inner^2 / outer^2.
+void init_bitmap(double inner, double outer, int ntablebits, int &masklo, int &maskhi, int &nmask, int &nshiftbits)
+{
+  constexpr int MANT_DIG = 24, FLOAT_BITS = 32;
+  if (ntablebits > FLOAT_BITS) input_error("Too many total bits for bitmapped lookup table");
+  int nlowermin = 1;
+  while (!((std::pow(2.0, (double) nlowermin) <= inner * inner) && (std::pow(2.0, (double) nlowermin + 1.0) > inner * inner))) {
+    if (std::pow(2.0, (double) nlowermin) <= inner * inner) nlowermin++;
+    else nlowermin--;
+  }
+  int nexpbits = 0;
+  const double required_range = outer * outer / std::pow(2.0, (double) nlowermin);
+  double available_range = 2.0;
+  while (available_range < required_range) {
+    nexpbits++;
+    available_range = std::pow(2.0, std::pow(2.0, (double) nexpbits));
+  }
+  const int nmantbits = ntablebits - nexpbits;
+  if (nexpbits > FLOAT_BITS - MANT_DIG) input_error("Too many exponent bits for lookup table");
+  if (nmantbits + 1 > MANT_DIG) input_error("Too many mantissa bits for lookup table");
+  if (nmantbits < 3) input_error("Too few bits for lookup table");
+  nshiftbits = MANT_DIG - (nmantbits + 1);
+  nmask = 1;
+  for (int j = 0; j < ntablebits + nshiftbits; j++) nmask *= 2;
+  nmask -= 1;
+  maskhi = float_as_int((float) (outer * outer)) & ~nmask;
+  masklo = float_as_int((float) (inner * inner)) & ~nmask;
+}
+
 void Table::param_extract(const std::string &line)
 {
   ninput = 0;
@@ -155,7 +200,14 @@ void Table::read_file(const std::string &file, const std::string &keyword)
   }
   if (!got) input_error("Missing pair table parameter line for " + keyword);
   param_extract(line);
-  if (rflag == RBMP) input_error("BITMAP tables are not supported by the GPU UCG styles");
+  // setup bitmap parameters for table to read in (:918-927)
+  int masklo = 0, maskhi = 0, nm = 0, nsh = 0;
+  ntablebits = 0;
+  if (rflag == RBMP) {
+    while (1 << ntablebits < ninput) ntablebits++;
+    if (1 << ntablebits != ninput) input_error("Bitmapped table is incorrect length in table file");
+    init_bitmap(rlo, rhi, ntablebits, masklo, maskhi, nm, nsh);
+  }
   rfile.assign((size_t) ninput, 0.0);
   efile.assign((size_t) ninput, 0.0);
   ffile.assign((size_t) ninput, 0.0);
@@ -181,6 +233,10 @@ void Table::read_file(const std::string &file, const std::string &keyword)
     else if (rflag == RSQ) {
       rnew = rlo * rlo + (rhi * rhi - rlo * rlo) * i / (ninput - 1);
       rnew = std::sqrt(rnew);
+    } else if (rflag == RBMP) {
+      float fl = int_as_float((i << nsh) | masklo);
+      if (fl < rlo * rlo) fl = int_as_float((i << nsh) | maskhi);
+      rnew = sqrtf(fl);
     }
     rfile[(size_t) i] = rnew;
   }
@@ -210,10 +266,11 @@ void Table::build(int tabstyle, int tablength, double cutoff)
   else { lo = rlo; hi = rhi; }
   if (cut <= lo || cut > hi) input_error("Pair table cutoff outside of table");
   if (lo <= 0.0) input_error("Invalid pair table lower boundary");
-  if (tabstyle == BITMAP) input_error("BITMAP tables are not supported by the GPU UCG styles");
 
   match = 0;
   if (tabstyle == LINEAR && ninput == tablength && rflag == RSQ && rhi == cut) match = 1;
+  if (tabstyle == BITMAP && ninput == 1 << tablength && rflag == RBMP && rhi == cut) match = 1;
+  if (rflag == RBMP && match == 0) input_error("Bitmapped table in file does not match requested table");
   if (match == 0) spline_table();
 
   const int tlm1 = tablength - 1;
@@ -255,6 +312,65 @@ void Table::build(int tabstyle, int tablength, double cutoff)
     for (int i = 0; i < tlm1; i++) {
       de[(size_t) i] = e[(size_t) i + 1] - e[(size_t) i];
       df[(size_t) i] = f[(size_t) i + 1] - f[(size_t) i];
+    }
+  } else if (tabstyle == BITMAP) {
+    // bitmapped linear tables (:1247-1340): 2^N bins from inner to cut, spaced in bitmapped manner
+    int masklo, maskhi;
+    init_bitmap(inner, cut, tablength, masklo, maskhi, nmask, nshiftbits);
+    ntablebits = tablength;
+    const int ntable = 1 << tablength, ntablem1 = ntable - 1;
+    rsq.assign((size_t) ntable, 0.0);
+    e.assign((size_t) ntable, 0.0);
+    f.assign((size_t) ntable, 0.0);
+    de.assign((size_t) ntable, 0.0);
+    df.assign((size_t) ntable, 0.0);
+    drsq.assign((size_t) ntable, 0.0);
+    float minrsq = int_as_float((0 << nshiftbits) | maskhi);
+    for (int i = 0; i < ntable; i++) {
+      float fl = int_as_float((i << nshiftbits) | masklo);
+      if (fl < innersq) fl = int_as_float((i << nshiftbits) | maskhi);
+      const double r = sqrtf(fl);
+      rsq[(size_t) i] = fl;
+      if (match) {
+        e[(size_t) i] = efile[(size_t) i];
+        f[(size_t) i] = ffile[(size_t) i] / r;
+      } else {
+        e[(size_t) i] = cubic_splint(rf, ef, e2f, ninput, r);
+        f[(size_t) i] = cubic_splint(rf, ff, f2f, ninput, r) / r;
+      }
+      minrsq = (minrsq < fl) ? minrsq : fl;
+    }
+    innersq = minrsq;
+    for (int i = 0; i < ntablem1; i++) {
+      de[(size_t) i] = e[(size_t) i + 1] - e[(size_t) i];
+      df[(size_t) i] = f[(size_t) i + 1] - f[(size_t) i];
+      drsq[(size_t) i] = 1.0 / (rsq[(size_t) i + 1] - rsq[(size_t) i]);
+    }
+    // tables are connected periodically between 0 and ntablem1
+    de[(size_t) ntablem1] = e[0] - e[(size_t) ntablem1];
+    df[(size_t) ntablem1] = f[0] - f[(size_t) ntablem1];
+    drsq[(size_t) ntablem1] = 1.0 / (rsq[0] - rsq[(size_t) ntablem1]);
+    // the bin holding the largest r gets the deltas towards cut*cut
+    const int itablemin = (float_as_int(minrsq) & nmask) >> nshiftbits;
+    int itablemax = itablemin - 1;
+    if (itablemin == 0) itablemax = ntablem1;
+    int itablemaxm1 = itablemax - 1;
+    if (itablemax == 0) itablemaxm1 = ntablem1;
+    float fl = int_as_float((itablemax << nshiftbits) | maskhi);
+    if (fl < cut * cut) {
+      if (match) {
+        de[(size_t) itablemax] = de[(size_t) itablemaxm1];
+        df[(size_t) itablemax] = df[(size_t) itablemaxm1];
+        drsq[(size_t) itablemax] = drsq[(size_t) itablemaxm1];
+      } else {
+        fl = (float) (cut * cut);
+        const double r = sqrtf(fl);
+        const double e_tmp = cubic_splint(rf, ef, e2f, ninput, r);
+        const double f_tmp = cubic_splint(rf, ff, f2f, ninput, r) / r;
+        de[(size_t) itablemax] = e_tmp - e[(size_t) itablemax];
+        df[(size_t) itablemax] = f_tmp - f[(size_t) itablemax];
+        drsq[(size_t) itablemax] = 1.0 / (fl - rsq[(size_t) itablemax]);
+      }
     }
   } else {  // SPLINE
     rsq.assign((size_t) tablength, 0.0);
@@ -307,6 +423,14 @@ int Table::eval(int tabstyle, int tablength, double r2, double &fval, double &ev
 {
   const int tlm1 = tablength - 1;
   if (r2 < innersq) return 1;
+  if (tabstyle == BITMAP) {  // :466-476: no outer-cutoff check in this branch
+    const float fl = (float) r2;
+    const int ib = (float_as_int(fl) & nmask) >> nshiftbits;
+    const double fraction = ((double) fl - rsq[(size_t) ib]) * drsq[(size_t) ib];
+    fval = f[(size_t) ib] + fraction * df[(size_t) ib];
+    eval_ = e[(size_t) ib] + fraction * de[(size_t) ib];
+    return 0;
+  }
   const int it = static_cast<int>((r2 - innersq) * invdelta);
   if (it >= tlm1) return 2;
   if (tabstyle == LOOKUP) {

@@ -28,6 +28,9 @@ class Table {
   std::vector<double> rfile, efile, ffile, e2file, f2file;
   double innersq = 0, delta = 0, invdelta = 0, deltasq6 = 0;
   std::vector<double> rsq, e, f, de, df, e2, f2;
+  // BITMAP tables (UCG/pair_table_ucgld.cpp:1247-1340): 2^tablength bins addressed by the bits of (float) rsq
+  std::vector<double> drsq;
+  int ntablebits = 0, nmask = 0, nshiftbits = 0;
 
   void read_file(const std::string &file, const std::string &keyword);
   void build(int tabstyle, int tablength, double cutoff);
@@ -38,6 +41,10 @@ class Table {
   void param_extract(const std::string &line);
   void spline_table();
 };
+
+// upstream Pair::init_bitmap (src/pair.cpp of LAMMPS; not part of the reference tree): which bits of a float in
+// [inner^2, outer^2] index a table of 2^ntablebits bins
+void init_bitmap(double inner, double outer, int ntablebits, int &masklo, int &maskhi, int &nmask, int &nshiftbits);
 
 void cubic_spline(const double *x, const double *y, int n, double yp1, double ypn, double *y2);
 double cubic_splint(const double *xa, const double *ya, const double *y2a, int n, double x);

@@ -545,10 +545,23 @@ hipError_t launch_style_ts(const PairDev &P, const AtomsDev &A, const ListDev &L
   return hipGetLastError();
 }
 
+// BITMAP tables: generic path only (bins in HBM / L2, per-table parameters), one lane per bead
+template <int STYLE>
+hipError_t launch_style_bitmap(const PairDev &P, const AtomsDev &A, const ListDev &L, bool ev, double *evpart,
+                               int *errflag, hipStream_t st, int nblocks)
+{
+  if (P.tab_in_lds || P.fast || P.gather_slots != 1) return hipErrorInvalidValue;
+  const size_t ldsbytes = P.stage_own ? (size_t) PAIR_BLOCK * (sizeof(double4) + sizeof(int)) : 0;
+  if (ev) hipLaunchKernelGGL((k_pair_gather<STYLE, 3, true, false, false, 1>), dim3(nblocks), dim3(PAIR_BLOCK), ldsbytes, st, P, A, L, evpart, errflag);
+  else hipLaunchKernelGGL((k_pair_gather<STYLE, 3, false, false, false, 1>), dim3(nblocks), dim3(PAIR_BLOCK), ldsbytes, st, P, A, L, evpart, errflag);
+  return hipGetLastError();
+}
+
 template <int STYLE>
 hipError_t launch_style(const PairDev &P, const AtomsDev &A, const ListDev &L, bool ev, double *evpart,
                         int *errflag, hipStream_t st, int nblocks)
 {
+  if (P.tabstyle == 3) return launch_style_bitmap<STYLE>(P, A, L, ev, evpart, errflag, st, nblocks);
 #define UCG_TS(SL)                                                                                  \
   switch (P.tabstyle) {                                                                             \
     case 0: return launch_style_ts<STYLE, 0, SL>(P, A, L, ev, evpart, errflag, st, nblocks);       \

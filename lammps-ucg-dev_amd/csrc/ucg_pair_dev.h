@@ -125,6 +125,28 @@ __device__ __forceinline__ void knot_eval_fast(const double2 *rec, const int str
   }
 }
 
+// one table of the generic (per-table parameters, tables in HBM / L2) path
+template <int TS, typename TabPtr>
+__device__ __forceinline__ void table_eval(TabPtr tab, const double4 par, const int tlm1, const double rsq, int &err,
+                                           double &fval, double &eval)
+{
+  if (TS == 3) {
+    // BITMAP (UCG/pair_table_ucgld.cpp:466-476): the bin is cut out of the bits of (float) rsq; par = {innersq,
+    // nmask, nshiftbits}; records {e, de, f, df}, {rsq, drsq}.  Only the inner cutoff is checked in this branch.
+    if (rsq < par.x) err |= 1;
+    const float fl = (float) rsq;
+    const int it = (__float_as_int(fl) & (int) par.y) >> (int) par.z;
+    const double4 k = tab[2 * it];
+    const double4 g = tab[2 * it + 1];
+    const double fraction = ((double) fl - g.x) * g.y;
+    fval = k.z + fraction * k.w;
+    eval = k.x + fraction * k.y;
+  } else {
+    const int it = grid_locate(par, tlm1, rsq, err);
+    knot_eval<TS>(tab, par.w, it, grid_basis<TS>(par, it, rsq), fval, eval);
+  }
+}
+
 // own-frame quad: u[a][b] = table(F(tk,a), F(tm,b)); equals the reference's u[b][a] when the
 // row owner is the pair's "j" (tabindex is symmetric after init_one)
 template <int TS, bool FAST, typename TabPtr>
@@ -148,29 +170,15 @@ __device__ __forceinline__ void eval_quad(TabPtr tab, const double4 *s_par, cons
     }
     knot_eval_fast<TS>(rec + 2 * t11, fast_stride, par.w, B, q.f11, q.u11);
   } else {
-    {
-      const double4 par = s_par[t00];
-      const int it = grid_locate(par, tlm1, rsq, err);
-      knot_eval<TS>(tab + t00 * tablength, par.w, it, grid_basis<TS>(par, it, rsq), q.f00, q.u00);
-    }
-    {
-      const double4 par = s_par[t01];
-      const int it = grid_locate(par, tlm1, rsq, err);
-      knot_eval<TS>(tab + t01 * tablength, par.w, it, grid_basis<TS>(par, it, rsq), q.f01, q.u01);
-    }
+    table_eval<TS>(tab + t00 * tablength, s_par[t00], tlm1, rsq, err, q.f00, q.u00);
+    table_eval<TS>(tab + t01 * tablength, s_par[t01], tlm1, rsq, err, q.f01, q.u01);
     if (t10 == t01) {
       q.f10 = q.f01;
       q.u10 = q.u01;
     } else {
-      const double4 par = s_par[t10];
-      const int it = grid_locate(par, tlm1, rsq, err);
-      knot_eval<TS>(tab + t10 * tablength, par.w, it, grid_basis<TS>(par, it, rsq), q.f10, q.u10);
+      table_eval<TS>(tab + t10 * tablength, s_par[t10], tlm1, rsq, err, q.f10, q.u10);
     }
-    {
-      const double4 par = s_par[t11];
-      const int it = grid_locate(par, tlm1, rsq, err);
-      knot_eval<TS>(tab + t11 * tablength, par.w, it, grid_basis<TS>(par, it, rsq), q.f11, q.u11);
-    }
+    table_eval<TS>(tab + t11 * tablength, s_par[t11], tlm1, rsq, err, q.f11, q.u11);
     q.f00 = factor_lj * q.f00; q.u00 *= factor_lj;
     q.f01 = factor_lj * q.f01; q.u01 *= factor_lj;
     q.f10 = factor_lj * q.f10; q.u10 *= factor_lj;

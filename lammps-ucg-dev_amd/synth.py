@@ -38,6 +38,28 @@ def lj_energy_force(r: np.ndarray, eps: float, sigma: float = 1.0, extra_exp: fl
     return u, f
 
 
+def bitmap_r(n: int, rlo: float, rhi: float) -> np.ndarray:
+    """r of the n = 2^bits entries of a BITMAP table section: entry i holds the float whose index bits are i
+    (upstream LAMMPS Pair::init_bitmap + UCG/pair_table_ucgld.cpp:954-972)"""
+    bits = int(n).bit_length() - 1
+    if 1 << bits != n:
+        raise ValueError("a BITMAP section holds 2^bits entries")
+    nlowermin = int(np.floor(np.log2(rlo * rlo)))
+    nexpbits, available = 0, 2.0
+    while available < rhi * rhi / 2.0 ** nlowermin:
+        nexpbits += 1
+        available = 2.0 ** (2.0 ** nexpbits)
+    nshift = 24 - (bits - nexpbits + 1)
+    nmask = (1 << (bits + nshift)) - 1
+    as_int = lambda v: int(np.array([v], np.float32).view(np.int32)[0])  # noqa: E731
+    masklo, maskhi = as_int(rlo * rlo) & ~nmask, as_int(rhi * rhi) & ~nmask
+    i = np.arange(n, dtype=np.int64) << nshift
+    lo = (i | masklo).astype(np.int32).view(np.float32)
+    hi = (i | maskhi).astype(np.int32).view(np.float32)
+    rsq = np.where(lo.astype(np.float64) < rlo * rlo, hi, lo)
+    return np.sqrt(rsq.astype(np.float32)).astype(np.float64)
+
+
 def write_table_file(path: str, sections: dict, n: int = 2000, rlo: float = 0.6, rhi: float = 2.5,
                      rmode: str = "R") -> str:
     """Write one table file holding several keyword sections.
@@ -55,6 +77,8 @@ def write_table_file(path: str, sections: dict, n: int = 2000, rlo: float = 0.6,
                 r = rlo + (rhi - rlo) * np.arange(n) / (n - 1)
             elif rmode == "RSQ":
                 r = np.sqrt(rlo * rlo + (rhi * rhi - rlo * rlo) * np.arange(n) / (n - 1))
+            elif rmode == "BITMAP":
+                r = bitmap_r(n, rlo, rhi)
             else:
                 raise ValueError(rmode)
             u, f = lj_energy_force(r, eps, 1.0, extra)

@@ -60,7 +60,15 @@ typedef struct {
   double *rfile, *efile, *ffile, *e2file, *f2file;
   double innersq, delta, invdelta, deltasq6;
   double *rsq, *e, *f, *de, *df, *e2, *f2;
+  /* BITMAP tables (:1247-1340): 2^tablength bins addressed by the bits of (float) rsq */
+  double *drsq;
+  int ntablebits, nmask, nshiftbits;
 } orc_table;
+
+/* upstream Pair::init_bitmap (src/pair.cpp, LAMMPS stable releases; not part of the reference tree): which bits of
+ * a float in [inner^2, outer^2] index a 2^ntablebits table.  Returns 0, or 1 with a message. */
+int orc_init_bitmap(double inner, double outer, int ntablebits, int *masklo, int *maskhi, int *nmask,
+                    int *nshiftbits, char *err, int errlen);
 
 void orc_spline(const double *x, const double *y, int n, double yp1, double ypn, double *y2);
 double orc_splint(const double *xa, const double *ya, const double *y2a, int n, double x);

@@ -28,6 +28,16 @@ const double *orc_pair_table_array(const orc_pair *p, int m, const char *name, i
   const int tl = p->tablength, tlm1 = tl - 1;
   const int lookup = (p->tabstyle == ORC_LOOKUP);
   *n = 0;
+  if (p->tabstyle == ORC_BITMAP) { /* every array of a bitmapped table is 2^tablength long */
+    const int nt = 1 << tl;
+    const double *v = !strcmp(name, "rsq") ? tb->rsq : !strcmp(name, "e") ? tb->e : !strcmp(name, "f") ? tb->f :
+                      !strcmp(name, "de") ? tb->de : !strcmp(name, "df") ? tb->df : !strcmp(name, "drsq") ? tb->drsq : NULL;
+    if (v) { *n = nt; return v; }
+    if (!strcmp(name, "bits")) { /* nmask, nshiftbits as doubles */
+      static double bits[2];
+      bits[0] = tb->nmask; bits[1] = tb->nshiftbits; *n = 2; return bits;
+    }
+  }
   if (!strcmp(name, "rfile")) { *n = tb->ninput; return tb->rfile; }
   if (!strcmp(name, "efile")) { *n = tb->ninput; return tb->efile; }
   if (!strcmp(name, "ffile")) { *n = tb->ninput; return tb->ffile; }

@@ -6,7 +6,7 @@
  *   spline_table   :1047-1065  compute_table :1105-1344
  *   spline         :1375-1404  splint        :1408-1428
  * and the per-pair interpolation block :436-482 (canonical copy single() :1474-1520).
- * BITMAP tables need upstream Pair::init_bitmap (absent) and are rejected.
+ * BITMAP tables use upstream Pair::init_bitmap (absent from the reference tree), restated in orc_init_bitmap.
  * The file reader restates upstream TableFileReader (absent): comment ('#') and
  * blank lines are skipped while searching for the keyword line; the line after
  * it is the parameter line; ONE raw line is skipped; N data lines follow.
@@ -87,7 +87,7 @@ static void null_table(orc_table *tb)
 void orc_table_free(orc_table *tb)
 {
   free(tb->rfile); free(tb->efile); free(tb->ffile); free(tb->e2file); free(tb->f2file);
-  free(tb->rsq); free(tb->e); free(tb->f); free(tb->de); free(tb->df); free(tb->e2); free(tb->f2);
+  free(tb->rsq); free(tb->e); free(tb->f); free(tb->de); free(tb->df); free(tb->e2); free(tb->f2); free(tb->drsq);
   null_table(tb);
 }
 
@@ -102,6 +102,53 @@ static void strip_comment(char *line)
 {
   char *h = strchr(line, '#');
   if (h) *h = '\0';
+}
+
+static float int_as_float(int i)
+{
+  float f;
+  memcpy(&f, &i, sizeof f);
+  return f;
+}
+
+static int float_as_int(float f)
+{
+  int i;
+  memcpy(&i, &f, sizeof i);
+  return i;
+}
+
+/* Pair::init_bitmap of upstream LAMMPS (src/pair.cpp): the table index is made of the low `nexpbits` exponent bits
+ * and the top `nmantbits` mantissa bits of the float; masklo / maskhi are the remaining high bits of inner^2 /
+ * outer^2 */
+int orc_init_bitmap(double inner, double outer, int ntablebits, int *masklo, int *maskhi, int *nmask,
+                    int *nshiftbits, char *err, int errlen)
+{
+  if (ntablebits > (int) sizeof(float) * 8) { set_err(err, errlen, "Too many total bits for bitmapped lookup table"); return 1; }
+  int nlowermin = 1;
+  while (!((pow(2.0, (double) nlowermin) <= inner * inner) && (pow(2.0, (double) nlowermin + 1.0) > inner * inner))) {
+    if (pow(2.0, (double) nlowermin) <= inner * inner) nlowermin++;
+    else nlowermin--;
+  }
+  int nexpbits = 0;
+  double required_range = outer * outer / pow(2.0, (double) nlowermin);
+  double available_range = 2.0;
+  while (available_range < required_range) {
+    nexpbits++;
+    available_range = pow(2.0, pow(2.0, (double) nexpbits));
+  }
+  int nmantbits = ntablebits - nexpbits;
+  if (nexpbits > (int) sizeof(float) * 8 - 24) { set_err(err, errlen, "Too many exponent bits for lookup table"); return 1; }
+  if (nmantbits + 1 > 24) { set_err(err, errlen, "Too many mantissa bits for lookup table"); return 1; }
+  if (nmantbits < 3) { set_err(err, errlen, "Too few bits for lookup table"); return 1; }
+  *nshiftbits = 24 - (nmantbits + 1);
+  int m = 1;
+  for (int j = 0; j < ntablebits + *nshiftbits; j++) m *= 2;
+  m -= 1;
+  *nmask = m;
+  *maskhi = float_as_int((float) (outer * outer)) & ~m;
+  *masklo = float_as_int((float) (inner * inner)) & ~m;
+  return 0;
 }
 
 /* param_extract :1067-1102 */
@@ -184,10 +231,20 @@ int orc_table_read(orc_table *tb, const char *file, const char *keyword, char *e
   }
   if (!got) { set_err(err, errlen, "Missing pair table parameter line"); fclose(fp); return 1; }
   if (param_extract(tb, line, err, errlen)) { fclose(fp); return 1; }
+  /* setup bitmap parameters for table to read in :918-927 */
+  int masklo = 0, maskhi = 0, nmask = 0, nshiftbits = 0;
+  tb->ntablebits = 0;
   if (tb->rflag == ORC_BMP) {
-    set_err(err, errlen, "BITMAP tables are not supported (need upstream init_bitmap)");
-    fclose(fp);
-    return 1;
+    while (1 << tb->ntablebits < tb->ninput) tb->ntablebits++;
+    if (1 << tb->ntablebits != tb->ninput) {
+      set_err(err, errlen, "Bitmapped table is incorrect length in table file");
+      fclose(fp);
+      return 1;
+    }
+    if (orc_init_bitmap(tb->rlo, tb->rhi, tb->ntablebits, &masklo, &maskhi, &nmask, &nshiftbits, err, errlen)) {
+      fclose(fp);
+      return 1;
+    }
   }
   tb->rfile = (double *) malloc(sizeof(double) * (size_t) tb->ninput);
   tb->efile = (double *) malloc(sizeof(double) * (size_t) tb->ninput);
@@ -232,6 +289,10 @@ int orc_table_read(orc_table *tb, const char *file, const char *keyword, char *e
     else if (tb->rflag == ORC_RSQ) {
       rnew = tb->rlo * tb->rlo + (tb->rhi * tb->rhi - tb->rlo * tb->rlo) * i / (tb->ninput - 1);
       rnew = sqrt(rnew);
+    } else if (tb->rflag == ORC_BMP) {
+      float fl = int_as_float((i << nshiftbits) | masklo);
+      if (fl < tb->rlo * tb->rlo) fl = int_as_float((i << nshiftbits) | maskhi);
+      rnew = sqrtf(fl);
     }
     tb->rfile[i] = rnew;
   }
@@ -306,11 +367,16 @@ int orc_table_build(orc_table *tb, int tabstyle, int tablength, double cut, char
   }
   if (tb->cut <= rlo || tb->cut > rhi) { set_err(err, errlen, "Pair table cutoff outside of table"); return 1; }
   if (rlo <= 0.0) { set_err(err, errlen, "Invalid pair table lower boundary"); return 1; }
-  if (tabstyle == ORC_BITMAP) { set_err(err, errlen, "BITMAP tables are not supported"); return 1; }
 
   tb->match = 0;
   if (tabstyle == ORC_LINEAR && tb->ninput == tablength && tb->rflag == ORC_RSQ && tb->rhi == tb->cut)
     tb->match = 1;
+  if (tabstyle == ORC_BITMAP && tb->ninput == 1 << tablength && tb->rflag == ORC_BMP && tb->rhi == tb->cut)
+    tb->match = 1;
+  if (tb->rflag == ORC_BMP && tb->match == 0) {
+    set_err(err, errlen, "Bitmapped table in file does not match requested table");
+    return 1;
+  }
 
   if (tb->match == 0) spline_table(tb);
 
@@ -413,6 +479,73 @@ int orc_table_build(orc_table *tb, int tabstyle, int tablength, double cut, char
     for (int i = 0; i < tablength; i++) tb->f[i] /= sqrt(tb->rsq[i]);
     orc_spline(tb->rsq, tb->f, tablength, fp0, fpn, tb->f2);
   }
+
+  /* bitmapped linear tables :1247-1340: 2^N bins from inner to cut, spaced in bitmapped manner */
+  if (tabstyle == ORC_BITMAP) {
+    int masklo, maskhi;
+    if (orc_init_bitmap(inner, tb->cut, tablength, &masklo, &maskhi, &tb->nmask, &tb->nshiftbits, err, errlen)) return 1;
+    const int ntable = 1 << tablength;
+    const int ntablem1 = ntable - 1;
+    tb->ntablebits = tablength;
+    tb->rsq = (double *) malloc(sizeof(double) * (size_t) ntable);
+    tb->e = (double *) malloc(sizeof(double) * (size_t) ntable);
+    tb->f = (double *) malloc(sizeof(double) * (size_t) ntable);
+    tb->de = (double *) malloc(sizeof(double) * (size_t) ntable);
+    tb->df = (double *) malloc(sizeof(double) * (size_t) ntable);
+    tb->drsq = (double *) malloc(sizeof(double) * (size_t) ntable);
+
+    float minrsq = int_as_float((0 << tb->nshiftbits) | maskhi);
+    float fl;
+    double r;
+    for (int i = 0; i < ntable; i++) {
+      fl = int_as_float((i << tb->nshiftbits) | masklo);
+      if (fl < tb->innersq) fl = int_as_float((i << tb->nshiftbits) | maskhi);
+      r = sqrtf(fl);
+      tb->rsq[i] = fl;
+      if (tb->match) {
+        tb->e[i] = tb->efile[i];
+        tb->f[i] = tb->ffile[i] / r;
+      } else {
+        tb->e[i] = orc_splint(tb->rfile, tb->efile, tb->e2file, tb->ninput, r);
+        tb->f[i] = orc_splint(tb->rfile, tb->ffile, tb->f2file, tb->ninput, r) / r;
+      }
+      minrsq = (minrsq < fl) ? minrsq : fl; /* MIN(minrsq_lookup.f, rsq_lookup.f) */
+    }
+    tb->innersq = minrsq;
+
+    for (int i = 0; i < ntablem1; i++) {
+      tb->de[i] = tb->e[i + 1] - tb->e[i];
+      tb->df[i] = tb->f[i + 1] - tb->f[i];
+      tb->drsq[i] = 1.0 / (tb->rsq[i + 1] - tb->rsq[i]);
+    }
+    /* tables are connected periodically between 0 and ntablem1 */
+    tb->de[ntablem1] = tb->e[0] - tb->e[ntablem1];
+    tb->df[ntablem1] = tb->f[0] - tb->f[ntablem1];
+    tb->drsq[ntablem1] = 1.0 / (tb->rsq[0] - tb->rsq[ntablem1]);
+
+    /* the bin holding the largest r gets the deltas towards cut*cut */
+    int itablemin = (float_as_int(minrsq) & tb->nmask) >> tb->nshiftbits;
+    int itablemax = itablemin - 1;
+    if (itablemin == 0) itablemax = ntablem1;
+    int itablemaxm1 = itablemax - 1;
+    if (itablemax == 0) itablemaxm1 = ntablem1;
+    fl = int_as_float((itablemax << tb->nshiftbits) | maskhi);
+    if (fl < tb->cut * tb->cut) {
+      if (tb->match) {
+        tb->de[itablemax] = tb->de[itablemaxm1];
+        tb->df[itablemax] = tb->df[itablemaxm1];
+        tb->drsq[itablemax] = tb->drsq[itablemaxm1];
+      } else {
+        fl = (float) (tb->cut * tb->cut);
+        r = sqrtf(fl);
+        double e_tmp = orc_splint(tb->rfile, tb->efile, tb->e2file, tb->ninput, r);
+        double f_tmp = orc_splint(tb->rfile, tb->ffile, tb->f2file, tb->ninput, r) / r;
+        tb->de[itablemax] = e_tmp - tb->e[itablemax];
+        tb->df[itablemax] = f_tmp - tb->f[itablemax];
+        tb->drsq[itablemax] = 1.0 / (fl - tb->rsq[itablemax]);
+      }
+    }
+  }
   return 0;
 }
 
@@ -425,6 +558,15 @@ int orc_table_eval(const orc_table *tb, int tabstyle, int tablength, double rsq,
   int itable;
   double fraction, value, a, b, evdwl;
   if (rsq < tb->innersq) return 1;
+  if (tabstyle == ORC_BITMAP) {
+    /* :466-476: the index is cut out of the bits of (float) rsq; no outer-cutoff check in this branch */
+    float fl = (float) rsq;
+    itable = (float_as_int(fl) & tb->nmask) >> tb->nshiftbits;
+    fraction = ((double) fl - tb->rsq[itable]) * tb->drsq[itable];
+    *fval = tb->f[itable] + fraction * tb->df[itable];
+    *eval = tb->e[itable] + fraction * tb->de[itable];
+    return 0;
+  }
   itable = (int) ((rsq - tb->innersq) * tb->invdelta);
   if (itable >= tlm1) return 2;
   if (tabstyle == ORC_LOOKUP) {

@@ -71,13 +71,20 @@ CASES = [
     ("table_ucgld", (), (6.0, 6.0, 0.2, 48279), "ld", 0.004, 120, 1, "wall"),
     ("table_ucgld", (), (6.0, 6.0, 0.2, 1234), "ld", 0.004, 100, 2, ("wall", 0.25)),
     ("table_ucgld", (), None, None, 0.004, 60, 1, ("wall", 0.1)),
+    # tabstyle bitmap (the "tab" keyword below is consumed by the test, not by the pair style)
+    ("table_ucgld", ("tab", "bitmap", 12), (1.0, 1.0, 1.0, 48279), "ld", 0.004, 80, 1, True),
+    ("table_ucg_bethe", ("tab", "bitmap", 11), None, ("mc", 9127, 0.2), 0.004, 60, 2, True),
+    ("table_ucg_bethe_density", ("tab", "bitmap", 12), None, ("mc", 4242, 0.3), 0.002, 40, 1, True),
 ]
 
 
 @pytest.mark.parametrize("style,extra,langevin,ucgstate,dt,steps,every,integrator", CASES)
 def test_md_trajectory_bitwise(fresh_ctx, pkg, orc, style, extra, langevin, ucgstate, dt, steps, every, integrator):
     dens = dict(density=(11.3, 1.5), extra11=0.05) if style.endswith("density") else {}
-    deck = util.make_deck("spline", 1024, extra_keywords=extra, **dens)
+    tabstyle, tablength = "spline", 1024
+    if extra[:1] == ("tab",):
+        tabstyle, tablength, extra = extra[1], extra[2], extra[3:]
+    deck = util.make_deck(tabstyle, tablength, extra_keywords=extra, **dens)
     wall = integrator is not True
     beads = pkg.synth.make_beads(8, seed=31, ucgml=0.5 if wall else 10.0)
     op = util.oracle_pair(style, deck)

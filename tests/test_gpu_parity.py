@@ -38,7 +38,8 @@ def test_ranmars_published_check_values(gpu_ctx):
     assert [int(v * 16777216.0) for v in got] == [6533892, 14220222, 7275067, 6172232, 8354498, 10633180]
 
 
-@pytest.mark.parametrize("tabstyle,tablength", [("spline", 1024), ("linear", 4096), ("lookup", 2000), ("spline", 8000)])
+@pytest.mark.parametrize("tabstyle,tablength", [("spline", 1024), ("linear", 4096), ("lookup", 2000), ("spline", 8000),
+                                                ("bitmap", 12), ("bitmap", 8)])
 @pytest.mark.parametrize("ncell", [6, 12])
 def test_pair_ucgld_parity(gpu_ctx, pkg, orc, tabstyle, tablength, ncell):
     deck = util.make_deck(tabstyle, tablength)
@@ -222,7 +223,8 @@ def test_exact_division_by_constant(gpu_ctx, kT):
 
 
 @pytest.mark.parametrize("style", ["table_ucgld", "table_ucg_bethe"])
-@pytest.mark.parametrize("tabstyle,tablength,T", [("spline", 1024, 0.7), ("linear", 2048, 1.3), ("lookup", 3000, 1.0), ("spline", 512, 0.25)])
+@pytest.mark.parametrize("tabstyle,tablength,T", [("spline", 1024, 0.7), ("linear", 2048, 1.3), ("lookup", 3000, 1.0), ("spline", 512, 0.25),
+                                                  ("bitmap", 10, 0.7)])
 def test_fast_and_generic_kernels_give_the_same_bits(fresh_ctx, pkg, orc, style, tabstyle, tablength, T):
     ctx = fresh_ctx
     deck = util.make_deck(tabstyle, tablength)
@@ -294,7 +296,7 @@ def test_generic_path_nonuniform_grids_and_special_lj(fresh_ctx, pkg, orc):
 DENS = dict(density=(11.3, 1.5), extra11=0.05)
 
 
-@pytest.mark.parametrize("tabstyle,tablength", [("spline", 1024), ("linear", 3000)])
+@pytest.mark.parametrize("tabstyle,tablength", [("spline", 1024), ("linear", 3000), ("bitmap", 11)])
 @pytest.mark.parametrize("entropy", [False, True])
 @pytest.mark.parametrize("as_shipped", [0, 1])
 def test_pair_bethe_density_parity(fresh_ctx, pkg, orc, tabstyle, tablength, entropy, as_shipped):

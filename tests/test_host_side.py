@@ -31,7 +31,8 @@ def test_no_gpu_means_loud_failure_not_fallback(pkg):
 
 
 @pytest.mark.parametrize("style", ["table_ucgld", "table_ucg_bethe"])
-@pytest.mark.parametrize("tabstyle,tablength", [("spline", 1024), ("linear", 4096), ("lookup", 777), ("spline", 33)])
+@pytest.mark.parametrize("tabstyle,tablength", [("spline", 1024), ("linear", 4096), ("lookup", 777), ("spline", 33),
+                                                ("bitmap", 12), ("bitmap", 9)])
 def test_host_tables_bit_identical_to_oracle(pkg, orc, style, tabstyle, tablength):
     deck = util.make_deck(tabstyle, tablength)
     o = util.oracle_pair(style, deck)
@@ -43,7 +44,7 @@ def test_host_tables_bit_identical_to_oracle(pkg, orc, style, tabstyle, tablengt
     for m in range(4):
         ti, tp = o.table_info(m), p.table_params(m)
         assert all(ti[k] == tp[k] for k in tp)
-        for w in ("rsq", "e", "f", "de", "df", "e2", "f2", "e2file", "f2file", "rfile", "efile", "ffile"):
+        for w in ("rsq", "e", "f", "de", "df", "e2", "f2", "drsq", "e2file", "f2file", "rfile", "efile", "ffile"):
             a, b = o.table_array(m, w), p.table_array(m, w)
             if a is None or len(a) == 0:
                 assert b is None or len(b) == 0
@@ -65,6 +66,52 @@ def test_rsq_and_match_tables(pkg, orc):
     for w in ("e", "f", "de", "df"):
         assert util.bits_equal(o.table_array(0, w), p.table_array(0, w))
     assert util.bits_equal(p.table_array(0, "e"), p.table_array(0, "efile"))
+
+
+def test_bitmap_tables(pkg, orc):
+    """tabstyle bitmap: 2^N bins addressed by the bits of (float) r^2 (UCG/pair_table_ucgld.cpp:1247-1340 with upstream
+    Pair::init_bitmap restated).  Properties any correct restatement has: every r^2 in [inner^2, cut^2] lands in a bin
+    whose lower edge is below it and whose fraction is in [0, 1); interpolation reproduces the tabulated function; a
+    BITMAP section of the file (2^N entries in bit order) is used verbatim ("match")."""
+    deck = util.make_deck("bitmap", 12)
+    o = util.oracle_pair("table_ucgld", deck)
+    p = pkg.capi.Pair(None, "table_ucgld")
+    p.settings(deck.pair_style_args())
+    p.coeff(deck.pair_coeff_args())
+    p.init(2, 1.0)
+    rsqt, drsq = p.table_array(0, "rsq"), p.table_array(0, "drsq")
+    assert len(rsqt) == 4096 and p.table_params(0)["innersq"] == rsqt.min() and 0.36 <= rsqt.min() < 0.3605
+    nmask, nshift = [int(v) for v in o.table_array(0, "bits")]
+    rng = np.random.default_rng(5)
+    r = rng.uniform(np.sqrt(rsqt.min()) + 1e-6, 2.5, 20000)
+    r32 = (r * r).astype(np.float32)
+    idx = (r32.view(np.int32) & nmask) >> nshift
+    frac = (r32.astype(np.float64) - rsqt[idx]) * drsq[idx]
+    assert frac.min() >= 0.0 and frac.max() < 1.0
+    ref = pkg.synth.lj_energy_force(np.sqrt(r32.astype(np.float64)), 1.0, 1.0, 0.0)
+    for k in range(0, 20000, 97):
+        e, f = p.single(1, 1, float(r[k] * r[k]), 1.0)
+        assert abs(e - ref[0][k]) <= 2e-4 * (abs(ref[0][k]) + 1.0)
+    # below the smallest tabulated r^2: the reference's error
+    with pytest.raises(pkg.capi.UcgError, match="inner"):
+        p.single(1, 1, 0.3, 1.0)
+    # a BITMAP section in the file
+    deck2 = util.make_deck("bitmap", 10, n_file=1024, rmode="BITMAP")
+    o2 = util.oracle_pair("table_ucgld", deck2)
+    p2 = pkg.capi.Pair(None, "table_ucgld")
+    p2.settings(deck2.pair_style_args())
+    p2.coeff(deck2.pair_coeff_args())
+    p2.init(2, 1.0)
+    assert o2.table_info(0)["match"] == 1
+    for w in ("rsq", "e", "f", "de", "df", "drsq", "rfile"):
+        assert util.bits_equal(o2.table_array(0, w), p2.table_array(0, w)), w
+    assert util.bits_equal(p2.table_array(0, "e"), p2.table_array(0, "efile"))
+    # and the mismatch the reference rejects: bitmapped file, other table length
+    deck3 = util.make_deck("bitmap", 11, n_file=1024, rmode="BITMAP")
+    p3 = pkg.capi.Pair(None, "table_ucgld")
+    p3.settings(deck3.pair_style_args())
+    with pytest.raises(pkg.capi.UcgError, match="Bitmapped table in file does not match"):
+        p3.coeff(deck3.pair_coeff_args())
 
 
 def test_single_matches_table_eval(pkg, orc):

@@ -207,8 +207,9 @@ def test_restart_round_trip(pkg, tmp_path):
 
 @pytest.mark.gpu
 def test_resident_loop_dump_restart_and_resume(fresh_ctx, pkg, tmp_path):
-    """run 20 steps; dump + restart at step 10 of a second run; a third run started from the restart file reproduces
-    the pair forces of the dumped state bit for bit and the dump read back through read_dump equals the device state"""
+    """run 10 steps, dump and write a restart; the dump read back through read_dump equals the device state bit for
+    bit, and a fresh system started from the restart file has the same forces at that configuration (to rounding: its
+    neighbour rows are ordered by the new positions)"""
     beads = pkg.synth.make_beads(12, seed=77)
     deck = util.make_deck("spline", 1024)
     ctx = fresh_ctx
@@ -254,7 +255,9 @@ def test_resident_loop_dump_restart_and_resume(fresh_ctx, pkg, tmp_path):
         gp2.check_errors()
         a2 = ctx2.atoms_download()
         o2, o1 = np.argsort(a2["tag"][:beads.n]), by_id
-        assert util.bits_equal(a2["f"][o2], at["f"][o1])
-        assert util.bits_equal(a2["ucgforce"][o2], at["ucgforce"][o1])
+        # same configuration, but this list is built AT the dumped positions while the first run's list dates from its
+        # last re-neighbouring: the rows hold the same pairs in another order, so the sums agree to rounding only
+        assert np.abs(a2["f"][o2] - at["f"][o1]).max() <= 1e-11 * np.abs(at["f"]).max()
+        assert np.abs(a2["ucgforce"][o2] - at["ucgforce"][o1]).max() <= 1e-11 * np.abs(at["ucgforce"]).max()
     finally:
         ctx2.close()
