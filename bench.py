@@ -89,8 +89,8 @@ def cpu_baseline_threads(pkg, deck, ncell, nsteps, dt, nthreads, integrator="wal
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=1000, help="timed steps (SURVEY.md 8d: >= 1000, re-neighbouring included)")
+    ap.add_argument("--warmup", type=int, default=200, help="untimed steps first (SURVEY.md 8d: 200 warm-up steps on the path itself)")
     ap.add_argument("--ncell", type=int, default=100, help="beads = ncell^3 (default 100 -> 1 M)")
     ap.add_argument("--tabstyle", default="spline")
     ap.add_argument("--tablength", type=int, default=1024)
@@ -280,6 +280,7 @@ def main():
             "pair_loop_only": {"algorithmic_bytes_per_launch": 44.0 * e_half + 96.0 * n_launch,
                                "note": "44 E + 96 N over the same launch time (which includes the fused hooks)",
                                "frac": (44.0 * e_half + 96.0 * n_launch) / pair_avg_s / 1e9 / HBM_PEAK_GBS if pair_avg_s > 0 else 0.0},
+            "compulsory_bytes_per_launch": 4.0 * e_half + 96.0 * n_launch,  # B_min = 4 E + 96 N
             "avg_launch_us": pair_avg_s * 1e6,
             "launches": int(result["pair_launches"]),
         },
@@ -320,6 +321,8 @@ def main():
             }
         else:
             out["cpu_baseline"] = one
+        cbl = out["cpu_baseline"]
+        cbl["gpu_over_cpu"] = {"vs_1_core": out["value"] / one["value"], f"vs_{cbl['cores']}_cores": out["value"] / cbl["value"]}
     emit(json.dumps(out))
     if dist is not None:
         dist.barrier()
