@@ -98,6 +98,8 @@ def main():
                     choices=["table_ucgld", "table_ucg_bethe", "table_ucg_bethe_density"],
                     help="pair style of the 1-GPU leg (default: the headline table_ucgld workload; the others are "
                          "BASELINE.md configs 3 and 5 at 1 M beads, reported with their own algorithmic bytes)")
+    ap.add_argument("--lattice", default="sc", choices=["sc", "fcc"],
+                    help="sc: ncell^3 beads (default); fcc: 4 ncell^3 beads (BASELINE.json's 4 M-bead configuration = --ncell 100 --lattice fcc)")
     ap.add_argument("--integrator", default="wall", choices=["wall", "nve"],
                     help="wall = fix nve/ucgld/wall/hard (default), nve = fix nve/ucgld.  The latter never clamps lambda "
                          "(UCG/fix_nve_ucgld.cpp:44-153): with the linear-in-lambda mixing nothing confines it, and after "
@@ -162,7 +164,7 @@ def main():
 
         result = multi.run_bench(args, deck, rank, world, local_rank, dist)
     else:
-        beads = synth.make_beads(args.ncell, seed=12345)
+        beads = synth.make_beads(args.ncell, seed=12345, lattice=args.lattice)
         ctx = capi.Context(local_rank, dt=dt)
         if os.environ.get("UCG_GATHER_SLOTS"):
             ctx.set_option("gather_slots", int(os.environ["UCG_GATHER_SLOTS"]))
@@ -234,7 +236,7 @@ def main():
     pair_avg_s = (result["pair_ms"] / max(result["pair_launches"], 1)) * 1e-3
     achieved = alg_bytes / pair_avg_s / 1e9 if pair_avg_s > 0 else 0.0
     out = {
-        "metric": "timesteps/sec at 1M UCG beads (" + {
+        "metric": "timesteps/sec at " + ("1M" if n == 1000000 else str(n)) + " UCG beads (" + {
             "table_ucgld": "table_ucgld + INTEG + ucgld/langevin + ucgstate ld",
             "table_ucg_bethe": "table_ucg_bethe method bethe pseudo yes prior ucgl + INTEG + ucgstate",
             "table_ucg_bethe_density": "table_ucg_bethe_density + INTEG + ucgstate mc 9127 0.01"}[args.style].replace(
@@ -252,7 +254,7 @@ def main():
         "data": "synthetic",
         "atom_steps_per_s": steps_per_s * n,
         "config": {
-            "workload": f"{n} beads (sc lattice {args.ncell}^3 + jitter), rho*=0.8, rc=2.5, skin=0.3, dt=0.002, "
+            "workload": f"{n} beads ({args.lattice} lattice {args.ncell}^3 + jitter), rho*=0.8, rc=2.5, skin=0.3, dt=0.002, "
                         f"pair_style {args.style} {args.tabstyle} {args.tablength} (2-state, 4 LJ-like tables) + " + {
                             "table_ucgld": "fix INTEG + fix ucgld/langevin 1.0 1.0 1.0 48279 + fix ucgstate ld; ",
                             "table_ucg_bethe": "method bethe pseudo yes prior ucgl + fix INTEG + fix ucgstate; ",
@@ -288,7 +290,7 @@ def main():
     # HBM traffic of the pair kernel: measured in separate rocprofv3 --pmc passes of this same
     # command (tools/profile_pmc.sh) and committed under profiles/; valid for the default workload
     tfile = os.path.join(ROOT, "profiles", "r01_pair_traffic.json")
-    if (world == 1 and args.style == "table_ucgld" and args.ncell == 100 and args.tabstyle == "spline"
+    if (world == 1 and args.style == "table_ucgld" and args.ncell == 100 and args.lattice == "sc" and args.tabstyle == "spline"
             and args.tablength == 1024 and os.path.exists(tfile)):
         with open(tfile) as fh:
             out["roofline"]["traffic"] = json.load(fh)["traffic_bytes_per_launch"]

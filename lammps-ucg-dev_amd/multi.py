@@ -356,7 +356,7 @@ def run_bench(args, deck, rank, world, local_rank, dist):
 
     dt = 0.002
     device = torch.device("cuda", local_rank)
-    beads = synth.make_beads(args.ncell, seed=12345)
+    beads = synth.make_beads(args.ncell, seed=12345, lattice=getattr(args, "lattice", "sc"))
     grid = choose_procgrid(world)
     # any initial split works: the first exchange sends every bead to its owner
     sl = slice(rank * beads.n // world, (rank + 1) * beads.n // world)
