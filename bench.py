@@ -166,8 +166,8 @@ def main():
     else:
         beads = synth.make_beads(args.ncell, seed=12345, lattice=args.lattice)
         ctx = capi.Context(local_rank, dt=dt)
-        if os.environ.get("UCG_GATHER_SLOTS"):
-            ctx.set_option("gather_slots", int(os.environ["UCG_GATHER_SLOTS"]))
+        # lanes per bead: 0 = chosen from the bead count (1 at 1 M beads; more for boxes too small to fill 256 CUs)
+        ctx.set_option("gather_slots", int(os.environ.get("UCG_GATHER_SLOTS", "0")))
         if os.environ.get("UCG_FMA_CONTRACT"):  # NOT the bit-exact path: see DESIGN.md 4.1; never the default
             ctx.set_option("fma_contract", int(os.environ["UCG_FMA_CONTRACT"]))
         if os.environ.get("UCG_POST_IN_PAIR"):
