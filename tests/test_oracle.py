@@ -61,6 +61,47 @@ def test_math_kernels_within_one_ulp_of_libm(orc):
     assert worst["tanh"] <= 4  # fdlibm's tanh (via expm1) is a few ulp, like glibc's
 
 
+def test_ranpark_published_check_value(orc, pkg):
+    """Park & Miller, CACM 31 (1988) 1192: the minimal standard generator started from 1 holds 1043618065 after 10000
+    steps.  RanPark (upstream random_park.cpp, used by fix cluster_switch) is that generator."""
+    L = orc.lib()
+    L.orc_ranpark_init.argtypes = [C.POINTER(C.c_int), C.c_int]
+    L.orc_ranpark_uniform.argtypes = [C.POINTER(C.c_int)]
+    L.orc_ranpark_uniform.restype = C.c_double
+    st = C.c_int(0)
+    L.orc_ranpark_init(C.byref(st), 1)
+    u = 0.0
+    for _ in range(10000):
+        u = L.orc_ranpark_uniform(C.byref(st))
+    assert st.value == 1043618065 and u == 1043618065 / 2147483647.0
+
+
+def test_spline_agrees_with_an_independent_clamped_cubic_spline(orc):
+    """spline()/splint() of the table builder (UCG/pair_table_ucgld.cpp:1380-1428, the Numerical Recipes routines)
+    against scipy's CubicSpline with the same clamped end slopes: another implementation of the same interpolant"""
+    from scipy.interpolate import CubicSpline
+    L = orc.lib()
+    dp = C.POINTER(C.c_double)
+    L.orc_spline.argtypes = [dp, dp, C.c_int, C.c_double, C.c_double, dp]
+    L.orc_splint.argtypes = [dp, dp, dp, C.c_int, C.c_double]
+    L.orc_splint.restype = C.c_double
+    rng = np.random.default_rng(11)
+    for n in (5, 40, 2000):
+        x = np.sort(rng.uniform(0.6, 2.5, n))
+        x[0], x[-1] = 0.6, 2.5
+        y = 4.0 * (x ** -12 - x ** -6) + rng.normal(scale=1e-3, size=n)
+        yp1, ypn = -50.0 * rng.random(), 0.1 * rng.random()
+        y2 = np.zeros(n)
+        L.orc_spline(x.ctypes.data_as(dp), y.ctypes.data_as(dp), n, yp1, ypn, y2.ctypes.data_as(dp))
+        ref = CubicSpline(x, y, bc_type=((1, yp1), (1, ypn)))
+        xs = rng.uniform(0.6, 2.5, 500)
+        got = np.array([L.orc_splint(x.ctypes.data_as(dp), y.ctypes.data_as(dp), y2.ctypes.data_as(dp), n, float(v)) for v in xs])
+        want = ref(xs)
+        assert np.max(np.abs(got - want)) <= 1e-9 * max(1.0, np.max(np.abs(y)))
+        # the second derivatives at the knots are the interpolant's
+        assert np.max(np.abs(y2 - ref(x, 2))) <= 1e-6 * max(1.0, np.max(np.abs(y2)))
+
+
 def test_spline_reproduces_a_cubic_exactly(orc):
     # a clamped cubic spline through samples of a cubic IS that cubic
     L = orc.lib()
