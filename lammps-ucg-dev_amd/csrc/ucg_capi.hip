@@ -1017,6 +1017,41 @@ static void rng_draw(ucg_ctx *ctx, RanMarsDev &R, DevBuf<unsigned int> &draws, i
   UCG_HIP(launch_ranmars(R, n, draws.get(), ctx->stream));
 }
 
+// The next n draws of a per-bead stream (one per owned bead, in local order).  The generator is sequential, so the
+// draws of the following steps are known in advance: one launch produces rng_batch steps' worth and the steps take
+// their slices.  When the bead count changes before the window is used up (migration in a decomposed run), the stream
+// is taken back to the window's start and advanced by what was actually consumed -- the values every step sees are
+// those of one launch per step.
+static const unsigned int *rng_next(ucg_ctx *ctx, RanMarsDev &R, DevBuf<unsigned int> &draws, RngBatch &B, int n)
+{
+  if (n <= 0) return draws.get();
+  if (B.unit == n && B.total - B.used >= n) {
+    const unsigned int *p = draws.get() + B.used;
+    B.used += n;
+    return p;
+  }
+  if (B.used < B.total) {
+    UCG_HIP(hipMemcpyAsync(R.hist[R.cur], B.hist_save.get(), 97 * sizeof(unsigned int), hipMemcpyDeviceToDevice, ctx->stream));
+    R.count = B.count0;
+    long long left = B.used;
+    while (left > 0) {  // replay the consumed part (into the window itself: it is regenerated below)
+      const int piece = (int) std::min<long long>(left, B.total);
+      rng_draw(ctx, R, draws, piece);
+      left -= piece;
+    }
+  }
+  const long long k = std::max(1, ctx->rng_batch);
+  const long long want = std::min<long long>(k * n, 1ll << 30);
+  B.hist_save.reserve(128);
+  UCG_HIP(hipMemcpyAsync(B.hist_save.get(), R.hist[R.cur], 97 * sizeof(unsigned int), hipMemcpyDeviceToDevice, ctx->stream));
+  B.count0 = R.count;
+  rng_draw(ctx, R, draws, (int) want);
+  B.total = want;
+  B.used = n;
+  B.unit = n;
+  return draws.get();
+}
+
 int ucg_fix_langevin_create(ucg_ctx *ctx, double t_start, double t_stop, double t_period, int seed, int me)
 {
   if (!ctx) return UCG_ERR_INVALID;
@@ -1033,6 +1068,8 @@ int ucg_fix_langevin_create(ucg_ctx *ctx, double t_start, double t_stop, double 
     L.seed = seed;
     L.inited = false;
     rng_setup(ctx, L.rng, L.hist0, L.hist1, seed + me);
+    L.batch.total = L.batch.used = 0;
+    L.batch.unit = 0;
     return UCG_OK;
   });
 }
@@ -1081,12 +1118,11 @@ int ucg_fix_langevin_post_force(ucg_ctx *ctx, int groupbit, long long ntimestep,
     if (delta != 0.0) delta /= (double) (endstep - beginstep);
     L.t_target = L.t_start + delta * (L.t_stop - L.t_start);
     L.tsqrt = std::sqrt(L.t_target);
-    rng_draw(ctx, L.rng, L.draws, ctx->nlocal);
     LangevinDev Lg;
     Lg.gfactor1 = L.gf1.get();
     Lg.gfactor2 = L.gf2.get();
     Lg.tsqrt = L.tsqrt;
-    Lg.draws = L.draws.get();
+    Lg.draws = rng_next(ctx, L.rng, L.draws, L.batch, ctx->nlocal);
     UCG_HIP(launch_langevin(ctx->atoms_dev(), Lg, groupbit, ctx->stream));
     return UCG_OK;
   });
@@ -1126,6 +1162,8 @@ int ucg_fix_ucgstate_create(ucg_ctx *ctx, int ld_flag, int mc_flag, int mc_seed,
     if (mc_flag) {
       if (mc_seed + me <= 0 || mc_seed + me > 900000000) throw InputError{"Invalid seed for Marsaglia random # generator"};
       rng_setup(ctx, S.rng, S.hist0, S.hist1, mc_seed + me);
+      S.batch.total = S.batch.used = 0;
+      S.batch.unit = 0;
     }
     return UCG_OK;
   });
@@ -1140,8 +1178,7 @@ int ucg_fix_ucgstate_post_force(ucg_ctx *ctx)
     const unsigned int *draws = nullptr;
     if (S.mc_flag && !S.ld_flag) {
       // one uniform() per 2-state owned bead in index order (:117); every bead is 2-state here
-      rng_draw(ctx, S.rng, S.draws, ctx->nlocal);
-      draws = S.draws.get();
+      draws = rng_next(ctx, S.rng, S.draws, S.batch, ctx->nlocal);
     }
     UCG_HIP(launch_ucgstate(ctx->atoms_dev(), S.ld_flag, S.mc_flag, S.mc_rate, draws, ctx->stream));
     return UCG_OK;
@@ -1161,19 +1198,17 @@ int ucg_md_post_fused(ucg_ctx *ctx, int use_langevin, int use_ucgstate, int use_
       if (delta != 0.0) delta /= (double) (endstep - beginstep);
       L.t_target = L.t_start + delta * (L.t_stop - L.t_start);
       L.tsqrt = std::sqrt(L.t_target);
-      rng_draw(ctx, L.rng, L.draws, ctx->nlocal);
       Lg.gfactor1 = L.gf1.get();
       Lg.gfactor2 = L.gf2.get();
       Lg.tsqrt = L.tsqrt;
-      Lg.draws = L.draws.get();
+      Lg.draws = rng_next(ctx, L.rng, L.draws, L.batch, ctx->nlocal);
     }
     const unsigned int *mc_draws = nullptr;
     FixUcgState &S = ctx->ucgst;
     if (use_ucgstate) {
       if (!S.active) return fail(ctx, UCG_ERR_INVALID, "fix ucgstate not created");
       if (S.mc_flag && !S.ld_flag) {
-        rng_draw(ctx, S.rng, S.draws, ctx->nlocal);
-        mc_draws = S.draws.get();
+        mc_draws = rng_next(ctx, S.rng, S.draws, S.batch, ctx->nlocal);
       }
     }
     UCG_HIP(launch_post_fused(ctx->atoms_dev(), use_langevin != 0, Lg, use_ucgstate != 0, S.ld_flag, S.mc_flag, S.mc_rate,
@@ -1209,11 +1244,10 @@ int ucg_md_pair_post(ucg_ctx *ctx, ucg_pair *p, int use_langevin, int use_ucgsta
       if (delta != 0.0) delta /= (double) (endstep - beginstep);
       L.t_target = L.t_start + delta * (L.t_stop - L.t_start);
       L.tsqrt = std::sqrt(L.t_target);
-      rng_draw(ctx, L.rng, L.draws, ctx->nlocal);  // the draws do not depend on the forces: generated first
       Q.gfactor1 = L.gf1.get();
       Q.gfactor2 = L.gf2.get();
       Q.tsqrt = L.tsqrt;
-      Q.lang_draws = L.draws.get();
+      Q.lang_draws = rng_next(ctx, L.rng, L.draws, L.batch, ctx->nlocal);  // the draws do not depend on the forces
     }
     FixUcgState &S = ctx->ucgst;
     if (use_ucgstate) {
@@ -1222,8 +1256,7 @@ int ucg_md_pair_post(ucg_ctx *ctx, ucg_pair *p, int use_langevin, int use_ucgsta
       Q.mc_flag = S.mc_flag;
       Q.mc_rate = S.mc_rate;
       if (S.mc_flag && !S.ld_flag) {
-        rng_draw(ctx, S.rng, S.draws, ctx->nlocal);
-        Q.mc_draws = S.draws.get();
+        Q.mc_draws = rng_next(ctx, S.rng, S.draws, S.batch, ctx->nlocal);
       }
     }
     ctx->pos4_alt.reserve_exact(ctx->pos4.capacity());
@@ -1320,6 +1353,14 @@ int ucg_ctx_set_option(ucg_ctx *ctx, const char *name, int value)
   }
   if (std::strcmp(name, "post_in_pair") == 0) {
     ctx->post_in_pair = value != 0;
+    return UCG_OK;
+  }
+  if (std::strcmp(name, "rng_batch") == 0) {
+    if (value < 1 || value > 64) {
+      ctx->err = "rng_batch must be 1 .. 64";
+      return UCG_ERR_INVALID;
+    }
+    ctx->rng_batch = value;
     return UCG_OK;
   }
   if (std::strcmp(name, "rows_untiled") == 0) {

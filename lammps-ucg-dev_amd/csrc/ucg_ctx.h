@@ -78,6 +78,14 @@ class DevBuf {
   size_t cap_ = 0;
 };
 
+// a window of pre-generated draws of one RanMars stream: K steps' worth per launch (option "rng_batch")
+struct RngBatch {
+  DevBuf<unsigned int> hist_save;  // the stream's 97 lag values at the start of the window
+  long long count0 = 0;            // ... and its call count there
+  long long total = 0, used = 0;   // draws in the window / handed out so far
+  int unit = 0;                    // draws per step the window was sized for
+};
+
 struct FixLangevin {
   bool active = false;
   double t_start = 0, t_stop = 0, t_period = 0, t_target = 0, tsqrt = 0;
@@ -86,6 +94,7 @@ struct FixLangevin {
   DevBuf<double> gf1, gf2;
   RanMarsDev rng{};
   DevBuf<unsigned int> hist0, hist1, draws;
+  RngBatch batch;
   double lambda_temp = 0;
 };
 
@@ -95,6 +104,7 @@ struct FixUcgState {
   double mc_rate = 0.01;
   RanMarsDev rng{};
   DevBuf<unsigned int> hist0, hist1, draws;
+  RngBatch batch;
 };
 
 }  // namespace ucg
@@ -117,6 +127,7 @@ struct ucg_ctx {
   int gather_slots = 1;  // option "gather_slots": lanes per bead of the ucgld / bethe gather kernels
   bool force_generic_kernels = false;  // option "generic_kernels": never pick the FAST variants
   bool fma_contract = false;           // option "fma_contract": gather kernels compiled with FMA contraction (not bit-exact)
+  int rng_batch = 10;                  // option "rng_batch": steps of per-bead draws generated per k_ranmars launch (1 = one launch per step)
   bool rows_untiled = false;           // option "rows_untiled": build rows with the one-lane-per-bead kernels
 
   // atoms

@@ -416,3 +416,31 @@ def test_fma_contracted_kernels_within_tolerance(fresh_ctx, pkg, orc, style):
         assert np.max(np.abs(G[k] - O[k])) <= 1e-12 * scale, k
         differs |= not util.bits_equal(G[k], O[k])
     assert differs  # it really is a different rounding, not the exact kernels
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch", [1, 4, 10])
+def test_rng_window_follows_the_sequential_stream_when_the_bead_count_changes(fresh_ctx, pkg, batch):
+    """fix ucgld/langevin takes one RanMars draw per owned bead per step from ONE sequential stream
+    (UCG/fix_ucgld_langevin.cpp:280).  The library generates several steps' worth per launch (option rng_batch); when
+    the bead count changes before a window is used up (migration), the stream must continue exactly where the
+    consumed draws ended."""
+    ctx = fresh_ctx
+    dt, seed = 0.002, 48279
+    ctx.set_units(1.0, 1.0, 1.0, dt)
+    ctx.set_option("rng_batch", batch)
+    ctx.fix_ucgld_langevin(1.0, 1.0, 1.0, seed)
+    pos = 0
+    g2 = np.sqrt(10.0) * np.sqrt(24.0 / 1.0 / dt)  # gfactor2 of init(): sqrt(m_lambda)/ftm2v * sqrt(24 kB/(t_period dt mvv2e))
+    for ncell, ncalls in ((6, 3), (7, 12), (5, 2), (7, 1)):
+        beads = pkg.synth.make_beads(ncell, seed=3 + ncell)   # ucgvl = 0: the friction term vanishes
+        ctx.upload_beads(beads)
+        ctx.fix_ucgld_langevin_init(2, beads.ucgml[:3])
+        for _ in range(ncalls):
+            ctx.force_clear()
+            ctx.fix_ucgld_langevin_post_force(0, 0, 10)
+            got = ctx.atoms_download()["ucgforce"]
+            u = ctx.ranmars_fill(seed, pos, beads.n)
+            want = g2 * 1.0 * (u - 0.5)
+            assert np.allclose(got, want, rtol=1e-13, atol=0.0), (ncell, pos)
+            pos += beads.n
