@@ -295,7 +295,7 @@ def main():
         with open(tfile) as fh:
             out["roofline"]["traffic"] = json.load(fh)["traffic_bytes_per_launch"]
         out["roofline"]["traffic_note"] = "HBM bytes per launch from rocprofv3 PMC (FETCH_SIZE x2 per the gfx950 calibration + WRITE_SIZE), profiles/r01_pair_traffic.json"
-    if not args.no_cpu_baseline and args.style == "table_ucgld":
+    if not args.no_cpu_baseline and args.style == "table_ucgld" and world == 1:  # rank 0 at N = 1 only
         cb = cpu_baseline(pkg, deck, args.cpu_ncell, args.cpu_steps, dt, args.integrator)
         one = {
             "value": cb["atom_steps_per_s"] / n,
