@@ -60,6 +60,10 @@ void PairTableUCGGPU::settings(int narg, char **arg)
   AtomVecUCG::get(lmp);    // "This pair style requires atom style ucg."
   check(ucg_ctx_set_units(ctx, force->boltz, force->ftm2v, force->mvv2e, update->dt, force->special_lj), true);
   check(ucg_pair_settings(gpair, narg, arg), true);
+  // accepted by the library, so arg[0] is one of the four table styles and arg[1] an integer (ucgld.cpp:660-675)
+  tabstyle = !strcmp(arg[0], "lookup") ? UCG_LOOKUP : !strcmp(arg[0], "linear") ? UCG_LINEAR :
+             !strcmp(arg[0], "spline") ? UCG_SPLINE : UCG_BITMAP;
+  tablength = utils::inumeric(FLERR, arg[1], false, lmp);
 }
 
 void PairTableUCGGPU::coeff(int narg, char **arg)
@@ -181,6 +185,46 @@ double PairTableUCGGPU::single(int, int, int itype, int jtype, double rsq, doubl
   double e = 0.0;
   check(ucg_pair_single(gpair, itype, jtype, rsq, factor_lj, &fforce, &e), false);
   return e;
+}
+
+// Restart files: exactly what the reference writes (UCG/pair_table_ucgld.cpp:1431-1473) -- the table style, its length
+// and the long-range flags; tables, the state-settings file and coefficients are NOT stored: pair_style / pair_coeff
+// are given again after read_restart, as with the reference.
+void PairTableUCGGPU::write_restart(FILE *fp)
+{
+  write_restart_settings(fp);
+}
+
+void PairTableUCGGPU::read_restart(FILE *fp)
+{
+  read_restart_settings(fp);
+  if (!allocated) {
+    allocated = 1;
+    const int n = atom->ntypes + 1;
+    memory->create(setflag, n, n, "pair:setflag");
+    memory->create(cutsq, n, n, "pair:cutsq");
+    for (int i = 0; i < n; i++)
+      for (int j = 0; j < n; j++) setflag[i][j] = 0;
+  }
+}
+
+void PairTableUCGGPU::write_restart_settings(FILE *fp)
+{
+  fwrite(&tabstyle, sizeof(int), 1, fp);
+  fwrite(&tablength, sizeof(int), 1, fp);
+  fwrite(&ewaldflag, sizeof(int), 1, fp);
+  fwrite(&pppmflag, sizeof(int), 1, fp);
+  fwrite(&msmflag, sizeof(int), 1, fp);
+  fwrite(&dispersionflag, sizeof(int), 1, fp);
+  fwrite(&tip4pflag, sizeof(int), 1, fp);
+}
+
+void PairTableUCGGPU::read_restart_settings(FILE *fp)
+{
+  int *vals[7] = {&tabstyle, &tablength, &ewaldflag, &pppmflag, &msmflag, &dispersionflag, &tip4pflag};
+  if (comm->me == 0)
+    for (int *v : vals) utils::sfread(FLERR, v, sizeof(int), 1, fp, nullptr, error);
+  for (int *v : vals) MPI_Bcast(v, 1, MPI_INT, 0, world);
 }
 
 void *PairTableUCGGPU::extract(const char *str, int &dim)

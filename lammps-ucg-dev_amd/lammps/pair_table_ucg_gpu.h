@@ -34,8 +34,10 @@ class PairTableUCGGPU : public Pair {
   double init_one(int, int) override;
   double single(int, int, int, int, double, double, double, double &) override;
   void *extract(const char *, int &) override;
-  void write_restart(FILE *) override {}
-  void read_restart(FILE *) override {}
+  void write_restart(FILE *) override;
+  void read_restart(FILE *) override;
+  void write_restart_settings(FILE *) override;
+  void read_restart_settings(FILE *) override;
 
  protected:
   int ucg_style;
@@ -43,6 +45,7 @@ class PairTableUCGGPU : public Pair {
   ucg_pair *gpair = nullptr;
   bigint last_list_build = -1;
   double T = 0.0;
+  int tabstyle = 0, tablength = 0;    // as given to pair_style: what the reference keeps in restart files
   void check(int rc, bool all);
   void upload_list();
 };
