@@ -289,6 +289,20 @@ class RankSim:
             self.ctx.fix_ucgstate_post_force()
         return out
 
+    def thermo(self, last=None, mass=None, mvv2e=1.0):
+        """One all-reduce per output step: E_pair, virial[6] of the last energy evaluation (`last` =
+        what setup() / run() returned on this rank), the state-1 population, sum of lambda, the kinetic energy of x and
+        of lambda, the bead count.  Host arithmetic on downloaded arrays: output steps are rare."""
+        a = self.ctx.atoms_download()
+        n = a["nlocal"]
+        m = np.ones(n) if mass is None else np.asarray(mass, float)[a["type"][:n]]
+        ke = 0.5 * mvv2e * float(np.sum(m * np.sum(a["v"][:n] ** 2, axis=1)))
+        kel = 0.5 * mvv2e * float(np.sum(a["ucgml"][:n] * a["ucgvl"][:n] ** 2))
+        e, vir = (last[0], list(last[1])) if last is not None else (0.0, [0.0] * 6)
+        tot = self.tr.allreduce_sum([e] + vir + [float(a["ucgstate"][:n].sum()), float(a["ucgl"][:n].sum()), ke, kel, float(n)])
+        return dict(eng_vdwl=tot[0], virial=np.array(tot[1:7]), state1=tot[7], sum_lambda=tot[8], ke=tot[9], ke_lambda=tot[10],
+                    natoms=int(tot[11]))
+
     def setup(self, nsteps, ntypes=2):
         self.beginstep = self.ntimestep
         self.endstep = self.ntimestep + nsteps

@@ -109,7 +109,8 @@ def main():
         pair.check_errors()
         A1 = ctx.atoms_download()
         etot = tr.allreduce_sum([e0, last[0]])
-        result = dict(tag0=A0["tag"], f0=A0["f"], uf0=A0["ucgforce"], s0=A0["scores"], p0=A0["ucgp"], inside=inside, tag1=A1["tag"],
+        th = sim.thermo(last, mass=beads.mass)
+        result = dict(thermo=th, tag0=A0["tag"], f0=A0["f"], uf0=A0["ucgforce"], s0=A0["scores"], p0=A0["ucgp"], inside=inside, tag1=A1["tag"],
                       x1=A1["x"], l1=A1["ucgl"], e0=etot[0], e1=etot[1], nrebuild=sim.nrebuild, nghost=A1["nghost"])
         pair.close()
         ctx.close()

@@ -116,6 +116,17 @@ def test_world2_decomposed_run_matches_single_rank(fresh_ctx, pkg, world):
     l_multi = by_tag(tag1, np.concatenate([r["l1"] for r in res]))
     assert np.max(np.abs(l_multi - by_tag(S1["tag"], S1["ucgl"]))) < 1e-9
     assert abs(res[0]["e1"] - e_single1) <= 1e-9 * abs(e_single1)
+    # the reduced thermo line is the same on every rank and equals the single-rank totals
+    th = res[0]["thermo"]
+    for r in res[1:]:
+        assert r["thermo"]["eng_vdwl"] == th["eng_vdwl"] and r["thermo"]["natoms"] == th["natoms"] == beads.n
+    assert abs(th["eng_vdwl"] - e_single1) <= 1e-9 * abs(e_single1)
+    n = S1["nlocal"]
+    ke_single = 0.5 * float(np.sum(beads.mass[S1["type"][:n]] * np.sum(S1["v"][:n] ** 2, axis=1)))
+    assert abs(th["ke"] - ke_single) <= 1e-8 * ke_single
+    assert th["state1"] == float(S1["ucgstate"][:n].sum())
+    assert abs(th["sum_lambda"] - float(S1["ucgl"][:n].sum())) <= 1e-8 * beads.n
+    assert np.allclose(th["virial"], ctx.md_thermo()["virial"], rtol=1e-8, atol=1e-6)
 
 
 @pytest.mark.gpu
