@@ -71,7 +71,17 @@ int ucg_ctx_set_units(ucg_ctx *ctx, double boltz, double ftm2v, double mvv2e, do
  * grid lookup, IEEE division) even when the faster equivalent variants apply; takes effect
  * at the next ucg_pair_init.  Used by the tests to check that both give the same bits.
  * "density_proximity_as_shipped" = 1 makes table_ucg_bethe_density use the proximity function
- * itself in the CV back-force, as shipped (:719), instead of its derivative. */
+ * itself in the CV back-force, as shipped (:719), instead of its derivative.
+ * Tuning / diagnostics (none changes a result bit except where stated):
+ *   "gather_slots"  lanes per bead of the gather kernels: 0 = chosen from the bead count, or 1 (default), 2, 4, 8, 16;
+ *                   part of the canonical summation order (ucg_pair_gather_slots reports the value in use)
+ *   "rng_batch"     steps of per-bead RanMars draws generated per launch, 1..64 (default 10)
+ *   "stage_own"     own-block staging of the gather kernels in LDS (default 1)
+ *   "post_in_pair"  per-bead hooks in the gather kernel's epilogue (default 1), "md_no_fuse" = 1 runs every hook as
+ *                   its own kernel
+ *   "rows_untiled"  = 1 builds neighbour rows with the one-lane-per-bead kernels (the fallback of the tiled builder)
+ *   "fma_contract"  = 1 runs the gather kernels compiled with FMA contraction: NOT the bit-exact path (results within
+ *                   1e-12), never the default */
 int ucg_ctx_set_option(ucg_ctx *ctx, const char *name, int value);
 /* PMC calibration aid: stream a fresh buffer of nbytes with 4-byte (wide=0) or 16-byte (wide=1)
  * loads per lane, `repeats` launches of k_stream; lets FETCH_SIZE be calibrated on a known
