@@ -28,6 +28,9 @@ import time
 
 import numpy as np
 
+# multi-process GPU work on this pool needs dmabuf IPC (RCCL across ranks); set before anything touches the GPU
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as entry  # noqa: E402
