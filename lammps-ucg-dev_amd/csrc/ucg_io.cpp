@@ -78,6 +78,13 @@ struct File {
     ~File() {
         if (fp) fclose(fp);
     }
+    // writers call this before returning: a full disk shows up in ferror / fclose, not in fprintf's callers
+    void finish(const char *what) {
+        const bool bad = ferror(fp) != 0;
+        const int rc = fclose(fp);
+        fp = nullptr;
+        if (bad || rc != 0) fail(UCG_ERR_INPUT, "Write error on %s", what);
+    }
 };
 
 // ------------------------------------------------------------------ dump columns
@@ -411,6 +418,7 @@ int ucg_io_dump_write(const char *path, int append, long long timestep, const uc
             line[off++] = '\n';
             fwrite(line.data(), 1, off, F.fp);
         }
+        F.finish(path);
         if (nwritten) *nwritten = (long long) clist.size();
         return UCG_OK;
     } catch (const IoError &e) {
@@ -690,6 +698,7 @@ int ucg_io_write_data(const char *path, long long timestep, const char *units, c
                 fprintf(F.fp, "%d %.17g %.17g %.17g %.17g\n", a->id[i], a->v[3 * i], a->v[3 * i + 1], a->v[3 * i + 2],
                         a->ucgvl ? a->ucgvl[i] : 0.0);
         }
+        F.finish(path);
         return UCG_OK;
     } catch (const IoError &e) {
         return report(e, err, errcap);
@@ -935,6 +944,7 @@ int ucg_io_write_restart(const char *path, long long timestep, const ucg_io_atom
         // fields_restart of the atom style, UCG/atom_vec_ucg.cpp:85
         put(a->ucgstate, 4 * n); put(a->ucgl, 8 * n); put(a->ucgml, 8 * n); put(a->ucgvl, 8 * n); put(a->ucgp, 8 * n);
         put(a->mass, 8 * (size_t) (a->ntypes + 1));
+        F.finish(path);
         return UCG_OK;
     } catch (const IoError &e) {
         return report(e, err, errcap);
