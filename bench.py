@@ -292,12 +292,15 @@ def main():
     }
     # HBM traffic of the pair kernel: measured in separate rocprofv3 --pmc passes of this same
     # command (tools/profile_pmc.sh) and committed under profiles/; valid for the default workload
-    tfile = os.path.join(ROOT, "profiles", "r01_pair_traffic.json")
-    if (world == 1 and args.style == "table_ucgld" and args.ncell == 100 and args.lattice == "sc" and args.tabstyle == "spline"
+    tname = {"table_ucgld": "r01_pair_traffic.json", "table_ucg_bethe": "r01_bethe_traffic.json",
+             "table_ucg_bethe_density": "r01_density_traffic.json"}[args.style]
+    tfile = os.path.join(ROOT, "profiles", tname)
+    if (world == 1 and args.ncell == 100 and args.lattice == "sc" and args.tabstyle == "spline"
             and args.tablength == 1024 and os.path.exists(tfile)):
         with open(tfile) as fh:
             out["roofline"]["traffic"] = json.load(fh)["traffic_bytes_per_launch"]
-        out["roofline"]["traffic_note"] = "HBM bytes per launch from rocprofv3 PMC (FETCH_SIZE x2 per the gfx950 calibration + WRITE_SIZE), profiles/r01_pair_traffic.json"
+        out["roofline"]["traffic_note"] = ("HBM bytes per launch from rocprofv3 PMC (FETCH_SIZE x2 per the gfx950 calibration + "
+                                           "WRITE_SIZE), profiles/" + tname)
     if not args.no_cpu_baseline and args.style == "table_ucgld" and world == 1:  # rank 0 at N = 1 only
         cb = cpu_baseline(pkg, deck, args.cpu_ncell, args.cpu_steps, dt, args.integrator)
         one = {
