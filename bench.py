@@ -290,6 +290,8 @@ def main():
             "launches": int(result["pair_launches"]),
         },
     }
+    if "small_messages" in result:
+        out["config"]["small_messages"] = result["small_messages"]  # counts / flags of re-neighbouring steps: route taken
     # HBM traffic of the pair kernel: measured in separate rocprofv3 --pmc passes of this same
     # command (tools/profile_pmc.sh) and committed under profiles/; valid for the default workload
     tname = {"table_ucgld": "r01_pair_traffic.json", "table_ucg_bethe": "r01_bethe_traffic.json",

@@ -75,20 +75,50 @@ class Transport:
         self.staged = staged  # gloo: stage through the host
         self.world = dist.get_world_size()
         self.rank = dist.get_rank()
-        # small HOST messages (counts, flags) go through a gloo side group when the main backend is RCCL: no
-        # device round trip for a few integers.  Any failure to create it leaves everything on the main group.
+        # small HOST messages (counts, flags): either a gloo side group on the loopback interface (no device round
+        # trip) or the main backend with device tensors.  Which one is faster depends on the rank count, so both are
+        # timed once here and every rank takes the same, faster one (UCG_HOST_GROUP=0 / 1 forces the choice).
         self.host_group = None
-        if not staged and os.environ.get("UCG_HOST_GROUP", "1") != "0":
+        self.use_host = False
+        self.small_msg_us = None
+        want = os.environ.get("UCG_HOST_GROUP", "auto")
+        if not staged and want != "0":
             try:
                 # one node: the loopback interface is always there (the host name may not resolve)
                 os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
                 self.host_group = dist.new_group(backend="gloo")
             except Exception:  # noqa: BLE001
                 self.host_group = None
+            if self.host_group is not None:
+                self.use_host = True if want == "1" else self._host_group_is_faster()
+
+    def _host_group_is_faster(self):
+        """time the two routes for the two small collectives of a re-neighbouring step; all ranks get one answer"""
+        import time
+
+        t = self.torch
+        counts = np.zeros(self.world, dtype=np.int64)
+        times = []
+        for use_host in (True, False):
+            self.use_host = use_host
+            for _ in range(3):  # warm up connections / communicators
+                self.alltoall_counts(counts)
+                self.allreduce_max(0)
+            self.dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                self.alltoall_counts(counts)
+                self.allreduce_max(0)
+            times.append((time.perf_counter() - t0) / 10)
+        x = t.tensor(times, dtype=t.float64, device=self.device)
+        self.dist.all_reduce(x, op=self.dist.ReduceOp.SUM)
+        both = x.cpu().numpy() / self.world
+        self.small_msg_us = dict(host_gloo=float(both[0]) * 1e6, device_main=float(both[1]) * 1e6)
+        return bool(both[0] <= both[1])
 
     def alltoall_counts(self, counts):
         t = self.torch
-        if self.host_group is not None:
+        if self.use_host:
             send = t.from_numpy(np.ascontiguousarray(counts, dtype=np.int64))
             recv = t.empty_like(send)
             self.dist.all_to_all_single(recv, send, group=self.host_group)
@@ -137,7 +167,7 @@ class Transport:
 
     def allreduce_max(self, value: int) -> int:
         t = self.torch
-        if self.host_group is not None:
+        if self.use_host:
             x = t.tensor([int(value)], dtype=t.int64)
             self.dist.all_reduce(x, op=self.dist.ReduceOp.MAX, group=self.host_group)
             return int(x.item())
@@ -416,4 +446,5 @@ def run_bench(args, deck, rank, world, local_rank, dist):
     launches = args.steps  # the two part launches of a step count as one evaluation
     return dict(elapsed=float(t.item()), n=beads.n, pair_launches=launches, pair_ms=pair_ms, list_entries=int(tot[0]),
                 nghost=int(tot[1]), rebuilds=sim.nrebuild - nre0, maxrow=info["maxrow"], grid=grid,
-                nlocal_sum=int(tot[2]), rank0_list_entries=info["list_entries"], rank0_nlocal=info["nlocal"])
+                nlocal_sum=int(tot[2]), rank0_list_entries=info["list_entries"], rank0_nlocal=info["nlocal"],
+                small_messages=dict(route="gloo side group" if tr.use_host else "main backend", timed_us=tr.small_msg_us))
