@@ -209,6 +209,7 @@ class RankSim:
         self.nrebuild = 0
         self.halo_send_counts = self.halo_recv_counts = None
         self._halo_send = None
+        self._halo_plan = None
 
     def _buf(self, nbytes):
         t = self.tr.torch
@@ -273,7 +274,19 @@ class RankSim:
     def halo_forward(self):
         ctx, tr = self.ctx, self.tr
         ctx.halo_pack(self._halo_send.data_ptr())
-        rb = tr.alltoall_bytes(self._halo_send, self.halo_send_counts, self.halo_recv_counts, self.halo_bytes)
+        if tr.staged:
+            rb = tr.alltoall_bytes(self._halo_send, self.halo_send_counts, self.halo_recv_counts, self.halo_bytes)
+        else:
+            # same counts until the next rebuild: the split lists and the receive buffer are made once per rebuild
+            # (the unpack of a step is ordered before the next step's collective on the stream, so one buffer does)
+            plan = self._halo_plan
+            if plan is None or plan[0] != self.nrebuild:
+                ins = [int(c) * self.halo_bytes for c in self.halo_send_counts]
+                outs = [int(c) * self.halo_bytes for c in self.halo_recv_counts]
+                rbuf = tr.torch.empty(max(sum(outs), 1), dtype=tr.torch.uint8, device=tr.device)
+                plan = self._halo_plan = (self.nrebuild, ins, outs, rbuf, self._halo_send[: sum(ins)], rbuf[: sum(outs)])
+            tr.dist.all_to_all_single(plan[5], plan[4], plan[2], plan[1])
+            rb = plan[3]
         ctx.halo_unpack(rb.data_ptr())
         self._keep = rb
 
