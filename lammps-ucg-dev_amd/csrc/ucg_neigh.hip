@@ -752,9 +752,13 @@ void sort_pairs(ucg_ctx *ctx, Domain &D, int n)
 template <typename T>
 void permute(ucg_ctx *ctx, int n, const int *perm, DevBuf<T> &arr, DevBuf<T> &tmp)
 {
+  // gather into the scratch buffer, then the two trade places (no copy back).  The scratch buffer is made at least as
+  // large as the array it replaces, so the arrays of one family converge to one capacity and nothing is reallocated
+  // afterwards; entries beyond n (ghosts) are rebuilt by the caller.
+  if (tmp.capacity() < arr.capacity()) tmp.reserve_exact(arr.capacity());  // exact: the family's capacity must not creep
   tmp.reserve((size_t) n);
   hipLaunchKernelGGL(k_gather<T>, dim3(nblk(n)), dim3(NB), 0, ctx->stream, n, perm, arr.get(), tmp.get());
-  UCG_HIP(hipMemcpyAsync(arr.get(), tmp.get(), (size_t) n * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream));
+  arr.swap(tmp);
 }
 
 // (1)+(3): wrap (optional), key, radix-sort owned beads by (bin, tag), permute the per-bead arrays
