@@ -152,6 +152,9 @@ def main():
     capi, synth = pkg.capi, pkg.synth
     dt = 0.002
     workdir = tempfile.mkdtemp(prefix=f"ucgbench_r{rank}_")
+    import atexit
+    import shutil
+    atexit.register(shutil.rmtree, workdir, True)  # the generated table / settings files
     if args.style == "table_ucg_bethe":
         deck = synth.make_deck(workdir, args.tabstyle, args.tablength,
                                extra_keywords=("method", "bethe", "pseudo", "yes", "prior", "ucgl"))

@@ -6,9 +6,18 @@ import numpy as np
 from conftest import load_oracle, load_package
 
 
+def _tmpdir(prefix):
+    """a scratch directory for generated decks, removed when the test process ends"""
+    import atexit
+    import shutil
+    d = tempfile.mkdtemp(prefix=prefix)
+    atexit.register(shutil.rmtree, d, True)
+    return d
+
+
 def make_deck(tabstyle="spline", tablength=1024, **kw):
     pkg = load_package()
-    return pkg.synth.make_deck(tempfile.mkdtemp(prefix="ucgdeck_"), tabstyle, tablength, **kw)
+    return pkg.synth.make_deck(_tmpdir("ucgdeck_"), tabstyle, tablength, **kw)
 
 
 GATHER_SLOTS = 1  # the library's default lanes per bead (ucg_pair_gather_slots); part of the canonical order
@@ -72,7 +81,7 @@ def max_ulp(a, b):
 
 def make_multi_deck(n_actual=2, tabstyle="spline", tablength=256, **kw):
     pkg = load_package()
-    return pkg.synth.make_multi_deck(tempfile.mkdtemp(prefix="ucgmdeck_"), n_actual, tabstyle, tablength, **kw)
+    return pkg.synth.make_multi_deck(_tmpdir("ucgmdeck_"), n_actual, tabstyle, tablength, **kw)
 
 
 def multi_type_beads(pkg, ncell, n_actual, seed, molecule_size=1):
