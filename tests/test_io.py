@@ -60,6 +60,26 @@ def test_dump_text_matches_oracle_bytes(pkg, tmp_path, columns, kw):
     assert nw == int(want.split("\n")[3])
 
 
+def test_dump_modify_format_line_column_and_boundary(pkg, tmp_path):
+    """dump_modify format line "..." / format M / boundary: the per-column formats are the words of the line format,
+    overridden column by column (DumpCustom::init_style, dump_custom.cpp:262-290)"""
+    a = small_atoms(n=5)
+    p = tmp_path / "f.dump"
+    pkg.ucgio.write_dump(p, a, "id type ucgl ucgp", timestep=3,
+                         modify=['format line "%d %3d %10.4f %g"', "format 4 %.3e", "boundary pp pp ff", "sort id"])
+    lines = open(p).read().split("\n")
+    assert lines[4] == "ITEM: BOX BOUNDS pp pp ff"
+    order = np.argsort(a["id"])
+    for ln, i in zip(lines[9:14], order):
+        assert ln == "%d %3d %10.4f %.3e" % (a["id"][i], a["type"][i], a["ucgl"][i], a["ucgp"][i])
+    with pytest.raises(pkg.capi.UcgError, match="format line is too short"):
+        pkg.ucgio.write_dump(p, a, "id type ucgl ucgp", modify=['format line "%d %d"'])
+    with pytest.raises(pkg.capi.UcgError, match="Invalid dump_modify thresh operator"):
+        pkg.ucgio.write_dump(p, a, "id", modify=["thresh ucgl => 0.5"])
+    with pytest.raises(pkg.capi.UcgError, match="not supported"):
+        pkg.ucgio.write_dump(p, a, "id", modify=["pbc yes"])
+
+
 def test_dump_golden_file(pkg, tmp_path):
     """six atoms written by hand in the native format (header widths, "%d" / "%g" columns, one blank between columns,
     none at the end of a line); both the oracle and the library must reproduce the file byte for byte"""
