@@ -3,6 +3,7 @@
   python mp_worker.py cpu <port> <outdir>   -- gloo on CPU: decomposition + transport protocol
   python mp_worker.py gpu <port> <outdir>   -- gloo (host-staged) with both ranks on ONE GPU
   python mp_worker.py gpu_density ...       -- the same with table_ucg_bethe_density (two mid-compute halos)
+  python mp_worker.py gpu_lang ...          -- thermostatted run with state switching (per-rank RanMars streams)
 """
 import os
 import pickle
@@ -45,6 +46,35 @@ def main():
         lo, hi = multi.sub_box(beads.boxlo, beads.boxhi, grid, rank)
         result = dict(n=len(got), inside=bool(np.all((got[:, :3] >= lo) & (got[:, :3] < hi))), tags=got[:, 3].astype(np.int64),
                       counts=counts, rc=rc, maxflag=tr.allreduce_max(rank), total=tr.allreduce_sum([len(got)])[0])
+    elif mode == "gpu_lang":
+        # thermostatted run: per-rank RanMars streams (seed + me) with draw windows that have to follow the bead
+        # count through migrations
+        capi = pkg.capi
+        deck = util.make_deck("spline", 1024)
+        ctx = capi.Context(0, dt=0.004)
+        sl = slice(rank * beads.n // world, (rank + 1) * beads.n // world)
+        n = sl.stop - sl.start
+        ctx.atoms_upload(n, 0, beads.ntypes, beads.x[sl], beads.v[sl], beads.type[sl], beads.tag[sl], beads.mask[sl],
+                         beads.ucgstate[sl], beads.ucgl[sl], beads.ucgvl[sl], beads.ucgml[sl], beads.ucgp[sl], beads.mass)
+        ctx.domain_set(beads.boxlo, beads.boxhi, 2.5, 0.3, every=2, delay=0, check=1)
+        pair = util.gpu_pair(ctx, "table_ucgld", deck)
+        ctx.fix_ucgld_langevin(1.0, 1.0, 1.0, 48279, me=rank)
+        ctx.fix_ucgstate("mc", 9127, 0.3, me=rank)
+        ctx.fix_nve_ucgld_wall_hard(False, 0.1)
+        tr = multi.Transport(dist, torch.device("cuda", 0), staged=True)
+        sim = multi.RankSim(ctx, pair, tr, grid, use_langevin=True, use_ucgstate=True, integrator="wall")
+        sim.setup(360)  # long enough for beads to cross the brick faces (0.54 sigma from the nearest lattice plane)
+        counts = [ctx.counts()[0]]
+        for _ in range(6):
+            sim.run(60)
+            counts.append(ctx.counts()[0])
+        pair.check_errors()
+        A = ctx.atoms_download()
+        nl = A["nlocal"]
+        result = dict(tag=A["tag"][:nl], x=A["x"][:nl], l=A["ucgl"][:nl], v=A["v"], st=A["ucgstate"][:nl], counts=counts,
+                      nrebuild=sim.nrebuild)
+        pair.close()
+        ctx.close()
     elif mode == "gpu_cluster":
         # fix cluster_switch on a decomposed run: labels must equal the single-rank ones; then a short run
         capi = pkg.capi

@@ -444,3 +444,27 @@ def test_rng_window_follows_the_sequential_stream_when_the_bead_count_changes(fr
             want = g2 * 1.0 * (u - 0.5)
             assert np.allclose(got, want, rtol=1e-13, atol=0.0), (ncell, pos)
             pos += beads.n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("style", ["table_ucgld", "table_ucg_bethe"])
+def test_bitmap_file_section_on_the_device(fresh_ctx, pkg, orc, style):
+    """a BITMAP section of the table file (2^10 entries in bit order, used verbatim: "match") through the device kernels"""
+    ctx = fresh_ctx
+    deck = util.make_deck("bitmap", 10, n_file=1024, rmode="BITMAP")
+    beads = pkg.synth.make_beads(9, seed=21)
+    beads.ucgp = np.clip(np.random.default_rng(4).uniform(size=beads.n), 1e-6, 1 - 1e-6)
+    op = util.oracle_pair(style, deck)
+    assert op.table_info(0)["match"] == 1
+    sim = util.oracle_sim(beads, op, mode=1)
+    sim.rebuild()
+    assert sim.compute_forces(1, 1) == 0
+    O = sim.arrays()
+    util.upload_from_oracle(ctx, sim, beads)
+    gp = util.gpu_pair(ctx, style, deck)
+    eng, vir = gp.compute(1, 1)
+    gp.check_errors()
+    G = ctx.atoms_download()
+    for k in ("f", "scores", "ucgforce"):
+        assert util.bits_equal(G[k], O[k]), k
+    assert abs(eng - sim.ev()["eng_vdwl"]) <= 1e-12 * abs(eng)

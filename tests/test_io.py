@@ -145,6 +145,30 @@ def test_read_dump_matches_oracle(pkg, tmp_path, options, kw):
     assert np.array_equal(a["ucgl"], small_atoms()["ucgl"])  # the caller's arrays are not written
 
 
+def test_read_dump_coordinate_representations(pkg, tmp_path):
+    """x may come as x / xs / xu / xsu in the file (reader_native.cpp:329-398); `scaled` / `wrapped` say which one is
+    preferred when several are present, and unwrapped input resets the image flags (read_dump.cpp:917)"""
+    a = small_atoms(n=9)
+    prd = a["boxhi"] - a["boxlo"]
+    p = tmp_path / "c.dump"
+    pkg.ucgio.write_dump(p, a, "id x y z xs ys zs xu yu zu xsu ysu zsu ix iy iz", modify=["format float %.17g"])
+    base = dict(a, x=np.zeros_like(a["x"]))
+    got, _ = pkg.ucgio.read_dump(p, 0, "x y z", base)                      # wrapped, unscaled: the x columns
+    assert util.bits_equal(got["x"], a["x"]) and np.array_equal(got["image"], a["image"])
+    got, _ = pkg.ucgio.read_dump(p, 0, "x y z", base, "scaled yes")        # xs * prd + lo
+    xs = (a["x"] - a["boxlo"]) * (1.0 / prd)
+    assert util.bits_equal(got["x"], xs * prd + a["boxlo"])
+    got, _ = pkg.ucgio.read_dump(p, 0, "x y z", base, "wrapped no")        # xu as is, images zeroed
+    assert util.bits_equal(got["x"], a["x"] + a["image"] * prd) and np.all(got["image"] == 0)
+    got, _ = pkg.ucgio.read_dump(p, 0, "x y z ix iy iz", base, "wrapped no")
+    assert np.all(got["image"] == 0)
+    # only scaled columns in the file: they are taken whatever the preference
+    q = tmp_path / "s.dump"
+    pkg.ucgio.write_dump(q, a, "id xs ys zs", modify=["format float %.17g"])
+    got, _ = pkg.ucgio.read_dump(q, 0, "x y z", base)
+    assert util.bits_equal(got["x"], xs * prd + a["boxlo"])
+
+
 def test_read_dump_errors(pkg, tmp_path):
     a = small_atoms()
     p = tmp_path / "e.dump"

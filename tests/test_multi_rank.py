@@ -213,3 +213,21 @@ def test_world2_cluster_switch(fresh_ctx, pkg):
         if st[m] in (0, 1) and labels_now[m] != labels_now[mol_seed]:
             checked += 1
     assert checked > 10
+
+
+@pytest.mark.gpu
+def test_world2_thermostatted_run_is_reproducible(pkg):
+    """fix ucgld/langevin + fix ucgstate mc on two ranks: beads migrate, so the ranks' bead counts -- and with them the
+    number of RanMars draws per step -- change during the run; two launches must agree bit for bit"""
+    a = _launch("gpu_lang", world=2)
+    b = _launch("gpu_lang", world=2)
+    n = sum(len(r["tag"]) for r in a)
+    assert n == 1000 and sorted(np.concatenate([r["tag"] for r in a]).tolist()) == list(range(1, n + 1))
+    assert any(len(set(r["counts"])) > 1 for r in a), "no migration happened: the test does not exercise the windows"
+    assert all(r["nrebuild"] >= 3 for r in a)
+    for ra, rb in zip(a, b):
+        assert ra["counts"] == rb["counts"] and np.array_equal(ra["tag"], rb["tag"]) and np.array_equal(ra["st"], rb["st"])
+        for k in ("x", "l", "v"):
+            assert util.bits_equal(ra[k], rb[k]), k
+    lam = np.concatenate([r["l"] for r in a])
+    assert lam.min() >= 0.0 and lam.max() <= 1.0 and 0 < np.concatenate([r["st"] for r in a]).sum() < n
