@@ -58,6 +58,7 @@ def main():
                          beads.ucgstate[sl], beads.ucgl[sl], beads.ucgvl[sl], beads.ucgml[sl], beads.ucgp[sl], beads.mass)
         ctx.domain_set(beads.boxlo, beads.boxhi, 2.5, 0.3, every=2, delay=0, check=1)
         pair = util.gpu_pair(ctx, "table_ucgld", deck)
+        ctx.set_option("rng_batch", int(os.environ.get("UCG_TEST_RNG_BATCH", "10")))
         ctx.fix_ucgld_langevin(1.0, 1.0, 1.0, 48279, me=rank)
         ctx.fix_ucgstate("mc", 9127, 0.3, me=rank)
         ctx.fix_nve_ucgld_wall_hard(False, 0.1)

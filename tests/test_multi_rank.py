@@ -216,10 +216,13 @@ def test_world2_cluster_switch(fresh_ctx, pkg):
 
 
 @pytest.mark.gpu
-def test_world2_thermostatted_run_is_reproducible(pkg):
+def test_world2_thermostatted_run_is_reproducible(pkg, monkeypatch):
     """fix ucgld/langevin + fix ucgstate mc on two ranks: beads migrate, so the ranks' bead counts -- and with them the
-    number of RanMars draws per step -- change during the run; two launches must agree bit for bit"""
+    number of RanMars draws per step -- change during the run.  A run with draw windows of ten steps must agree bit
+    for bit with one that launches the generator every step (the sequential stream of the reference)"""
+    monkeypatch.setenv("UCG_TEST_RNG_BATCH", "10")
     a = _launch("gpu_lang", world=2)
+    monkeypatch.setenv("UCG_TEST_RNG_BATCH", "1")
     b = _launch("gpu_lang", world=2)
     n = sum(len(r["tag"]) for r in a)
     assert n == 1000 and sorted(np.concatenate([r["tag"] for r in a]).tolist()) == list(range(1, n + 1))
