@@ -39,11 +39,41 @@ __device__ __forceinline__ double post_wall_bias(const double lmd, const double 
   return (-7980.0 * x * x * x * x * x * x * x * x * x + 2.0 * x) * 10.0 * H;
 }
 
-template <int STYLE, int TS, bool EV, bool LDS_TAB, bool FAST, int SLOTS>
+// ---- ONCE variants ("own-block pairs once", option pair_once): rows built for them (ListDev::once_beads) hold an
+// own-block pair -- both beads among the ONCE_BEADS beads of one workgroup -- only in the row of ONE of its beads
+// (ucg_neigh.hip: once_evaluates).  That lane evaluates the pair and also forms what the pair adds to the PARTNER
+// -- the very numbers the reference's half-list sweep adds to it (UCG/pair_table_ucgld.cpp:500-502, :514-517,
+// :523-530: fpair, the energies and the weights do not depend on which bead is "i") -- and adds them to the
+// partner's six LDS accumulators as 64-bit FIXED-POINT integers (2^-34 units, ds_add_u64): integer addition is
+// associative, so the accumulated value does not depend on the order in which the lanes arrive and the result
+// stays bit-reproducible.  A bead's total is (its lanes' double sums, row order, fixed tree) + (its accumulators,
+// converted back).  The oracle's canonical order implements the same (orc_pair_set_once).  Each term must be
+// smaller than P.once_limit (65536 / the largest number of terms any bead receives); a larger one sets error
+// bit 4 (the caller then has to run without the option).
+constexpr int ONCE_BEADS = PAIR_BLOCK / 2;             // two lanes per bead
+constexpr double ONCE_MAGIC = 393216.0;                 // 1.5 * 2^18: ulp = 2^-34, so v + MAGIC holds round(v * 2^34) in its low bits
+constexpr double ONCE_UNIT = 5.8207660913467407e-11;    // 2^-34
+
+__device__ __forceinline__ void once_add(unsigned long long *acc, const double v, const double limit, int &err)
+{
+  if (!(fabs(v) < limit)) err |= 4;
+  atomicAdd(acc, (unsigned long long) __double_as_longlong(v + ONCE_MAGIC));
+}
+
+// sum of the images: n * bits(MAGIC) + sum of round(v * 2^34); bits(MAGIC) is a multiple of 2^51, so the low 51
+// bits hold the signed sum (|sum| < 2^50 by the term limit)
+__device__ __forceinline__ double once_decode(const unsigned long long s)
+{
+  const long long n = ((long long) (s << 13)) >> 13;
+  return (double) n * ONCE_UNIT;
+}
+
+template <int STYLE, int TS, bool EV, bool LDS_TAB, bool FAST, int SLOTS, bool ONCE = false>
 __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, const AtomsDev A,
                                                            const ListDev Lst, double *evpart,
                                                            int *errflag)
 {
+  static_assert(!ONCE || (LDS_TAB && FAST && SLOTS == 2 && STYLE == 0), "ONCE: tables + own beads + accumulators in LDS, two lanes per bead");
   extern __shared__ double4 s_tab[];
   __shared__ double s_red[(PAIR_BLOCK / 64) * 8];
   // the small per-model arrays (bounded by UCG_MAX_ACTUAL / UCG_MAX_TABLES at upload time)
@@ -61,9 +91,13 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
   // along a Morton curve, so ~3/4 of a bead's neighbours are beads of its own workgroup and are then
   // read from LDS instead of through the vector L1, whose tag rate (one line per lane per load) is
   // what bounds this kernel otherwise.  Same values either way.
-  const bool stage_own = P.stage_own != 0;
+  const bool stage_own = ONCE || P.stage_own != 0;
   double4 *s_ownpos = s_tab + (LDS_TAB ? ntabent : 0);
   int *s_ownmeta = reinterpret_cast<int *>(s_ownpos + PAIR_BLOCK / SLOTS);
+  // ONCE: six accumulators per bead, field-major (a wavefront's adds to one field spread over all banks)
+  unsigned long long *s_acc = reinterpret_cast<unsigned long long *>(s_ownmeta + PAIR_BLOCK / SLOTS);
+  if (ONCE)
+    for (int t = threadIdx.x; t < 6 * ONCE_BEADS; t += blockDim.x) s_acc[t] = 0ull;
   const int k0 = chunk_id * (PAIR_BLOCK / SLOTS);
   if (stage_own) {
     for (int t = threadIdx.x; t < PAIR_BLOCK / SLOTS; t += blockDim.x) {
@@ -97,10 +131,14 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
   const int kTp2 = P.kT_pow2;
   double ev[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int err = 0;
+  const bool active = k < nlocal;
+  double4 pk = make_double4(0, 0, 0, 0);
+  int mk = 0;
+  double fx = 0.0, fy = 0.0, fz = 0.0, uf = 0.0, s0 = 0.0, s1 = 0.0;
 
-  if (k < nlocal) {
-    const double4 pk = A.pos4[k];
-    const int mk = A.meta[k];
+  if (active) {
+    pk = A.pos4[k];
+    mk = A.meta[k];
     const int tk = UCG_META_TYPE(mk);
     const double lk = pk.w;
     const int n = Lst.numneigh[k];
@@ -108,7 +146,6 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
     const size_t rstep = pitch * SLOTS;
     const int *rp = Lst.neigh + k + (size_t) slot * pitch;
 
-    double fx = 0.0, fy = 0.0, fz = 0.0, uf = 0.0, s0 = 0.0, s1 = 0.0;
     const double mu0 = P.mu[tk * 2 + 0], mu1 = P.mu[tk * 2 + 1];
     if (slot == 0) {  // the prologue values (:170-180 / bethe :155-162) start slot 0's sums
       if (STYLE == 0) {
@@ -187,6 +224,8 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
         mm = A.meta[m0];
       }
     }
+    const int sk = UCG_META_STATE(mk);
+    const double once_limit = P.once_limit;
     rp += rstep;
     for (int e = slot; e < n; e += SLOTS) {
       rp += rstep;
@@ -260,6 +299,29 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
             evdwl = w00 * q.u00 + e1st + e2nd + w11 * q.u11;
           }
           uf -= lm * (q.u11 - q.u01) + (1. - lm) * (q.u10 - q.u00);
+          if (ONCE) {
+            const unsigned ml = (unsigned) (m - k0);
+            if (ml < nown) {
+              // the partner's side of this pair: the transposed quad (u'[a][b] = u[b][a]) with lambda_k as the
+              // neighbour's weight and this bead's state selecting the score terms; minus the same force
+              unsigned long long *ap = s_acc + ml;
+              once_add(ap, -(dx * fpair), once_limit, err);
+              once_add(ap + ONCE_BEADS, -(dy * fpair), once_limit, err);
+              once_add(ap + 2 * ONCE_BEADS, -(dz * fpair), once_limit, err);
+              once_add(ap + 3 * ONCE_BEADS, -(lk * (q.u11 - q.u10) + (1. - lk) * (q.u01 - q.u00)), once_limit, err);
+              once_add(ap + 4 * ONCE_BEADS, -div_kT(sk ? q.u10 : q.u00, kT, rkT, kTp2), once_limit, err);
+              once_add(ap + 5 * ONCE_BEADS, -div_kT(sk ? q.u11 : q.u01, kT, rkT, kTp2), once_limit, err);
+              if (EV) {  // the pair is seen once: its whole energy and virial (two halves elsewhere)
+                ev[0] += 0.5 * evdwl;
+                ev[1] += 0.5 * (dx * dx * fpair);
+                ev[2] += 0.5 * (dy * dy * fpair);
+                ev[3] += 0.5 * (dz * dz * fpair);
+                ev[4] += 0.5 * (dx * dy * fpair);
+                ev[5] += 0.5 * (dx * dz * fpair);
+                ev[6] += 0.5 * (dy * dz * fpair);
+              }
+            }
+          }
         } else {
           // Bethe closure in the reference's orientation (UCG/pair_table_ucg_bethe.cpp:544-604)
           const double cu01 = k_is_i ? q.u01 : q.u10, cu10 = k_is_i ? q.u10 : q.u01;
@@ -362,6 +424,10 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
       pm = pm_n;
       mm = mm_n;
     }
+  }
+  if (ONCE) __syncthreads();  // every lane of the workgroup has made its adds
+  if (active) {
+    const int tk = UCG_META_TYPE(mk);
     if (SLOTS > 1) {
       // fixed tree over the bead's lanes: s[l] += s[l + off], off = SLOTS/2 ... 1
 #pragma unroll
@@ -373,6 +439,15 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
         s0 += __shfl_down(s0, off, SLOTS);
         s1 += __shfl_down(s1, off, SLOTS);
       }
+    }
+    if (ONCE && slot == 0) {
+      const unsigned long long *ap = s_acc + (k - k0);
+      fx += once_decode(ap[0]);
+      fy += once_decode(ap[ONCE_BEADS]);
+      fz += once_decode(ap[2 * ONCE_BEADS]);
+      uf += once_decode(ap[3 * ONCE_BEADS]);
+      s0 += once_decode(ap[4 * ONCE_BEADS]);
+      s1 += once_decode(ap[5 * ONCE_BEADS]);
     }
     if (slot == 0) {
       const PostDev &Q = Lst.post;

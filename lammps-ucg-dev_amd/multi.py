@@ -403,39 +403,37 @@ class RankSim:
         return last
 
 
-def run_bench(args, deck, rank, world, local_rank, dist):
-    """bench.py's N > 1 leg: the same 1 M beads split over `world` GPUs (strong scaling)"""
+def run_bench(args, deck, beads, cs, rank, world, device_index, dist, shared, make_pair, attach_fixes, apply_options):
+    """bench.py's N > 1 leg: the same beads split over `world` ranks (strong scaling).  `shared`: fewer GPUs than
+    ranks (a one-GPU box rehearsing the path): the ranks share the GPUs and the halo is host-staged over gloo."""
     import time
 
     import torch
 
-    from . import capi, synth
+    from . import capi
 
     dt = 0.002
-    device = torch.device("cuda", local_rank)
-    beads = synth.make_beads(args.ncell, seed=12345, lattice=getattr(args, "lattice", "sc"))
+    device = torch.device("cuda", device_index)
     grid = choose_procgrid(world)
     # any initial split works: the first exchange sends every bead to its owner
     sl = slice(rank * beads.n // world, (rank + 1) * beads.n // world)
-    ctx = capi.Context(local_rank, dt=dt)
+    ctx = capi.Context(device_index, dt=dt)
     n = sl.stop - sl.start
     ctx.atoms_upload(n, 0, beads.ntypes, beads.x[sl], beads.v[sl], beads.type[sl], beads.tag[sl], beads.mask[sl],
                      beads.ucgstate[sl], beads.ucgl[sl], beads.ucgvl[sl], beads.ucgml[sl], beads.ucgp[sl], beads.mass)
+    if cs:
+        ctx.upload_molecule(beads.molecule[sl])
     ctx.domain_set(beads.boxlo, beads.boxhi, 2.5, 0.3, every=10, delay=0, check=1)
     # lanes per bead: 0 = chosen from the rank's bead count so that a 1/8 brick still fills 256 CUs
-    ctx.set_option("gather_slots", int(os.environ.get("UCG_GATHER_SLOTS", "0")))
-    pair = capi.Pair(ctx, "table_ucgld")
-    pair.settings(deck.pair_style_args())
-    pair.coeff(deck.pair_coeff_args())
-    pair.init(2, 1.0)
-    ctx.fix_ucgld_langevin(1.0, 1.0, 1.0, 48279, me=rank)
-    ctx.fix_ucgstate("ld", me=rank)
-    tr = Transport(dist, device, staged=False)
+    apply_options(ctx)
+    pair = make_pair(ctx)
+    use_lang, use_st = attach_fixes(ctx)
+    tr = Transport(dist, device, staged=shared)
     wall = getattr(args, "integrator", "wall") == "wall"
-    if wall:
-        ctx.fix_nve_ucgld_wall_hard(False, 0.1)
-    sim = RankSim(ctx, pair, tr, grid, integrator="wall" if wall else "nve")
-    sim.setup(args.warmup + args.steps)
+    sim = RankSim(ctx, pair, tr, grid, use_langevin=use_lang, use_ucgstate=use_st, integrator="wall" if wall else "nve")
+    if cs:
+        sim.cluster_switch(cs["mol_seed"], 0, cs["cutoff"], cs["seed"], cs["switch_freq"], cs["rates"], cs["contacts"])
+    sim.setup(args.warmup + args.steps, ntypes=beads.ntypes)
     sim.run(args.warmup)
     ctx.synchronize()
     ctx.profile_enable(True)
@@ -452,12 +450,17 @@ def run_bench(args, deck, rank, world, local_rank, dist):
     launches, pair_ms = ctx.profile_read(reset=True)
     ctx.profile_enable(False)
     pair.check_errors()
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if shared else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     info = ctx.md_info()
     tot = tr.allreduce_sum([info["list_entries"], info["nghost"], info["nlocal"]])
-    launches = args.steps  # the two part launches of a step count as one evaluation
-    return dict(elapsed=float(t.item()), n=beads.n, pair_launches=launches, pair_ms=pair_ms, list_entries=int(tot[0]),
-                nghost=int(tot[1]), rebuilds=sim.nrebuild - nre0, maxrow=info["maxrow"], grid=grid,
-                nlocal_sum=int(tot[2]), rank0_list_entries=info["list_entries"], rank0_nlocal=info["nlocal"],
-                small_messages=dict(route="gloo side group" if tr.use_host else "main backend", timed_us=tr.small_msg_us))
+    launches = args.steps  # the launches of one step (two parts, or the density style's three passes) count as one evaluation
+    out = dict(elapsed=float(t.item()), n=beads.n, pair_launches=launches, pair_ms=pair_ms, list_entries=int(tot[0]),
+               nghost=int(tot[1]), rebuilds=sim.nrebuild - nre0, maxrow=info["maxrow"], grid=grid,
+               nlocal_sum=int(tot[2]), rank0_list_entries=info["list_entries"], rank0_nlocal=info["nlocal"],
+               transport=(f"gloo, host-staged: {world} ranks share {torch.cuda.device_count()} GPU(s) (rehearsal of the N > 1 path)"
+                          if shared else "RCCL (torch.distributed nccl backend) over xGMI"),
+               small_messages=dict(route="gloo side group" if tr.use_host else "main backend", timed_us=tr.small_msg_us))
+    if cs:
+        out["cluster_switch_vector"] = [float(v) for v in ctx.fix_cluster_switch_vector()]
+    return out

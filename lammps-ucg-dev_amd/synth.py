@@ -194,10 +194,12 @@ class MultiDeck:
 
 def make_multi_deck(workdir: str, n_actual: int = 2, tabstyle: str = "spline", tablength: int = 1024,
                     mu=(0.0, 0.5), n_file: int = 1200, rlo: float = 0.6, rhi: float = 2.5, cut: float = 2.5,
-                    extra_keywords=()) -> MultiDeck:
+                    extra_keywords=(), density=None, entropy: bool = False, extra11: float = 0.0) -> MultiDeck:
     """n_actual two-state atom types; the LJ-like well depths of DEFAULT_EPS are scaled per actual pair so that
     every one of the 4 * n_actual (n_actual + 1) / 2 tables is different (u_ab of pair (i, j), i < j, is NOT
-    symmetric in the states: state a belongs to type i, state b to type j)."""
+    symmetric in the states: state a belongs to type i, state b to type j).  ``density=(rho_th, r_th)`` writes the
+    settings file of table_ucg_bethe_density (every type a density type; ``extra11`` adds extra11 * exp(-r) to the
+    (1,1) tables so that J never vanishes, SURVEY.md App. B #9)."""
     os.makedirs(workdir, exist_ok=True)
     sections = {}
     for i in range(1, n_actual + 1):
@@ -206,13 +208,19 @@ def make_multi_deck(workdir: str, n_actual: int = 2, tabstyle: str = "spline", t
             for a in (0, 1):
                 for b in (0, 1):
                     eps = DEFAULT_EPS[f"{a}{b}"] * scale * (1.0 + (0.07 * (a - b) if i != j else 0.0))
-                    sections[f"P{i}{j}_{a}{b}"] = (eps, 0.0)
+                    sections[f"P{i}{j}_{a}{b}"] = (eps, extra11 if (a == 1 and b == 1) else 0.0)
     tfile = write_table_file(os.path.join(workdir, "ucg_multi.table"), sections, n_file, rlo, rhi, "R")
     cfile = os.path.join(workdir, "ucg_multi.conf")
     with open(cfile, "w") as fh:
         fh.write(f"{n_actual} {2 * n_actual} 2\n")
         for a in range(1, n_actual + 1):
-            fh.write(f"{a} 2\n{2 * a - 1} {2 * a}\n{float(mu[0] + 0.1 * (a - 1))!r} {float(mu[1] - 0.05 * (a - 1))!r}\n")
+            fh.write(f"{a} 2\n")
+            if density is None:
+                fh.write(f"{2 * a - 1} {2 * a}\n")
+            else:
+                fh.write(f"{2 * a - 1} {2 * a} density {'entropy' if entropy else 'no_entropy'} \n")
+                fh.write(f"{float(density[0])!r} {float(density[1])!r}\n")
+            fh.write(f"{float(mu[0] + 0.1 * (a - 1))!r} {float(mu[1] - 0.05 * (a - 1))!r}\n")
     return MultiDeck(workdir, tfile, cfile, n_actual, tabstyle, tablength, cut, tuple(extra_keywords))
 
 

@@ -4,6 +4,8 @@
   python mp_worker.py gpu <port> <outdir>   -- gloo (host-staged) with both ranks on ONE GPU
   python mp_worker.py gpu_density ...       -- the same with table_ucg_bethe_density (two mid-compute halos)
   python mp_worker.py gpu_lang ...          -- thermostatted run with state switching (per-rank RanMars streams)
+  python mp_worker.py gpu_config5 ...       -- BASELINE.json config 5 in small: table_ucg_bethe_density + ucgstate mc +
+                                               fix cluster_switch (two actual atom types), decomposed
 """
 import os
 import pickle
@@ -113,6 +115,44 @@ def main():
         result = dict(labels=labels, state0=state0, restrict0=restrict0, rounds=rounds, tag=A["tag"], type=A["type"],
                       mol=ctx.download_molecule(), vec=ctx.fix_cluster_switch_vector(), state1=ctx.cs_array(1),
                       mol_seed=mol_seed, nrebuild=sim.nrebuild)
+        pair.close()
+        ctx.close()
+    elif mode == "gpu_config5":
+        # BASELINE.json config 5 in small: table_ucg_bethe_density (two actual types, both density types) + fix ucgstate mc
+        # + fix cluster_switch, decomposed: the density style's two mid-compute halos AND the cluster reductions
+        capi = pkg.capi
+        deck = util.make_multi_deck(2, "spline", 256, density=(11.3, 1.5), extra11=0.05)
+        mb = util.multi_type_beads(pkg, 10, 2, seed=5, molecule_size=2)
+        rates, contacts = pkg.synth.write_cluster_switch_files(deck.workdir, 0.35, [1], [2], [(1, 1)])
+        mol_seed = int(mb.molecule[np.flatnonzero(mb.type == 1)[0]])
+        ctx = capi.Context(0, dt=0.002)
+        sl = slice(rank * mb.n // world, (rank + 1) * mb.n // world)
+        n = sl.stop - sl.start
+        ctx.atoms_upload(n, 0, mb.ntypes, mb.x[sl], mb.v[sl], mb.type[sl], mb.tag[sl], mb.mask[sl], mb.ucgstate[sl],
+                         mb.ucgl[sl], mb.ucgvl[sl], mb.ucgml[sl], mb.ucgp[sl], mb.mass)
+        ctx.upload_molecule(mb.molecule[sl])
+        ctx.domain_set(mb.boxlo, mb.boxhi, 2.5, 0.3, every=5, delay=0, check=1)
+        pair = util.gpu_pair_multi(ctx, "table_ucg_bethe_density", deck)
+        ctx.fix_ucgstate("mc", 9127, 0.3, me=rank)
+        tr = multi.Transport(dist, torch.device("cuda", 0), staged=True)
+        sim = multi.RankSim(ctx, pair, tr, grid, use_langevin=False, use_ucgstate=True)
+        sim.cluster_switch(mol_seed, 0, 1.15, 4711, 5, rates, contacts)
+        e0, v0 = sim.setup(30, ntypes=mb.ntypes)
+        A0 = ctx.atoms_download()
+        changed = ctx.cs_sweep(1)
+        while True:
+            ctx.cs_set_array(5, tr.allreduce_array(ctx.cs_array(5), "min"))
+            if not tr.allreduce_max(changed):
+                break
+            changed = ctx.cs_sweep(0)
+        ctx.cs_finalize()
+        labels = ctx.cs_array(0)
+        sim.run(30)
+        pair.check_errors()
+        A = ctx.atoms_download()
+        result = dict(tag0=A0["tag"], f0=A0["f"], p0=A0["ucgp"], st0=A0["ucgstate"], e0=tr.allreduce_sum([e0])[0],
+                      labels=labels, tag=A["tag"], type=A["type"], st=A["ucgstate"], x=A["x"], mol=ctx.download_molecule(),
+                      vec=ctx.fix_cluster_switch_vector(), mol_seed=mol_seed, nrebuild=sim.nrebuild, nghost=A["nghost"])
         pair.close()
         ctx.close()
     else:

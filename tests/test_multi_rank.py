@@ -117,6 +117,22 @@ def test_world2_decomposed_run_matches_single_rank(fresh_ctx, pkg, world):
     assert np.max(np.abs(l_multi - by_tag(S1["tag"], S1["ucgl"]))) < 1e-9
     assert abs(res[0]["e1"] - e_single1) <= 1e-9 * abs(e_single1)
     # the reduced thermo line is the same on every rank and equals the single-rank totals
+    # ... and against the ORACLE's single-rank trajectory of the same beads (reference-order loop), by tag
+    op = util.oracle_pair("table_ucgld", deck)
+    osim = util.oracle_sim(beads, op, mode=0, dt=0.004, nve=True, every=2)
+    assert osim.setup(40) == 0
+    O0 = osim.arrays()
+    for key, okey in (("f0", "f"), ("uf0", "ucgforce"), ("s0", "scores")):
+        multi = by_tag(tag0, np.concatenate([r[key] for r in res]))
+        ref = by_tag(O0["tag"], O0[okey])
+        assert np.max(np.abs(multi - ref)) <= 1e-11 * np.max(np.abs(ref)), ("oracle", key)
+    assert osim.run(40, 40) == 0
+    O1 = osim.arrays()
+    d = x_multi - by_tag(O1["tag"], O1["x"])
+    d -= np.round(d / beads.boxhi) * beads.boxhi
+    assert np.max(np.abs(d)) < 1e-9
+    assert np.max(np.abs(l_multi - by_tag(O1["tag"], O1["ucgl"]))) < 1e-9
+    assert abs(res[0]["e1"] - osim.ev()["eng_vdwl"]) <= 1e-9 * abs(e_single1)
     th = res[0]["thermo"]
     for r in res[1:]:
         assert r["thermo"]["eng_vdwl"] == th["eng_vdwl"] and r["thermo"]["natoms"] == th["natoms"] == beads.n
@@ -234,3 +250,56 @@ def test_world2_thermostatted_run_is_reproducible(pkg, monkeypatch):
             assert util.bits_equal(ra[k], rb[k]), k
     lam = np.concatenate([r["l"] for r in a])
     assert lam.min() >= 0.0 and lam.max() <= 1.0 and 0 < np.concatenate([r["st"] for r in a]).sum() < n
+
+
+@pytest.mark.gpu
+def test_world2_config5_density_with_cluster_switch_vs_oracle(pkg, orc):
+    """BASELINE.json config 5 in small (table_ucg_bethe_density + fix ucgstate mc + fix cluster_switch on two actual atom
+    types), two ranks, against the ORACLE's single-rank run of the same beads: forces, posteriors and states at setup by
+    tag, the cluster labels (independent of the decomposition), then 30 steps with switching every 5"""
+    res = _launch("gpu_config5")
+    deck = util.make_multi_deck(2, "spline", 256, density=(11.3, 1.5), extra11=0.05)
+    mb = util.multi_type_beads(pkg, 10, 2, seed=5, molecule_size=2)
+    rates, contacts = pkg.synth.write_cluster_switch_files(deck.workdir, 0.35, [1], [2], [(1, 1)])
+    mol_seed = res[0]["mol_seed"]
+    op = util.oracle_pair_multi("table_ucg_bethe_density", deck)
+    sim = util.oracle_sim(mb, op, mode=1, dt=0.002, nve=True, ucgstate=("mc", 9127, 0.3), every=5)
+    sim.cluster_switch(mol_seed, 0, 1.15, 4711, 5, rates, contacts)
+    assert sim.setup(30) == 0
+    O = sim.arrays()
+
+    def by_tag(tag, arr):
+        out = np.zeros((mb.n,) + np.asarray(arr).shape[1:])
+        out[np.asarray(tag) - 1] = arr
+        return out
+
+    tag0 = np.concatenate([r["tag0"] for r in res])
+    assert sorted(tag0.tolist()) == list(range(1, mb.n + 1))
+    f_multi, f_orc = by_tag(tag0, np.concatenate([r["f0"] for r in res])), by_tag(O["tag"], O["f"])
+    assert np.max(np.abs(f_multi - f_orc)) <= 1e-10 * np.max(np.abs(f_orc))
+    p_multi, p_orc = by_tag(tag0, np.concatenate([r["p0"] for r in res])), by_tag(O["tag"], O["ucgp"])
+    assert np.max(np.abs(p_multi - p_orc)) <= 1e-10
+    assert abs(res[0]["e0"] - sim.ev()["eng_vdwl"]) <= 1e-10 * abs(sim.ev()["eng_vdwl"])
+    # cluster labels: the oracle's check_cluster on the same configuration
+    L = orc.lib()
+    cs = L.orc_sim_cs(sim.h)
+    assert L.orc_cs_check_cluster(cs, L.orc_sim_atoms(sim.h), L.orc_sim_molecule(sim.h), L.orc_sim_full_list(sim.h)) == 0
+    lab = sim.cs_arrays()["mol_cluster"]
+    for r in res:
+        assert np.array_equal(r["labels"], lab)
+    assert 1 < int((lab == lab[mol_seed]).sum()) < mb.molecule.max()
+    # after the run: every bead once, molecules whole (wholly ON or OFF), switching happened, states are 0 / 1
+    tag = np.concatenate([r["tag"] for r in res])
+    typ = np.concatenate([r["type"] for r in res])
+    mol = np.concatenate([r["mol"] for r in res])
+    st = np.concatenate([r["st"] for r in res])
+    assert sorted(tag.tolist()) == list(range(1, mb.n + 1))
+    assert np.array_equal(mol, mb.molecule[tag - 1])
+    for m in np.unique(mol):
+        assert len(np.unique(typ[mol == m])) == 1
+    assert set(np.unique(st)) <= {0, 1} and 0 < st.sum() < mb.n
+    assert np.array_equal(res[0]["vec"], res[1]["vec"])
+    assert res[0]["vec"][0] > 100 and 0 < res[0]["vec"][1] < res[0]["vec"][0]
+    assert (typ != mb.type[tag - 1]).sum() > 0
+    assert all(r["nrebuild"] >= 6 and r["nghost"] > 0 for r in res)
+    assert np.all(np.isfinite(np.concatenate([r["x"] for r in res])))
