@@ -318,7 +318,8 @@ def run_single(args, pkg, capi, deck, beads, cs, local_rank, steps, warmup, inte
     pair.check_errors()
     info = ctx.md_info()
     out = dict(elapsed=elapsed, n=beads.n, pair_launches=launches, pair_ms=pair_ms, list_entries=info["list_entries"],
-               nghost=info["nghost"], rebuilds=info["nrebuild"] - info0["nrebuild"], maxrow=info["maxrow"])
+               nghost=info["nghost"], rebuilds=info["nrebuild"] - info0["nrebuild"], maxrow=info["maxrow"],
+               once_beads=info.get("once_beads", 0), lanes_per_bead=pair.gather_slots)
     if cs:
         out["cluster_switch_vector"] = [float(v) for v in ctx.fix_cluster_switch_vector()]
     pair.close()
@@ -485,6 +486,11 @@ def main():
         out["roofline"]["with_fused_hooks"] = {
             "algorithmic_bytes_per_launch": b172, "frac": b172 / pair_avg_s / 1e9 / HBM_PEAK_GBS if pair_avg_s > 0 else 0.0,
             "note": "44 E + 172 N: the pair loop's bytes minus the 48 B kept in registers plus the 124 B of the fused hooks"}
+    if "once_beads" in result:
+        out["config"]["pair_kernel"] = {"lanes_per_bead": int(result["lanes_per_bead"]),
+                                        "own_block_pairs_once": int(result["once_beads"]),
+                                        "note": "own_block_pairs_once = beads per workgroup whose mutual pairs are evaluated by one "
+                                                "lane only (option pair_once, DESIGN.md 4.1); 0 = every pair from both rows"}
     if cs and "cluster_switch_vector" in result:
         out["config"]["cluster_switch_vector"] = result["cluster_switch_vector"]
     if "small_messages" in result:

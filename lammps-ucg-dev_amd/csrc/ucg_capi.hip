@@ -99,6 +99,7 @@ ListDev ucg_ctx::list_dev() const
   L.numneigh = numneigh.get();
   L.blockflag = nullptr;
   L.blockwant = 0;
+  L.once_beads = list_once_beads;
   L.post = PostDev{};
   return L;
 }
@@ -412,7 +413,17 @@ int ucg_pair_init(ucg_pair *p, int ntypes, double T)
       // own-bead staging: 36 bytes per bead of the workgroup behind the tables, if the 160 KB allow it
       if (bitmap && ctx->gather_slots > 1)
         return fail(ctx, UCG_ERR_UNSUPPORTED, "bitmap tables run with one lane per bead (option gather_slots 0 or 1)");
-      const int slots0 = ctx->gather_slots > 0 ? ctx->gather_slots : 1;
+      int slots0 = ctx->gather_slots > 0 ? ctx->gather_slots : 1;
+      // option pair_once: table_ucgld with its tables, 512 own beads (36 B each) and their 6 fixed-point
+      // accumulators (48 B each) in the 160 KB of LDS next to the static model arrays; two lanes per bead
+      p->once = ctx->pair_once && M.style == STYLE_UCGLD && fast && D.tab_in_lds && ctx->stage_own && !ctx->fma_contract &&
+                bytes + 512 * (36 + 48) + 4608 <= 160 * 1024;
+      if (p->once) {
+        slots0 = 2;
+        ctx->once_beads_wanted = 512;
+      } else if (ctx->pair_once) {
+        ctx->once_beads_wanted = 0;
+      }
       D.gather_slots = slots0;
       p->tab_lds_bytes = bytes;
       const size_t own = (size_t) (1024 / slots0) * 36;
@@ -525,7 +536,12 @@ static int pair_compute_impl(ucg_pair *p, int eflag, int vflag, double *eng_vdwl
     if (!p->uploaded) return fail(ctx, UCG_ERR_INVALID, "ucg_pair_compute before ucg_pair_init");
     if (ctx->list_inum != ctx->nlocal) return fail(ctx, UCG_ERR_INVALID, "neighbour list does not match the resident atoms");
     const bool ev = (eflag || vflag);
-    if (ctx->gather_slots == 0 && p->dev.tabstyle != BITMAP) {
+    if (ctx->list_once_beads > 0 && !p->once)
+      return fail(ctx, UCG_ERR_INVALID, "the neighbour rows were built for option pair_once (own-block pairs in one row only); "
+                                        "this pair style cannot sweep them");
+    if (p->once && ctx->list_once_maxin > 2048)
+      return fail(ctx, UCG_ERR_UNSUPPORTED, "option pair_once: a bead is the partner of more than 2048 own-block pairs");
+    if (ctx->gather_slots == 0 && p->dev.tabstyle != BITMAP && !p->once) {
       // auto: the kernel's time is (rounds of workgroups over the 256 CUs) x (lifetime of one workgroup),
       // the latter ~ row length / lanes per bead + a fixed part; pick the lanes per bead that minimise it
       // (matches the measured order at 125 k / 250 k / 500 k / 1 M beads per GPU)
@@ -654,7 +670,9 @@ int ucg_pair_check_errors(ucg_pair *p)
     if (!flag) return UCG_OK;
     UCG_HIP(hipMemsetAsync(p->d_err.get(), 0, sizeof(int), ctx->stream));
     if (flag & 1) return fail(ctx, UCG_ERR_TABLE_INNER, "Pair distance < table inner cutoff");
-    return fail(ctx, UCG_ERR_TABLE_OUTER, "Pair distance > table outer cutoff");
+    if (flag & 2) return fail(ctx, UCG_ERR_TABLE_OUTER, "Pair distance > table outer cutoff");
+    return fail(ctx, UCG_ERR_UNSUPPORTED, "option pair_once: a pair term left the range of the fixed-point accumulators "
+                                          "(|term| >= 2048); run without the option");
   });
 }
 
@@ -897,6 +915,8 @@ int ucg_neigh_upload_full(ucg_ctx *ctx, int inum, const int *numneigh, const lon
     ctx->list_pitch = pitch;
     ctx->list_maxrow = maxrow;
     ctx->list_entries = total;
+    ctx->list_stored = total;
+    ctx->list_once_beads = 0;  // a caller's full list holds every pair in both rows
     return UCG_OK;
   });
 }
@@ -906,7 +926,7 @@ int ucg_neigh_download(ucg_ctx *ctx, int *inum, int *numneigh, long long *first,
   if (!ctx) return UCG_ERR_INVALID;
   return guarded(ctx, [&]() -> int {
     if (inum) *inum = ctx->list_inum;
-    if (total) *total = ctx->list_entries;
+    if (total) *total = ctx->list_stored;
     if (!numneigh && !neigh) return UCG_OK;
     const int n = ctx->list_inum;
     std::vector<int> nn((size_t) n);
@@ -1365,6 +1385,11 @@ int ucg_ctx_set_option(ucg_ctx *ctx, const char *name, int value)
   }
   if (std::strcmp(name, "rows_untiled") == 0) {
     ctx->rows_untiled = value != 0;
+    return UCG_OK;
+  }
+  if (std::strcmp(name, "pair_once") == 0) {
+    ctx->pair_once = value != 0;
+    if (!ctx->pair_once) ctx->once_beads_wanted = 0;
     return UCG_OK;
   }
   if (std::strcmp(name, "stage_own") == 0) {

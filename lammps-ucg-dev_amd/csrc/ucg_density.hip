@@ -195,6 +195,7 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass2(const PairDev P, c
   const int kTp2 = P.kT_pow2;
   double ev[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int err = 0;
+  RangeTrack rtrack = range_track_init();
 
   if (k < nlocal) {
     const double4 pk = A.pos4[k];
@@ -257,8 +258,8 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass2(const PairDev P, c
       if (rsq < s_cutsq[tk * na1 + tm]) {
         const int *pt = s_pairtab + (tk * na1 + tm) * 4;
         Quad q;
-        if (LDS_TAB) eval_quad<TS, FAST>(s_tab, s_par, pt, P.tablength, P.tlm1, P.fast_stride, rsq, factor_lj, q, err);
-        else eval_quad<TS, FAST>(FAST ? P.tab_fast : P.tab, s_par, pt, P.tablength, P.tlm1, P.fast_stride, rsq, factor_lj, q, err);
+        if (LDS_TAB) eval_quad<TS, FAST>(s_tab, s_par, pt, P.tablength, P.tlm1, P.fast_stride, rsq, factor_lj, q, err, rtrack);
+        else eval_quad<TS, FAST>(FAST ? P.tab_fast : P.tab, s_par, pt, P.tablength, P.tlm1, P.fast_stride, rsq, factor_lj, q, err, rtrack);
         // scores: only the row owner's (:597-603)
         if (FAST) {
           s0 -= div_kT(sm ? q.u01 : q.u00, kT, rkT, kTp2);
@@ -330,6 +331,7 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass2(const PairDev P, c
     }
     cv[k] = c;
   }
+  if (FAST) err |= range_flags(s_par[0], P.tlm1, rtrack);
   if (err) atomicOr(errflag, err);
   if (EV) block_sum_store<8>(ev, s_red, evpart);
 }

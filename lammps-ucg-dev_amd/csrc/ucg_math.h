@@ -152,6 +152,64 @@ UCG_HD double ucg_expm1(double x)
   return y;
 }
 
+/* exp(x) and expm1(x) of the SAME argument (the Bethe closure needs both, UCG/pair_table_ucg_bethe.cpp:550-551), with
+ * one shared argument reduction and almost no control flow -- on a GPU the two functions' many early exits and
+ * k-dependent formulas make a wavefront run every path one of its 64 lanes takes.  Every result is bit for bit that of
+ * ucg_exp / ucg_expm1 above (tests/test_math.py compares them on millions of arguments, all branches included):
+ *   - |x| <= ln2/2 is the general path with k = 0: then t = 0, hi = x - 0 = x, lo = 0, c = 0, and the k = 0 formulas
+ *     are the general ones ((x c)/(c - 2) = -((x c)/(2 - c)) exactly; scaling by 2^0 adds 0 to the exponent);
+ *   - expm1's k = 0 and k = -1 results are formed from the shared x - e and selected; the other k (|x| > 1.04) and the
+ *     special arguments (NaN, overflow, underflow, tiny) go through the original functions in one rarely taken branch. */
+UCG_HD void ucg_exp_expm1(double x0, double *ex, double *em1)
+{
+  const double ln2HI = 6.93147180369123816490e-01;
+  const double ln2LO = 1.90821492927058770002e-10;
+  const double P1 = 1.66666666666666019037e-01;
+  const double P2 = -2.77777777770155933842e-03;
+  const double P3 = 6.61375632143793436117e-05;
+  const double P4 = -1.65339022054652515390e-06;
+  const double P5 = 4.13813679705723846039e-08;
+  const double Q1 = -3.33333333333331316428e-02;
+  const double Q2 = 1.58730158725481460165e-03;
+  const double Q3 = -7.93650757867487942473e-05;
+  const double Q4 = 4.00821782732936239552e-06;
+  const double Q5 = -2.01099218183624371326e-07;
+
+  const double ax = x0 < 0.0 ? -x0 : x0;
+  /* common range: -1.03972077083991796 < x < ... i.e. k in {-1, 0} and no special case; NaN fails the tests */
+  const int common = (ax >= 5.551115123125783e-17) && (x0 > -1.0397207708399179) && (x0 <= 0.34657359027997264);
+  if (!common) {
+    *ex = ucg_exp(x0);
+    *em1 = ucg_expm1(x0);
+    return;
+  }
+  /* k = 0 for |x| <= ln2/2, else (here x < 0) k = (int)(invln2 x - 0.5) = -1 */
+  const int km1 = ax > 0.34657359027997264;
+  const double t = km1 ? -1.0 : 0.0;
+  const double hi = x0 - t * ln2HI;
+  const double lo = t * ln2LO;
+  const double x = hi - lo;
+  const double c2 = (hi - x) - lo; /* expm1's correction term; 0 when k = 0 */
+  /* exp */
+  const double tt = x * x;
+  const double c = x - tt * (P1 + tt * (P2 + tt * (P3 + tt * (P4 + tt * P5))));
+  const double y = 1.0 - ((lo - (x * c) / (2.0 - c)) - hi);
+  /* y * 2^k, k in {-1, 0}: exponent arithmetic as ucg_scalbn_ does for k >= -1021 */
+  *ex = km1 ? UCG_BITS_U2D(UCG_BITS_D2U(y) - ((uint64_t)1 << 52)) : y;
+  /* expm1 */
+  const double hfx = 0.5 * x;
+  const double hxs = x * hfx;
+  const double r1 = 1.0 + hxs * (Q1 + hxs * (Q2 + hxs * (Q3 + hxs * (Q4 + hxs * Q5))));
+  const double t3 = 3.0 - r1 * hfx;
+  double e = hxs * ((r1 - t3) / (6.0 - x * t3));
+  /* k = 0: x - (x e - hxs);  k = -1: e = x (e - c) - c; e -= hxs; 0.5 (x - e) - 0.5.  With c = 0 the k = -1 chain
+     gives e = x e - hxs as well, so both cases share it */
+  e = (x * (e - c2) - c2);
+  e -= hxs;
+  const double d = x - e;
+  *em1 = km1 ? 0.5 * d - 0.5 : d;
+}
+
 UCG_HD double ucg_log(double x)
 {
   const double ln2_hi = 6.93147180369123816490e-01;

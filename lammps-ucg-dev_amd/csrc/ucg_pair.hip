@@ -39,36 +39,52 @@ __device__ __forceinline__ double post_wall_bias(const double lmd, const double 
   return (-7980.0 * x * x * x * x * x * x * x * x * x + 2.0 * x) * 10.0 * H;
 }
 
+// A neighbour's record {x, y, z, lambda | type, state}: from the workgroup's LDS copy when it is one of its own beads,
+// else through L1 / L2.  Written as one select of the two pointers, which the compiler turns into generic-address
+// (flat) loads.  Measured alternative (round 2): two branches, an LDS read and a global load each under its lane mask,
+// are SLOWER (422 -> 472 us at 1 M beads): both write the same registers, so every LDS read waits for the other
+// lanes' outstanding global loads (vmcnt), and the two serial branch bodies cost more than the flat path.
+__device__ __forceinline__ void gather_bead_split(const AtomsDev &A, const double4 *s_ownpos, const int *s_ownmeta, const int k0,
+                                                  const unsigned nown, const int m, double4 &pm, int &mm)
+{
+  const unsigned ml = (unsigned) (m - k0);
+  if (ml < nown) {
+    pm = s_ownpos[ml];
+    mm = s_ownmeta[ml];
+  } else {
+    pm = A.pos4[m];
+    mm = A.meta[m];
+  }
+}
+
 // ---- ONCE variants ("own-block pairs once", option pair_once): rows built for them (ListDev::once_beads) hold an
 // own-block pair -- both beads among the ONCE_BEADS beads of one workgroup -- only in the row of ONE of its beads
 // (ucg_neigh.hip: once_evaluates).  That lane evaluates the pair and also forms what the pair adds to the PARTNER
 // -- the very numbers the reference's half-list sweep adds to it (UCG/pair_table_ucgld.cpp:500-502, :514-517,
 // :523-530: fpair, the energies and the weights do not depend on which bead is "i") -- and adds them to the
-// partner's six LDS accumulators as 64-bit FIXED-POINT integers (2^-34 units, ds_add_u64): integer addition is
+// partner's six LDS accumulators as 64-bit FIXED-POINT integers (2^-40 units, ds_add_u64): integer addition is
 // associative, so the accumulated value does not depend on the order in which the lanes arrive and the result
 // stays bit-reproducible.  A bead's total is (its lanes' double sums, row order, fixed tree) + (its accumulators,
 // converted back).  The oracle's canonical order implements the same (orc_pair_set_once).  Each term must be
-// smaller than P.once_limit (65536 / the largest number of terms any bead receives); a larger one sets error
+// smaller than ONCE_LIMIT = 2048 in magnitude (thousands of them then fit the 64 bits); a larger one sets error
 // bit 4 (the caller then has to run without the option).
 constexpr int ONCE_BEADS = PAIR_BLOCK / 2;             // two lanes per bead
-constexpr double ONCE_MAGIC = 393216.0;                 // 1.5 * 2^18: ulp = 2^-34, so v + MAGIC holds round(v * 2^34) in its low bits
-constexpr double ONCE_UNIT = 5.8207660913467407e-11;    // 2^-34
+constexpr double ONCE_MAGIC = 6144.0;                   // 1.5 * 2^12: ulp = 2^-40, so bits(v + MAGIC) - bits(MAGIC) = round(v * 2^40)
+constexpr double ONCE_UNIT = 9.094947017729282e-13;     // 2^-40
+constexpr double ONCE_LIMIT = 2048.0;                   // v + MAGIC stays inside [2^12, 2^13)
 
-__device__ __forceinline__ void once_add(unsigned long long *acc, const double v, const double limit, int &err)
+__device__ __forceinline__ void once_add(unsigned long long *acc, const double v, int &err)
 {
-  if (!(fabs(v) < limit)) err |= 4;
-  atomicAdd(acc, (unsigned long long) __double_as_longlong(v + ONCE_MAGIC));
+  if (!(fabs(v) < ONCE_LIMIT)) err |= 4;
+  // the low word of bits(MAGIC) is zero: the 64-bit difference costs one 32-bit subtraction
+  atomicAdd(acc, (unsigned long long) (__double_as_longlong(v + ONCE_MAGIC) - __double_as_longlong(ONCE_MAGIC)));
 }
 
-// sum of the images: n * bits(MAGIC) + sum of round(v * 2^34); bits(MAGIC) is a multiple of 2^51, so the low 51
-// bits hold the signed sum (|sum| < 2^50 by the term limit)
-__device__ __forceinline__ double once_decode(const unsigned long long s)
-{
-  const long long n = ((long long) (s << 13)) >> 13;
-  return (double) n * ONCE_UNIT;
-}
+__device__ __forceinline__ double once_decode(const unsigned long long s) { return (double) (long long) s * ONCE_UNIT; }
 
-template <int STYLE, int TS, bool EV, bool LDS_TAB, bool FAST, int SLOTS, bool ONCE = false>
+// SCE (table_ucg_bethe): -1 = P.pseudo_flag decides at run time; 0 = pseudo-likelihood scores only (`pseudo yes`), the
+// full-SCE code and the per-row reciprocals it keeps in registers are compiled out; 1 = full SCE (`pseudo no`)
+template <int STYLE, int TS, bool EV, bool LDS_TAB, bool FAST, int SLOTS, bool ONCE = false, bool ONETYPE = false, int SCE = -1>
 __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, const AtomsDev A,
                                                            const ListDev Lst, double *evpart,
                                                            int *errflag)
@@ -129,8 +145,10 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
   const int na1 = P.n_actual + 1;
   const double kT = P.kT, rkT = P.rkT;
   const int kTp2 = P.kT_pow2;
+  const int pseudo_flag = SCE < 0 ? P.pseudo_flag : SCE;
   double ev[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int err = 0;
+  RangeTrack rtrack = range_track_init();
   const bool active = k < nlocal;
   double4 pk = make_double4(0, 0, 0, 0);
   int mk = 0;
@@ -191,7 +209,7 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
     // proven range keep the hardware division.
     double rk_i0 = 0.0, rk_i1 = 0.0, rk_j0 = 0.0, rk_j1 = 0.0;
     bool rk_ok = false;
-    if (STYLE == 1 && FAST) {
+    if (STYLE == 1 && FAST && pseudo_flag == 1) {
       rk_ok = !k_first_chempot && recip_ok(pk_as_i0) && recip_ok(pk_as_i1) && recip_ok(pk_as_j0) && recip_ok(pk_as_j1);
       if (rk_ok) {
         rk_i0 = 1.0 / pk_as_i0;
@@ -201,11 +219,13 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
       }
     }
 
-    // one actual type (the usual UCG deck): cutoff and table ids are the same for every pair
-    const bool onetype = (P.n_actual == 1);
-    const double cut11 = s_cutsq[na1 + 1];
-    const int pt11_0 = s_pairtab[(na1 + 1) * 4 + 0], pt11_1 = s_pairtab[(na1 + 1) * 4 + 1];
-    const int pt11_2 = s_pairtab[(na1 + 1) * 4 + 2], pt11_3 = s_pairtab[(na1 + 1) * 4 + 3];
+    // one actual type (the usual UCG deck): cutoff and table ids are the same for every pair (ONETYPE: known at
+    // compile time, so they stay scalars)
+    const bool onetype = ONETYPE || (P.n_actual == 1);
+    // read through the kernel-argument pointers (uniform addresses: scalar loads, the values live in SGPRs)
+    const double cut11 = P.cutsq[na1 + 1];
+    const int pt11_0 = P.pairtab[(na1 + 1) * 4 + 0], pt11_1 = P.pairtab[(na1 + 1) * 4 + 1];
+    const int pt11_2 = P.pairtab[(na1 + 1) * 4 + 2], pt11_3 = P.pairtab[(na1 + 1) * 4 + 3];
 
     // two-stage software pipeline: while entry e is evaluated, the gather of entry e+SLOTS is in
     // flight and the list word of entry e+2*SLOTS is being fetched (no exposed index-load latency)
@@ -213,36 +233,15 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
     int ent_n = (slot + SLOTS < n) ? rp[rstep] : ent;
     double4 pm;
     int mm;
-    {
-      const int m0 = ent & 0x1FFFFFFF;
-      const unsigned ml = (unsigned) (m0 - k0);
-      if (ml < nown) {
-        pm = s_ownpos[ml];
-        mm = s_ownmeta[ml];
-      } else {
-        pm = A.pos4[m0];
-        mm = A.meta[m0];
-      }
-    }
+    gather_bead_split(A, s_ownpos, s_ownmeta, k0, nown, ent & 0x1FFFFFFF, pm, mm);
     const int sk = UCG_META_STATE(mk);
-    const double once_limit = P.once_limit;
     rp += rstep;
     for (int e = slot; e < n; e += SLOTS) {
       rp += rstep;
       const int ent_nn = (e + 2 * SLOTS < n) ? rp[0] : ent_n;
       double4 pm_n;
       int mm_n;
-      {
-        const int m1 = ent_n & 0x1FFFFFFF;
-        const unsigned ml = (unsigned) (m1 - k0);
-        if (ml < nown) {
-          pm_n = s_ownpos[ml];
-          mm_n = s_ownmeta[ml];
-        } else {
-          pm_n = A.pos4[m1];
-          mm_n = A.meta[m1];
-        }
-      }
+      gather_bead_split(A, s_ownpos, s_ownmeta, k0, nown, ent_n & 0x1FFFFFFF, pm_n, mm_n);
 
       const int m = ent & 0x1FFFFFFF;
       const bool k_is_i = (ent >> 29) & 1;
@@ -268,11 +267,11 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
           pt[0] = ps[0]; pt[1] = ps[1]; pt[2] = ps[2]; pt[3] = ps[3];
         }
         Quad q;
-        if (LDS_TAB) eval_quad<TS, FAST>(s_tab, s_par, pt, P.tablength, P.tlm1, P.fast_stride, rsq, factor_lj, q, err);
-        else eval_quad<TS, FAST>(FAST ? P.tab_fast : P.tab, s_par, pt, P.tablength, P.tlm1, P.fast_stride, rsq, factor_lj, q, err);
+        if (LDS_TAB) eval_quad<TS, FAST>(s_tab, s_par, pt, P.tablength, P.tlm1, P.fast_stride, rsq, factor_lj, q, err, rtrack);
+        else eval_quad<TS, FAST>(FAST ? P.tab_fast : P.tab, s_par, pt, P.tablength, P.tlm1, P.fast_stride, rsq, factor_lj, q, err, rtrack);
 
         double evdwl = 0.0, fpair;
-        if (STYLE == 0 || P.pseudo_flag == 0) {
+        if (STYLE == 0 || pseudo_flag == 0) {
           // pseudo-likelihood scores (:492-502): S[k][a] -= u[a][state of the neighbour] / kT
           const double ua = sm ? q.u01 : q.u00, ub = sm ? q.u11 : q.u10;
           if (FAST) {
@@ -305,12 +304,12 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
               // the partner's side of this pair: the transposed quad (u'[a][b] = u[b][a]) with lambda_k as the
               // neighbour's weight and this bead's state selecting the score terms; minus the same force
               unsigned long long *ap = s_acc + ml;
-              once_add(ap, -(dx * fpair), once_limit, err);
-              once_add(ap + ONCE_BEADS, -(dy * fpair), once_limit, err);
-              once_add(ap + 2 * ONCE_BEADS, -(dz * fpair), once_limit, err);
-              once_add(ap + 3 * ONCE_BEADS, -(lk * (q.u11 - q.u10) + (1. - lk) * (q.u01 - q.u00)), once_limit, err);
-              once_add(ap + 4 * ONCE_BEADS, -div_kT(sk ? q.u10 : q.u00, kT, rkT, kTp2), once_limit, err);
-              once_add(ap + 5 * ONCE_BEADS, -div_kT(sk ? q.u11 : q.u01, kT, rkT, kTp2), once_limit, err);
+              once_add(ap, -(dx * fpair), err);
+              once_add(ap + ONCE_BEADS, -(dy * fpair), err);
+              once_add(ap + 2 * ONCE_BEADS, -(dz * fpair), err);
+              once_add(ap + 3 * ONCE_BEADS, -(lk * (q.u11 - q.u10) + (1. - lk) * (q.u01 - q.u00)), err);
+              once_add(ap + 4 * ONCE_BEADS, -div_kT(sk ? q.u10 : q.u00, kT, rkT, kTp2), err);
+              once_add(ap + 5 * ONCE_BEADS, -div_kT(sk ? q.u11 : q.u01, kT, rkT, kTp2), err);
               if (EV) {  // the pair is seen once: its whole energy and virial (two halves elsewhere)
                 ev[0] += 0.5 * evdwl;
                 ev[1] += 0.5 * (dx * dx * fpair);
@@ -361,8 +360,8 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
           double Jij = q.u11 + q.u00 - cu01 - cu10;
           if ((FAST ? div_kT(Jij, kT, rkT, kTp2) : Jij / kT) < -709.0) Jij = -700.0 * kT;
           const double mJkT = FAST ? div_kT(-Jij, kT, rkT, kTp2) : -Jij / kT;
-          const double bij = ucg_exp(mJkT);
-          const double aij = ucg_expm1(mJkT);
+          double bij, aij;
+          ucg_exp_expm1(mJkT, &bij, &aij);  // = ucg_exp, ucg_expm1 bit for bit: one argument reduction, no k branches
           const double Qij = (pi1 + pj1) * aij + 1.;
           double Dij = Qij * Qij - 4. * aij * bij * pi1 * pj1;
           Dij = (Dij > 0.0) ? Dij : 0.0;
@@ -377,7 +376,7 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
           const double pij00 = 1. + pij11 - pi1 - pj1;
           const double pij10 = pi1 - pij11;
           const double pij01 = pj1 - pij11;
-          if (P.pseudo_flag == 1) {
+          if (pseudo_flag == 1) {
             // full-SCE scores exactly as shipped (:583-601)
             if (FAST && rk_ok) {
               // same quotients; the row bead's priors are pi when it is "i" and pj when it is "j"
@@ -540,6 +539,7 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
       }
     }
   }
+  if (FAST) err |= range_flags(s_par[0], P.tlm1, rtrack);
   if (err) atomicOr(errflag, err);
   if (EV) block_sum_store<8>(ev, s_red, evpart);
 }
@@ -595,9 +595,35 @@ hipError_t launch_style_ts(const PairDev &P, const AtomsDev &A, const ListDev &L
                                  : (size_t) P.ntab * P.tablength * sizeof(double4);
   const size_t ownbytes = P.stage_own ? (size_t) (PAIR_BLOCK / SLOTS) * (sizeof(double4) + sizeof(int)) : 0;
   const size_t ldsbytes = (P.tab_in_lds ? tabbytes : 0) + ownbytes;
+  if (L.once_beads) {
+    // rows built for the ONCE variant can only be swept by it (own-block pairs are in one row only)
+    if constexpr (STYLE == 0 && SLOTS == 2) {
+      if (L.once_beads != ONCE_BEADS || !P.tab_in_lds || !P.fast || !P.stage_own) return hipErrorInvalidValue;
+      const size_t lds = ldsbytes + (size_t) 6 * ONCE_BEADS * sizeof(unsigned long long);
+      if (lds + 4608 > 160 * 1024) return hipErrorInvalidValue;
+      auto kern = ev ? k_pair_gather<STYLE, TS, true, true, true, 2, true> : k_pair_gather<STYLE, TS, false, true, true, 2, true>;
+      if (P.n_actual == 1)
+        kern = ev ? k_pair_gather<STYLE, TS, true, true, true, 2, true, true> : k_pair_gather<STYLE, TS, false, true, true, 2, true, true>;
+      hipError_t e = hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(kern, dim3(nblocks), dim3(PAIR_BLOCK), lds, st, P, A, L, evpart, errflag);
+      return hipGetLastError();
+    } else {
+      return hipErrorInvalidValue;
+    }
+  }
 #define UCG_LAUNCH(EVF, LDSF, FASTF)                                                                   \
   do {                                                                                                 \
     auto kern = k_pair_gather<STYLE, TS, EVF, LDSF, FASTF, SLOTS>;                                     \
+    if constexpr (LDSF && FASTF && SLOTS <= 2) {                                                       \
+      if constexpr (STYLE == 1) {                                                                      \
+        if (P.n_actual == 1)                                                                           \
+          kern = P.pseudo_flag ? k_pair_gather<STYLE, TS, EVF, LDSF, FASTF, SLOTS, false, true, 1>     \
+                               : k_pair_gather<STYLE, TS, EVF, LDSF, FASTF, SLOTS, false, true, 0>;    \
+      } else if (P.n_actual == 1) {                                                                    \
+        kern = k_pair_gather<STYLE, TS, EVF, LDSF, FASTF, SLOTS, false, true>;                         \
+      }                                                                                                \
+    }                                                                                                  \
     if (ldsbytes > 48 * 1024) {                                                                        \
       hipError_t e = hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                          (int) ldsbytes);                                              \

@@ -59,6 +59,27 @@ __device__ __forceinline__ int grid_locate(const double4 par, const int tlm1, co
   return it;
 }
 
+// the same for the FAST kernels (one shared grid): instead of two compares and flag updates per pair they keep the
+// smallest r^2 and the largest raw knot index seen, and the two range tests are made once per row (range_flags)
+struct RangeTrack {
+  double rsq_min;
+  int it_max;
+};
+__device__ __forceinline__ RangeTrack range_track_init() { return RangeTrack{1.0e300, -1}; }
+__device__ __forceinline__ int grid_locate_track(const double4 par, const int tlm1, const double rsq, RangeTrack &rt)
+{
+  rt.rsq_min = fmin(rt.rsq_min, rsq);
+  const int raw = static_cast<int>((rsq - par.x) * par.z);
+  rt.it_max = max(rt.it_max, raw);
+  int it = min(raw, tlm1 - 1);
+  if (it < 0) it = 0;
+  return it;
+}
+__device__ __forceinline__ int range_flags(const double4 par, const int tlm1, const RangeTrack &rt)
+{
+  return (rt.rsq_min < par.x ? 1 : 0) | (rt.it_max >= tlm1 ? 2 : 0);
+}
+
 struct Basis {
   double a, b, a3, b3;  // SPLINE: a, b, a^3-a, b^3-b ; LINEAR: b = fraction
 };
@@ -152,12 +173,12 @@ __device__ __forceinline__ void table_eval(TabPtr tab, const double4 par, const 
 template <int TS, bool FAST, typename TabPtr>
 __device__ __forceinline__ void eval_quad(TabPtr tab, const double4 *s_par, const int *pt, const int tablength,
                                           const int tlm1, const int fast_stride, const double rsq,
-                                          const double factor_lj, Quad &q, int &err)
+                                          const double factor_lj, Quad &q, int &err, RangeTrack &rt)
 {
   const int t00 = pt[0], t01 = pt[1], t10 = pt[2], t11 = pt[3];
   if (FAST) {
     const double4 par = s_par[0];
-    const int it = grid_locate(par, tlm1, rsq, err);
+    const int it = grid_locate_track(par, tlm1, rsq, rt);
     const Basis B = grid_basis<TS>(par, it, rsq);
     const double2 *rec = reinterpret_cast<const double2 *>(tab) + it * fast_stride;
     knot_eval_fast<TS>(rec + 2 * t00, fast_stride, par.w, B, q.f00, q.u00);

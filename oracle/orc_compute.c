@@ -291,6 +291,16 @@ int orc_pair_compute_half(orc_pair *p, orc_atoms *a, const orc_list *l, int newt
   return ev->err ? 2 : 0;
 }
 
+/* pair_once: image of one term in units of 2^-40 (round to nearest even, as the double addition does) */
+static long long once_image(const orc_pair *p, double v, orc_ev *ev)
+{
+  union { double d; long long i; } t, m;
+  if (!(fabs(v) < p->once_limit)) ev->err |= 4;
+  t.d = v + ORC_ONCE_MAGIC;
+  m.d = ORC_ONCE_MAGIC;
+  return t.i - m.i;
+}
+
 int orc_pair_compute_gather(orc_pair *p, orc_atoms *a, const orc_list *l, int eflag, int vflag,
                             orc_ev *ev)
 {
@@ -298,7 +308,16 @@ int orc_pair_compute_gather(orc_pair *p, orc_atoms *a, const orc_list *l, int ef
   const int nall = a->nlocal + a->nghost;
   const double kT = p->kT;
   const double *x = a->x;
+  const int B = p->once_block;
+  long long *acc = NULL; /* pair_once: six integer accumulators per owned bead */
   memset(ev, 0, sizeof(*ev));
+  if (B > 0) {
+    if (p->style != ORC_STYLE_UCGLD) {
+      strcpy(p->errmsg, "pair_once order is defined for table_ucgld");
+      return 1;
+    }
+    acc = (long long *) calloc((size_t) a->nlocal * 6 + 1, sizeof(long long));
+  }
   if (p->style == ORC_STYLE_BETHE_DENSITY) {
     strcpy(p->errmsg, "use orc_pair_density_compute for table_ucg_bethe_density");
     return 1;
@@ -338,8 +357,19 @@ int orc_pair_compute_gather(orc_pair *p, orc_atoms *a, const orc_list *l, int ef
     }
 
     sfx[0] = fx; sfy[0] = fy; sfz[0] = fz; suf[0] = uf; ss0[0] = s0; ss1[0] = s1;
+    int ekept = 0; /* position in the row as the library stores it (pair_once rows lack the dropped entries) */
     for (int e = 0; e < n; e++) {
-      const int slot = e % S;
+      int own_pair = 0;
+      if (B > 0) {
+        const int mm = row[e] & ORC_NEIGHMASK;
+        if (mm < a->nlocal && k / B == mm / B) {
+          const int k_keeps = (k < mm) != (((k + mm) & 1) != 0);
+          if (!k_keeps) continue; /* swept from the partner's row */
+          own_pair = 1;
+        }
+      }
+      const int slot = ekept % S;
+      ekept++;
       fx = sfx[slot]; fy = sfy[slot]; fz = sfz[slot]; uf = suf[slot]; s0 = ss0[slot]; s1 = ss1[slot];
       int m = row[e];
       const int k_is_i = (m >> ORC_ORIENT_BIT) & 1;
@@ -424,6 +454,39 @@ int orc_pair_compute_gather(orc_pair *p, orc_atoms *a, const orc_list *l, int ef
           v_acc[4] += 0.5 * (delx * delz * fpair);
           v_acc[5] += 0.5 * (dely * delz * fpair);
         }
+        if (own_pair) {
+          /* pair_once: this row is the only one holding the pair; what the half-list sweep adds to the partner m
+             (UCG/pair_table_ucgld.cpp:500-502 / :492-498, :514-517, :523-530) goes to m's integer accumulators */
+          long long *am = acc + (size_t) m * 6;
+          double ufm, sm0, sm1;
+          if (k_is_i) { /* m is "j" */
+            am[0] += once_image(p, -(delx * fpair), ev);
+            am[1] += once_image(p, -(dely * fpair), ev);
+            am[2] += once_image(p, -(delz * fpair), ev);
+            ufm = ldi * (u11 - u10) + (1. - ldi) * (u01 - u00);
+            sm0 = q.u[istate][0] / kT;
+            sm1 = q.u[istate][1] / kT;
+          } else { /* m is "i" */
+            am[0] += once_image(p, delx * fpair, ev);
+            am[1] += once_image(p, dely * fpair, ev);
+            am[2] += once_image(p, delz * fpair, ev);
+            ufm = ldj * (u11 - u01) + (1. - ldj) * (u10 - u00);
+            sm0 = q.u[0][jstate] / kT;
+            sm1 = q.u[1][jstate] / kT;
+          }
+          am[3] += once_image(p, -ufm, ev);
+          am[4] += once_image(p, -sm0, ev);
+          am[5] += once_image(p, -sm1, ev);
+          if (eflag) e_acc += 0.5 * evdwl;
+          if (vflag) {
+            v_acc[0] += 0.5 * (delx * delx * fpair);
+            v_acc[1] += 0.5 * (dely * dely * fpair);
+            v_acc[2] += 0.5 * (delz * delz * fpair);
+            v_acc[3] += 0.5 * (delx * dely * fpair);
+            v_acc[4] += 0.5 * (delx * delz * fpair);
+            v_acc[5] += 0.5 * (dely * delz * fpair);
+          }
+        }
       }
       sfx[slot] = fx; sfy[slot] = fy; sfz[slot] = fz; suf[slot] = uf; ss0[slot] = s0; ss1[slot] = s1;
     }
@@ -441,6 +504,19 @@ int orc_pair_compute_gather(orc_pair *p, orc_atoms *a, const orc_list *l, int ef
     a->scores[2 * k + 1] = s1;
     ev->eng_vdwl += e_acc;
     for (int c = 0; c < 6; c++) ev->virial[c] += v_acc[c];
+  }
+  if (acc) {
+    for (int ii = 0; ii < l->inum; ii++) {
+      const int k = l->ilist[ii];
+      const long long *ak = acc + (size_t) k * 6;
+      a->f[3 * k + 0] += (double) ak[0] * ORC_ONCE_UNIT;
+      a->f[3 * k + 1] += (double) ak[1] * ORC_ONCE_UNIT;
+      a->f[3 * k + 2] += (double) ak[2] * ORC_ONCE_UNIT;
+      a->ucgforce[k] += (double) ak[3] * ORC_ONCE_UNIT;
+      a->scores[2 * k + 0] += (double) ak[4] * ORC_ONCE_UNIT;
+      a->scores[2 * k + 1] += (double) ak[5] * ORC_ONCE_UNIT;
+    }
+    free(acc);
   }
   return ev->err ? 2 : 0;
 }
