@@ -369,11 +369,11 @@ def main():
         if "MASTER_ADDR" not in os.environ:
             os.environ["MASTER_ADDR"] = "127.0.0.1"
             os.environ.setdefault("MASTER_PORT", "29533")
-        if shared:
-            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device_index))
+        # torch.distributed (gloo) only carries the rendezvous, the barriers around the timed region and rank 0's
+        # RCCL id; the halo itself is moved by the library (RCCL called from its C++ step loop), or -- ranks sharing
+        # a GPU -- by host-staged gloo callbacks
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     pkg = entry.load_package()
     capi = pkg.capi

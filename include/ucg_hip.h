@@ -35,7 +35,8 @@ enum {
   UCG_ERR_TABLE_INNER = 4,  /* "Pair distance < table inner cutoff"  (ucgld.cpp:437-439) */
   UCG_ERR_TABLE_OUTER = 5,  /* "Pair distance > table outer cutoff"  (ucgld.cpp:442-444) */
   UCG_ERR_UNSUPPORTED = 6,  /* feature the GPU path does not cover (e.g. prior noise) */
-  UCG_ERR_NEIGH_OVERFLOW = 7
+  UCG_ERR_NEIGH_OVERFLOW = 7,
+  UCG_ERR_COMM = 8          /* communicator failure of a decomposed run (RCCL / caller's callbacks) */
 };
 
 enum { UCG_STYLE_UCGLD = 0, UCG_STYLE_BETHE = 1, UCG_STYLE_BETHE_DENSITY = 2 };
@@ -232,6 +233,39 @@ int ucg_halo_unpack(ucg_ctx *ctx, const void *recvbuf);
 int ucg_halo_aux_pack(ucg_ctx *ctx, const void *field_dev, void *sendbuf);
 int ucg_halo_aux_unpack(ucg_ctx *ctx, void *field_dev, const void *recvbuf);
 int ucg_decide_local(ucg_ctx *ctx, int *due, int *flag);
+
+/* ------------------------------------------------- communicator of a decomposed run
+ * With a communicator attached, ucg_md_setup / ucg_md_run drive the whole rank-level step loop inside the library
+ * (csrc/ucg_comm.hip): exchange / borders at a re-neighbouring, one forward halo per step, the density style's two
+ * mid-compute halos, the MPI_Allreduce steps of Neighbor::decide and of fix cluster_switch, the thermo all-reduce --
+ * what upstream CommBrick + Verlet do around the styles of this package.  Two kinds of communicator:
+ *   ucg_comm_attach_rccl   built in: RCCL called directly on the context's stream (grouped ncclSend / ncclRecv to the
+ *                          <= 7 peers, ncclAllReduce for the small host reductions); the caller only distributes the
+ *                          128-byte id of rank 0 (ucg_comm_rccl_unique_id) -- MPI_Bcast in a LAMMPS build;
+ *   ucg_comm_attach        the caller's callbacks (MPI in a LAMMPS build without RCCL, gloo in the tests):
+ *     alltoallv      DEVICE buffers; sendbytes[r] bytes for rank r lie in consecutive blocks of `send` in rank
+ *                    order, the block received from rank r goes to `recv` in rank order; must be ordered after the
+ *                    work queued on `stream` (a hipStream_t) and complete, or be ordered on it, on return
+ *     alltoall_ll    host arrays, one long long per rank each way, blocking
+ *     allreduce_ll / allreduce_f64   host arrays of n elements, in place, blocking; op 0 = sum, 1 = max, 2 = min
+ * Callbacks return 0 on success.  fix cluster_switch on a decomposed run: create it on every rank after the beads
+ * and molecule ids are uploaded; the library performs its reductions at the next ucg_md_setup. */
+typedef struct ucg_comm_ops {
+  void *user;
+  int rank, world;
+  int (*alltoallv)(void *user, const void *send, const long long *sendbytes, void *recv, const long long *recvbytes,
+                   void *stream);
+  int (*alltoall_ll)(void *user, const long long *send, long long *recv);
+  int (*allreduce_ll)(void *user, long long *buf, int n, int op);
+  int (*allreduce_f64)(void *user, double *buf, int n, int op);
+} ucg_comm_ops;
+typedef struct ucg_rccl_id { char internal[128]; } ucg_rccl_id; /* = ncclUniqueId */
+int ucg_comm_attach(ucg_ctx *ctx, const ucg_comm_ops *ops);
+int ucg_comm_rccl_unique_id(ucg_rccl_id *out);
+int ucg_comm_attach_rccl(ucg_ctx *ctx, const ucg_rccl_id *id, int rank, int world);
+int ucg_comm_detach(ucg_ctx *ctx);
+int ucg_comm_info(const ucg_ctx *ctx, int *rank, int *world, int *is_rccl, long long *nrebuild);
+int ucg_comm_allreduce_f64(ucg_ctx *ctx, double *buf, int n, int op);
 
 /* ---------------------------------------------------------------- fix nve/ucgld
  * replaces FixNVE_UCGLD::initial_integrate / final_integrate

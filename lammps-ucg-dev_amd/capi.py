@@ -58,7 +58,24 @@ SYMBOLS = [
     "ucg_ranmars_fill",
     "ucg_md_attach", "ucg_md_post_fused", "ucg_md_pair_post", "ucg_md_setup", "ucg_md_run", "ucg_md_info", "ucg_md_thermo",
     "ucg_profile_enable", "ucg_profile_read",
+    "ucg_comm_attach", "ucg_comm_rccl_unique_id", "ucg_comm_attach_rccl", "ucg_comm_detach", "ucg_comm_info",
+    "ucg_comm_allreduce_f64",
 ]
+
+# communicator callbacks of a decomposed run (include/ucg_hip.h: ucg_comm_ops)
+CB_ALLTOALLV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_longlong), C.c_void_p, C.POINTER(C.c_longlong), C.c_void_p)
+CB_ALLTOALL_LL = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong))
+CB_ALLREDUCE_LL = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_longlong), C.c_int, C.c_int)
+CB_ALLREDUCE_F64 = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int)
+
+
+class CommOps(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("rank", C.c_int), ("world", C.c_int), ("alltoallv", CB_ALLTOALLV),
+                ("alltoall_ll", CB_ALLTOALL_LL), ("allreduce_ll", CB_ALLREDUCE_LL), ("allreduce_f64", CB_ALLREDUCE_F64)]
+
+
+class RcclId(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]
 
 
 class UcgError(RuntimeError):
@@ -190,6 +207,12 @@ def lib():
     L.ucg_md_thermo.argtypes = [vp, c_double_p]
     L.ucg_profile_enable.argtypes = [vp, C.c_int]
     L.ucg_profile_read.argtypes = [vp, c_ll_p, c_double_p, C.c_int]
+    L.ucg_comm_attach.argtypes = [vp, C.POINTER(CommOps)]
+    L.ucg_comm_rccl_unique_id.argtypes = [C.POINTER(RcclId)]
+    L.ucg_comm_attach_rccl.argtypes = [vp, C.POINTER(RcclId), C.c_int, C.c_int]
+    L.ucg_comm_detach.argtypes = [vp]
+    L.ucg_comm_info.argtypes = [vp, c_int_p, c_int_p, c_int_p, c_ll_p]
+    L.ucg_comm_allreduce_f64.argtypes = [vp, c_double_p, C.c_int, C.c_int]
     _LIB = L
     return L
 
@@ -587,6 +610,38 @@ class Context:
         out = np.zeros(9)
         self.chk(self.L.ucg_md_thermo(self.h, _dp(out)))
         return dict(eng_vdwl=out[0], virial=out[1:7].copy(), lambda_temp=out[7], state1=out[8])
+
+    # ---- communicator of a decomposed run (the rank-level step loop then runs inside ucg_md_setup / ucg_md_run)
+    def comm_attach(self, rank, world, alltoallv, alltoall_ll, allreduce_ll, allreduce_f64):
+        """caller-provided transport: Python callables wrapped as the C callbacks of ucg_comm_ops"""
+        self._comm_cbs = (CB_ALLTOALLV(alltoallv), CB_ALLTOALL_LL(alltoall_ll), CB_ALLREDUCE_LL(allreduce_ll),
+                          CB_ALLREDUCE_F64(allreduce_f64))  # keep them alive as long as the context
+        self._comm_ops = CommOps(None, int(rank), int(world), *self._comm_cbs)
+        self.chk(self.L.ucg_comm_attach(self.h, C.byref(self._comm_ops)))
+
+    @staticmethod
+    def rccl_unique_id():
+        rid = RcclId()
+        if lib().ucg_comm_rccl_unique_id(C.byref(rid)):
+            raise UcgError(8, "ncclGetUniqueId failed (librccl not loadable?)")
+        return bytes(rid)
+
+    def comm_attach_rccl(self, id_bytes, rank, world):
+        rid = RcclId.from_buffer_copy(id_bytes)
+        self.chk(self.L.ucg_comm_attach_rccl(self.h, C.byref(rid), int(rank), int(world)))
+
+    def comm_detach(self):
+        self.chk(self.L.ucg_comm_detach(self.h))
+
+    def comm_info(self):
+        r, w, k, n = C.c_int(0), C.c_int(0), C.c_int(0), C.c_longlong(0)
+        self.chk(self.L.ucg_comm_info(self.h, C.byref(r), C.byref(w), C.byref(k), C.byref(n)))
+        return dict(rank=r.value, world=w.value, rccl=bool(k.value), nrebuild=n.value)
+
+    def comm_allreduce_sum(self, values):
+        a = _f64(values).copy()
+        self.chk(self.L.ucg_comm_allreduce_f64(self.h, _dp(a), len(a), 0))
+        return a
 
     # ---- measurement
     def profile_enable(self, on=True):

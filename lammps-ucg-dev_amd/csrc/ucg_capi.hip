@@ -149,6 +149,7 @@ void ucg_ctx_destroy(ucg_ctx *ctx)
   if (!ctx) return;
   (void) hipStreamSynchronize(ctx->stream);
   for (auto ev : ctx->prof_ev) (void) hipEventDestroy(ev);
+  comm_destroy(ctx);
   domain_destroy(ctx);
   cluster_destroy(ctx);
   if (ctx->own_stream && ctx->stream) (void) hipStreamDestroy(ctx->stream);

@@ -1,0 +1,557 @@
+// ucg_comm.hip -- decomposed runs behind the C ABI: the communicator and the rank-level Verlet step loop.
+//
+// What it replaces: upstream CommBrick::exchange / borders / forward_comm driven by the field lists of
+// UCG/atom_vec_ucg.cpp:66-82, Neighbor::decide's MPI_Allreduce of the "a bead moved too far" flag, the mid-compute
+// forward_comm of table_ucg_bethe_density (UCG/pair_table_ucg_bethe_density.cpp:280, a no-op as shipped) and the
+// MPI_Allreduce steps of fix cluster_switch (UCG/fix_cluster_switch.cpp:114-120, 157-158, 587, 664, 750).
+//
+// One process per GPU.  The device work (count / pack / unpack, rebuild, forces, fixes) is the single-rank
+// library's; this file only sequences it and moves the packed buffers through a communicator:
+//   * built in: RCCL, called directly (ncclGroupStart; one ncclSend + ncclRecv per peer with bytes to move;
+//     ncclGroupEnd on the context's stream) -- with 2 bricks per periodic dimension the 26 neighbour directions
+//     fold onto the 7 other ranks, i.e. exactly the point-to-point xGMI links.  librccl is loaded at run time
+//     (dlopen), so the library does not depend on it for single-GPU use;
+//   * or caller-provided callbacks (ucg_comm_ops): MPI in a LAMMPS build, gloo in the tests that put two ranks
+//     on one GPU (RCCL refuses two ranks per device).
+// Small host-side reductions (per-peer counts at a re-neighbouring, the decision flag every `every` steps, the
+// per-molecule arrays of fix cluster_switch) go through the same communicator.
+#include <dlfcn.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ucg_hip.h"
+#include "ucg_ctx.h"
+
+namespace ucg {
+
+// the few RCCL entry points used, resolved with dlsym (types as in rccl.h; ncclComm_t is an opaque pointer)
+struct Rccl {
+  void *lib = nullptr;
+  int (*GetUniqueId)(void *id) = nullptr;
+  int (*CommInitRank)(void **comm, int nranks, ucg_rccl_id id, int rank) = nullptr;
+  int (*CommDestroy)(void *comm) = nullptr;
+  int (*Send)(const void *buf, size_t count, int dtype, int peer, void *comm, hipStream_t st) = nullptr;
+  int (*Recv)(void *buf, size_t count, int dtype, int peer, void *comm, hipStream_t st) = nullptr;
+  int (*AllReduce)(const void *s, void *r, size_t count, int dtype, int op, void *comm, hipStream_t st) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+  std::string err;
+  bool load()
+  {
+    if (lib) return true;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (lib) break;
+    }
+    if (!lib) {
+      err = "librccl.so.1 could not be loaded";
+      return false;
+    }
+#define UCG_SYM(field, sym)                                         \
+  field = reinterpret_cast<decltype(field)>(dlsym(lib, sym));      \
+  if (!field) {                                                     \
+    err = std::string("librccl lacks ") + sym;                      \
+    return false;                                                   \
+  }
+    UCG_SYM(GetUniqueId, "ncclGetUniqueId");
+    UCG_SYM(CommInitRank, "ncclCommInitRank");
+    UCG_SYM(CommDestroy, "ncclCommDestroy");
+    UCG_SYM(Send, "ncclSend");
+    UCG_SYM(Recv, "ncclRecv");
+    UCG_SYM(AllReduce, "ncclAllReduce");
+    UCG_SYM(GroupStart, "ncclGroupStart");
+    UCG_SYM(GroupEnd, "ncclGroupEnd");
+    UCG_SYM(GetErrorString, "ncclGetErrorString");
+#undef UCG_SYM
+    return true;
+  }
+};
+static Rccl g_rccl;
+// rccl.h: ncclInt8 = 0 (ncclChar), ncclInt64 = 4, ncclFloat64 = 8; ncclSum = 0, ncclMax = 2, ncclMin = 3
+enum { NCCL_CHAR = 0, NCCL_INT64 = 4, NCCL_F64 = 8, NCCL_SUM = 0, NCCL_MAX = 2, NCCL_MIN = 3 };
+
+struct CommState {
+  bool attached = false, rccl = false;
+  int rank = 0, world = 1;
+  ucg_comm_ops ops{};
+  void *nccl = nullptr;
+  DevBuf<char> send, recv, auxsend, auxrecv;
+  DevBuf<long long> dsmall;  // device staging of small host messages on the RCCL transport
+  std::vector<long long> halo_send, halo_recv;  // per-peer ghost counts of the last border exchange
+  long long nsend = 0, nrecv = 0;
+  long long nrebuild = 0;
+  bool cluster_synced = false;
+};
+
+void comm_destroy(ucg_ctx *ctx)
+{
+  if (!ctx->comm) return;
+  if (ctx->comm->nccl && g_rccl.CommDestroy) (void) g_rccl.CommDestroy(ctx->comm->nccl);
+  delete ctx->comm;
+  ctx->comm = nullptr;
+}
+
+namespace {
+
+struct CommFailure {
+  std::string msg;
+};
+
+void nccl_check(int rc, const char *what)
+{
+  if (rc != 0) throw CommFailure{std::string("RCCL error in ") + what + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?")};
+}
+
+void cb_check(int rc, const char *what)
+{
+  if (rc != 0) throw CommFailure{std::string("communicator callback failed: ") + what};
+}
+
+// device buffers, `sendbytes[r]` bytes to rank r taken from consecutive blocks of `send` (rank order), received
+// blocks land in `recv` in rank order; ordered on the context's stream
+void alltoallv(ucg_ctx *ctx, const void *send, const long long *sendbytes, void *recv, const long long *recvbytes)
+{
+  CommState &C = *ctx->comm;
+  if (!C.rccl) {
+    cb_check(C.ops.alltoallv(C.ops.user, send, sendbytes, recv, recvbytes, (void *) ctx->stream), "alltoallv");
+    return;
+  }
+  nccl_check(g_rccl.GroupStart(), "ncclGroupStart");
+  long long so = 0, ro = 0;
+  for (int r = 0; r < C.world; r++) {
+    if (sendbytes[r] > 0)
+      nccl_check(g_rccl.Send((const char *) send + so, (size_t) sendbytes[r], NCCL_CHAR, r, C.nccl, ctx->stream), "ncclSend");
+    if (recvbytes[r] > 0)
+      nccl_check(g_rccl.Recv((char *) recv + ro, (size_t) recvbytes[r], NCCL_CHAR, r, C.nccl, ctx->stream), "ncclRecv");
+    so += sendbytes[r];
+    ro += recvbytes[r];
+  }
+  nccl_check(g_rccl.GroupEnd(), "ncclGroupEnd");
+}
+
+// one long long per peer, host arrays, blocking
+void alltoall_counts(ucg_ctx *ctx, const long long *send, long long *recv)
+{
+  CommState &C = *ctx->comm;
+  if (!C.rccl) {
+    cb_check(C.ops.alltoall_ll(C.ops.user, send, recv), "alltoall_ll");
+    return;
+  }
+  const size_t w = (size_t) C.world;
+  C.dsmall.reserve(2 * w + 8);
+  UCG_HIP(hipMemcpyAsync(C.dsmall.get(), send, w * sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
+  nccl_check(g_rccl.GroupStart(), "ncclGroupStart");
+  for (int r = 0; r < C.world; r++) {
+    nccl_check(g_rccl.Send(C.dsmall.get() + r, 1, NCCL_INT64, r, C.nccl, ctx->stream), "ncclSend");
+    nccl_check(g_rccl.Recv(C.dsmall.get() + w + r, 1, NCCL_INT64, r, C.nccl, ctx->stream), "ncclRecv");
+  }
+  nccl_check(g_rccl.GroupEnd(), "ncclGroupEnd");
+  UCG_HIP(hipMemcpyAsync(recv, C.dsmall.get() + w, w * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+  UCG_HIP(hipStreamSynchronize(ctx->stream));
+}
+
+// op: 0 sum, 1 max, 2 min
+void allreduce_ll(ucg_ctx *ctx, long long *buf, int n, int op)
+{
+  CommState &C = *ctx->comm;
+  if (n <= 0) return;
+  if (!C.rccl) {
+    cb_check(C.ops.allreduce_ll(C.ops.user, buf, n, op), "allreduce_ll");
+    return;
+  }
+  C.dsmall.reserve((size_t) n + 8);
+  UCG_HIP(hipMemcpyAsync(C.dsmall.get(), buf, (size_t) n * sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
+  nccl_check(g_rccl.AllReduce(C.dsmall.get(), C.dsmall.get(), (size_t) n, NCCL_INT64, op == 0 ? NCCL_SUM : op == 1 ? NCCL_MAX : NCCL_MIN,
+                              C.nccl, ctx->stream),
+             "ncclAllReduce");
+  UCG_HIP(hipMemcpyAsync(buf, C.dsmall.get(), (size_t) n * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+  UCG_HIP(hipStreamSynchronize(ctx->stream));
+}
+
+void allreduce_f64(ucg_ctx *ctx, double *buf, int n, int op)
+{
+  CommState &C = *ctx->comm;
+  if (n <= 0) return;
+  if (!C.rccl) {
+    cb_check(C.ops.allreduce_f64(C.ops.user, buf, n, op), "allreduce_f64");
+    return;
+  }
+  C.dsmall.reserve((size_t) n + 8);
+  UCG_HIP(hipMemcpyAsync(C.dsmall.get(), buf, (size_t) n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  nccl_check(g_rccl.AllReduce(C.dsmall.get(), C.dsmall.get(), (size_t) n, NCCL_F64, op == 0 ? NCCL_SUM : op == 1 ? NCCL_MAX : NCCL_MIN,
+                              C.nccl, ctx->stream),
+             "ncclAllReduce");
+  UCG_HIP(hipMemcpyAsync(buf, C.dsmall.get(), (size_t) n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  UCG_HIP(hipStreamSynchronize(ctx->stream));
+}
+
+void allreduce_int_array(ucg_ctx *ctx, std::vector<int> &a, int op)
+{
+  std::vector<long long> t(a.begin(), a.end());
+  allreduce_ll(ctx, t.data(), (int) t.size(), op);
+  for (size_t i = 0; i < a.size(); i++) a[i] = (int) t[i];
+}
+
+#define UCG_RC(call)            \
+  do {                          \
+    const int rc__ = (call);    \
+    if (rc__ != UCG_OK) return rc__; \
+  } while (0)
+
+long long sum(const std::vector<long long> &v)
+{
+  long long s = 0;
+  for (long long x : v) s += x;
+  return s;
+}
+
+// CommBrick::exchange + borders: every bead to the rank that owns its wrapped position, then the images every
+// rank's extended brick needs; afterwards bins and rows are rebuilt (ucg_border_unpack)
+int multi_rebuild(ucg_ctx *ctx)
+{
+  CommState &C = *ctx->comm;
+  const size_t w = (size_t) C.world;
+  int arec = 0, hrec = 0;
+  ucg_record_bytes(&arec, &hrec);
+  std::vector<long long> sc(w), rc(w), sb(w), rb(w);
+  UCG_RC(ucg_exchange_count(ctx, sc.data()));
+  alltoall_counts(ctx, sc.data(), rc.data());
+  for (size_t r = 0; r < w; r++) {
+    sb[r] = sc[r] * arec;
+    rb[r] = rc[r] * arec;
+  }
+  C.send.reserve((size_t) sum(sb) + 16);
+  C.recv.reserve((size_t) sum(rb) + 16);
+  UCG_RC(ucg_exchange_pack(ctx, C.send.get()));
+  alltoallv(ctx, C.send.get(), sb.data(), C.recv.get(), rb.data());
+  UCG_RC(ucg_exchange_unpack(ctx, C.recv.get(), sum(rc)));
+  UCG_RC(ucg_border_count(ctx, sc.data()));
+  alltoall_counts(ctx, sc.data(), rc.data());
+  for (size_t r = 0; r < w; r++) {
+    sb[r] = sc[r] * hrec;
+    rb[r] = rc[r] * hrec;
+  }
+  C.send.reserve((size_t) sum(sb) + 16);
+  C.recv.reserve((size_t) sum(rb) + 16);
+  UCG_RC(ucg_border_pack(ctx, C.send.get()));
+  alltoallv(ctx, C.send.get(), sb.data(), C.recv.get(), rb.data());
+  UCG_RC(ucg_border_unpack(ctx, C.recv.get(), sum(rc)));
+  C.halo_send = sc;
+  C.halo_recv = rc;
+  C.nsend = sum(sc);
+  C.nrecv = sum(rc);
+  if (ctx->cs) {  // ghosts' group bits and molecule ids, for fix cluster_switch
+    for (size_t r = 0; r < w; r++) {
+      sb[r] = sc[r] * 8;
+      rb[r] = rc[r] * 8;
+    }
+    C.auxsend.reserve((size_t) C.nsend * 8 + 16);
+    C.auxrecv.reserve((size_t) C.nrecv * 8 + 16);
+    UCG_RC(ucg_halo_molmask_pack(ctx, C.auxsend.get()));
+    alltoallv(ctx, C.auxsend.get(), sb.data(), C.auxrecv.get(), rb.data());
+    UCG_RC(ucg_halo_molmask_unpack(ctx, C.auxrecv.get()));
+  }
+  C.nrebuild++;
+  return UCG_OK;
+}
+
+// forward_comm: x (+ shift), lambda, ucgp, state of every ghost from its owner, with the send lists of the last
+// border exchange; the unpack of a step is ordered before the next step's transfer on the stream, so one pair of
+// buffers serves
+int multi_halo_forward(ucg_ctx *ctx)
+{
+  CommState &C = *ctx->comm;
+  const size_t w = (size_t) C.world;
+  int arec = 0, hrec = 0;
+  ucg_record_bytes(&arec, &hrec);
+  std::vector<long long> sb(w), rb(w);
+  for (size_t r = 0; r < w; r++) {
+    sb[r] = C.halo_send[r] * hrec;
+    rb[r] = C.halo_recv[r] * hrec;
+  }
+  UCG_RC(ucg_halo_pack(ctx, C.send.get()));
+  alltoallv(ctx, C.send.get(), sb.data(), C.recv.get(), rb.data());
+  UCG_RC(ucg_halo_unpack(ctx, C.recv.get()));
+  return UCG_OK;
+}
+
+// one double2 per ghost from its owner: the density style's priors (which = 0) and CV forces (which = 1)
+int multi_aux_halo(ucg_ctx *ctx, ucg_pair *p, int which)
+{
+  CommState &C = *ctx->comm;
+  const size_t w = (size_t) C.world;
+  std::vector<long long> sb(w), rb(w);
+  for (size_t r = 0; r < w; r++) {
+    sb[r] = C.halo_send[r] * 16;
+    rb[r] = C.halo_recv[r] * 16;
+  }
+  C.auxsend.reserve((size_t) C.nsend * 16 + 16);
+  C.auxrecv.reserve((size_t) C.nrecv * 16 + 16);
+  void *field = ucg_pair_density_buffer(p, which);
+  UCG_RC(ucg_halo_aux_pack(ctx, field, C.auxsend.get()));
+  alltoallv(ctx, C.auxsend.get(), sb.data(), C.auxrecv.get(), rb.data());
+  UCG_RC(ucg_halo_aux_unpack(ctx, field, C.auxrecv.get()));
+  return UCG_OK;
+}
+
+int multi_pair_compute(ucg_ctx *ctx, int ev)
+{
+  ucg_pair *p = ctx->md_pair;
+  double e = 0.0, vir[6] = {0, 0, 0, 0, 0, 0};
+  if (p->model.style != STYLE_BETHE_DENSITY) {
+    UCG_RC(ucg_pair_compute(p, ev, ev, ev ? &e : nullptr, ev ? vir : nullptr));
+  } else {
+    // table_ucg_bethe_density: its two mid-compute halos cross ranks
+    UCG_RC(ucg_pair_density_phase(p, 1, ev, ev, nullptr, nullptr));
+    UCG_RC(multi_aux_halo(ctx, p, 0));
+    UCG_RC(ucg_pair_density_phase(p, 2, ev, ev, nullptr, nullptr));
+    UCG_RC(multi_aux_halo(ctx, p, 1));
+    UCG_RC(ucg_pair_density_phase(p, 3, ev, ev, ev ? &e : nullptr, ev ? vir : nullptr));
+  }
+  if (ev) {  // thermo output: one all-reduce of {E_pair, virial[6]}; each rank keeps the totals
+    double t[7] = {e, vir[0], vir[1], vir[2], vir[3], vir[4], vir[5]};
+    allreduce_f64(ctx, t, 7, 0);
+    for (int c = 0; c < 7; c++) ctx->thermo[c] = t[c];
+  }
+  return UCG_OK;
+}
+
+// FixClusterSwitch across ranks: the reductions the reference does with MPI_Allreduce
+int multi_cluster_sync_after_create(ucg_ctx *ctx)
+{
+  long long s[3];
+  UCG_RC(ucg_fix_cluster_switch_scalars(ctx, s));
+  allreduce_ll(ctx, &s[0], 1, 1);
+  allreduce_ll(ctx, &s[1], 2, 0);
+  UCG_RC(ucg_fix_cluster_switch_set_scalars(ctx, s[0], s[1], s[2]));
+  const int n = ucg_fix_cluster_switch_maxmol(ctx) + 1;
+  std::vector<int> a((size_t) n);
+  for (int which : {1, 2, 4}) {  // mol_state, mol_restrict, presence
+    UCG_RC(ucg_fix_cluster_switch_array(ctx, which, a.data()));
+    allreduce_int_array(ctx, a, 1);
+    UCG_RC(ucg_fix_cluster_switch_set_array(ctx, which, a.data()));
+  }
+  ctx->comm->cluster_synced = true;
+  return UCG_OK;
+}
+
+// check_cluster + attempt_switch on fresh lists (UCG/fix_cluster_switch.cpp:452-469)
+int multi_cluster_step(ucg_ctx *ctx)
+{
+  const int n = ucg_fix_cluster_switch_maxmol(ctx) + 1;
+  std::vector<int> a((size_t) n);
+  int changed = 0;
+  UCG_RC(ucg_fix_cluster_switch_sweep(ctx, 1, &changed));
+  for (;;) {
+    UCG_RC(ucg_fix_cluster_switch_array(ctx, 5, a.data()));
+    allreduce_int_array(ctx, a, 2);
+    UCG_RC(ucg_fix_cluster_switch_set_array(ctx, 5, a.data()));
+    long long any = changed;
+    allreduce_ll(ctx, &any, 1, 1);
+    if (!any) break;
+    UCG_RC(ucg_fix_cluster_switch_sweep(ctx, 0, &changed));
+  }
+  UCG_RC(ucg_fix_cluster_switch_finalize(ctx));
+  UCG_RC(ucg_fix_cluster_switch_attempt_local(ctx));
+  UCG_RC(ucg_fix_cluster_switch_array(ctx, 3, a.data()));
+  allreduce_int_array(ctx, a, 1);
+  UCG_RC(ucg_fix_cluster_switch_set_array(ctx, 3, a.data()));
+  UCG_RC(ucg_fix_cluster_switch_attempt_apply(ctx));
+  UCG_RC(ucg_fix_cluster_switch_advance(ctx));
+  return multi_halo_forward(ctx);  // comm->forward_comm(this): the ghosts' new atom types
+}
+
+template <typename F>
+int guarded_comm(ucg_ctx *ctx, F &&fn)
+{
+  try {
+    return fn();
+  } catch (const CommFailure &e) {
+    ctx->err = e.msg;
+    return UCG_ERR_COMM;
+  } catch (const InputError &e) {
+    ctx->err = e.msg;
+    return UCG_ERR_INPUT;
+  } catch (const HipFailure &e) {
+    ctx->err = std::string("HIP error: ") + hipGetErrorString(e.code) + " in " + e.what;
+    return UCG_ERR_HIP;
+  } catch (const std::exception &e) {
+    ctx->err = e.what();
+    return UCG_ERR_INVALID;
+  }
+}
+
+int poll_pair_errors(ucg_ctx *ctx)
+{
+  // the sticky table-range flag of the pair kernels; every rank must take the same decision
+  int rc = ucg_pair_check_errors(ctx->md_pair);
+  long long worst = rc;
+  allreduce_ll(ctx, &worst, 1, 1);
+  if (rc == UCG_OK && worst != 0) {
+    ctx->err = "another rank reported a pair-table range error";
+    return (int) worst;
+  }
+  return rc;
+}
+
+}  // namespace
+
+// ---- the step loop of one rank (upstream Verlet::setup / run), called by ucg_md_setup / ucg_md_run
+int md_setup_multi(ucg_ctx *ctx)
+{
+  return guarded_comm(ctx, [&]() -> int {
+    if (ctx->cs && !ctx->comm->cluster_synced) UCG_RC(multi_cluster_sync_after_create(ctx));
+    UCG_RC(multi_rebuild(ctx));
+    if (ctx->md_lang && !ctx->lang.inited) {
+      // Fix_UCGLD_Langevin::init(): reads atom->ucgml[1..ntypes] of the LOCAL bead order (App. B #5)
+      std::vector<double> ml((size_t) ctx->ntypes + 1, 0.0);
+      const int cnt = ctx->ntypes + 1 <= ctx->nlocal ? ctx->ntypes + 1 : ctx->nlocal;
+      if (cnt > 0) {
+        UCG_HIP(hipMemcpyAsync(ml.data(), ctx->ucgml.get(), (size_t) cnt * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        UCG_HIP(hipStreamSynchronize(ctx->stream));
+      }
+      for (int i = cnt; i <= ctx->ntypes; i++) ml[(size_t) i] = cnt > 0 ? ml[0] : 1.0;
+      UCG_RC(ucg_fix_langevin_init_from_ucgml(ctx, ctx->ntypes, ml.data()));
+    }
+    UCG_RC(multi_pair_compute(ctx, 1));
+    if (ctx->md_lang) UCG_RC(ucg_fix_langevin_post_force(ctx, ctx->groupbit, ctx->ntimestep, ctx->beginstep, ctx->endstep));
+    if (ctx->md_ucgst) UCG_RC(ucg_fix_ucgstate_post_force(ctx));
+    return poll_pair_errors(ctx);
+  });
+}
+
+int md_run_multi(ucg_ctx *ctx, long long nsteps, int thermo_every)
+{
+  return guarded_comm(ctx, [&]() -> int {
+    ucg_pair *p = ctx->md_pair;
+    const bool density = p->model.style == STYLE_BETHE_DENSITY;
+    bool initial_done = false;
+    for (long long s = 0; s < nsteps; s++) {
+      ctx->ntimestep++;
+      const int ev = (thermo_every > 0 && (ctx->ntimestep % thermo_every == 0)) ? 1 : 0;
+      if (ctx->md_nve && !initial_done)
+        UCG_RC(ctx->md_nve == 2 ? ucg_fix_nve_wall_hard_initial(ctx, ctx->groupbit) : ucg_fix_nve_initial(ctx, ctx->groupbit));
+      int due = 0, flag = 0;
+      UCG_RC(ucg_decide_local(ctx, &due, &flag));
+      const bool fuse_next = ctx->md_nve && !ev && (s + 1 < nsteps) && !ctx->md_no_fuse;
+      bool rebuilt = false;
+      if (due) {  // Neighbor::decide(): MPI_Allreduce of the flag
+        long long f = flag;
+        allreduce_ll(ctx, &f, 1, 1);
+        rebuilt = f != 0;
+      }
+      if (rebuilt) {
+        UCG_RC(poll_pair_errors(ctx));  // the stream is drained here anyway: check the steps since the last rebuild
+        UCG_RC(multi_rebuild(ctx));
+        if (ctx->cs) {
+          int forced = 0, switching = 0;
+          UCG_RC(ucg_fix_cluster_switch_due(ctx, &forced, &switching));
+          if (switching) UCG_RC(multi_cluster_step(ctx));
+        }
+      } else {
+        UCG_RC(multi_halo_forward(ctx));
+      }
+      // pair force, then langevin -> ucgstate -> final_integrate (-> next initial_integrate): one launch (the gather
+      // kernel's epilogue) where that applies, else two
+      int rc = (fuse_next && !density) ? ucg_md_pair_post(ctx, p, ctx->md_lang, ctx->md_ucgst, ctx->md_nve, ctx->groupbit,
+                                                          ctx->ntimestep, ctx->beginstep, ctx->endstep)
+                                       : UCG_ERR_UNSUPPORTED;
+      if (rc == UCG_ERR_UNSUPPORTED) {
+        UCG_RC(multi_pair_compute(ctx, ev));
+        rc = ucg_md_post_fused(ctx, ctx->md_lang, ctx->md_ucgst, ctx->md_nve, fuse_next, ctx->groupbit, ctx->ntimestep,
+                               ctx->beginstep, ctx->endstep);
+      }
+      if (rc) return rc;
+      initial_done = fuse_next;
+      if (ev && ctx->md_lang) UCG_RC(ucg_fix_langevin_end_of_step(ctx, ctx->groupbit, nullptr));
+      if (ev) UCG_RC(poll_pair_errors(ctx));
+    }
+    return poll_pair_errors(ctx);
+  });
+}
+
+}  // namespace ucg
+
+using namespace ucg;
+
+extern "C" {
+
+int ucg_comm_attach(ucg_ctx *ctx, const ucg_comm_ops *ops)
+{
+  if (!ctx || !ops || !ops->alltoallv || !ops->alltoall_ll || !ops->allreduce_ll || !ops->allreduce_f64 || ops->world < 1 ||
+      ops->rank < 0 || ops->rank >= ops->world)
+    return UCG_ERR_INVALID;
+  comm_destroy(ctx);
+  ctx->comm = new CommState();
+  ctx->comm->attached = true;
+  ctx->comm->ops = *ops;
+  ctx->comm->rank = ops->rank;
+  ctx->comm->world = ops->world;
+  return UCG_OK;
+}
+
+int ucg_comm_rccl_unique_id(ucg_rccl_id *out)
+{
+  if (!out) return UCG_ERR_INVALID;
+  if (!g_rccl.load()) return UCG_ERR_COMM;
+  return g_rccl.GetUniqueId(out) == 0 ? UCG_OK : UCG_ERR_COMM;
+}
+
+int ucg_comm_attach_rccl(ucg_ctx *ctx, const ucg_rccl_id *id, int rank, int world)
+{
+  if (!ctx || !id || world < 1 || rank < 0 || rank >= world) return UCG_ERR_INVALID;
+  if (!g_rccl.load()) {
+    ctx->err = g_rccl.err;
+    return UCG_ERR_COMM;
+  }
+  comm_destroy(ctx);
+  void *comm = nullptr;
+  if (hipSetDevice(ctx->device) != hipSuccess) {
+    ctx->err = "hipSetDevice failed";
+    return UCG_ERR_HIP;
+  }
+  const int rc = g_rccl.CommInitRank(&comm, world, *id, rank);
+  if (rc != 0) {
+    ctx->err = std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(rc);
+    return UCG_ERR_COMM;
+  }
+  ctx->comm = new CommState();
+  ctx->comm->attached = true;
+  ctx->comm->rccl = true;
+  ctx->comm->nccl = comm;
+  ctx->comm->rank = rank;
+  ctx->comm->world = world;
+  return UCG_OK;
+}
+
+int ucg_comm_detach(ucg_ctx *ctx)
+{
+  if (!ctx) return UCG_ERR_INVALID;
+  comm_destroy(ctx);
+  return UCG_OK;
+}
+
+int ucg_comm_info(const ucg_ctx *ctx, int *rank, int *world, int *is_rccl, long long *nrebuild)
+{
+  if (!ctx || !ctx->comm) return UCG_ERR_INVALID;
+  if (rank) *rank = ctx->comm->rank;
+  if (world) *world = ctx->comm->world;
+  if (is_rccl) *is_rccl = ctx->comm->rccl ? 1 : 0;
+  if (nrebuild) *nrebuild = ctx->comm->nrebuild;
+  return UCG_OK;
+}
+
+/* sum / max / min of small host arrays over the ranks of the attached communicator (thermo output of a caller) */
+int ucg_comm_allreduce_f64(ucg_ctx *ctx, double *buf, int n, int op)
+{
+  if (!ctx || !ctx->comm || !buf || n < 0 || op < 0 || op > 2) return UCG_ERR_INVALID;
+  return guarded_comm(ctx, [&]() -> int {
+    allreduce_f64(ctx, buf, n, op);
+    return UCG_OK;
+  });
+}
+
+}  // extern "C"

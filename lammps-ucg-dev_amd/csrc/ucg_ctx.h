@@ -113,6 +113,7 @@ struct ucg_pair;
 namespace ucg {
 struct Domain;
 struct ClusterSwitch;
+struct CommState;
 }
 
 struct ucg_ctx {
@@ -166,6 +167,8 @@ struct ucg_ctx {
   int dom_world = 1;
   // fix cluster_switch (ucg_cluster.hip)
   ucg::ClusterSwitch *cs = nullptr;
+  // communicator of a decomposed run (ucg_comm.hip)
+  ucg::CommState *comm = nullptr;
   // resident driver
   ucg_pair *md_pair = nullptr;
   int md_nve = 0;  // 0 none, 1 fix nve/ucgld, 2 fix nve/ucgld/wall/hard
@@ -217,6 +220,9 @@ namespace ucg {
 // ucg_neigh.hip
 void domain_destroy(ucg_ctx *ctx);
 void cluster_destroy(ucg_ctx *ctx);
+void comm_destroy(ucg_ctx *ctx);
+int md_setup_multi(ucg_ctx *ctx);
+int md_run_multi(ucg_ctx *ctx, long long nsteps, int thermo_every);
 bool cluster_forces_rebuild(const ucg_ctx *ctx);
 void cluster_pre_exchange(ucg_ctx *ctx);
 }

@@ -1481,6 +1481,7 @@ int ucg_md_setup(ucg_ctx *ctx, long long nsteps_planned)
   // FixUCGState::setup both call post_force (UCG/fix_ucgld_langevin.cpp:187-197, UCG/fix_ucgstate.cpp:142-171)
   ctx->beginstep = ctx->ntimestep;
   ctx->endstep = ctx->ntimestep + nsteps_planned;
+  if (ctx->comm) return md_setup_multi(ctx);  // decomposed run: csrc/ucg_comm.hip
   int rc = guarded(ctx, [&]() -> int {
     if (ctx->md_lang && !ctx->lang.inited) {
       // Fix_UCGLD_Langevin::init(): reads atom->ucgml[1..ntypes] of the CURRENT bead order (App. B #5)
@@ -1494,13 +1495,15 @@ int ucg_md_setup(ucg_ctx *ctx, long long nsteps_planned)
     return UCG_OK;
   });
   if (rc) return rc;
-  return forces_and_post_force(ctx, 1);
+  if ((rc = forces_and_post_force(ctx, 1))) return rc;
+  return ucg_pair_check_errors(ctx->md_pair);
 }
 
 int ucg_md_run(ucg_ctx *ctx, long long nsteps, int thermo_every)
 {
   if (!ctx || !ctx->md_pair) return UCG_ERR_INVALID;
   if (int rc = need_domain(ctx)) return rc;
+  if (ctx->comm) return md_run_multi(ctx, nsteps, thermo_every);  // decomposed run: csrc/ucg_comm.hip
   // Per step (upstream Verlet::run):
   //   initial_integrate | decide -> rebuild or halo refresh | pair | post_force fixes | final_integrate | end_of_step
   // The per-bead hooks after the pair kernel run as ONE fused kernel; when no thermo output has to
@@ -1517,6 +1520,9 @@ int ucg_md_run(ucg_ctx *ctx, long long nsteps, int thermo_every)
     initial_done = false;
     rc = guarded(ctx, [&]() -> int {
       if (decide(ctx)) {
+        // a table-range violation (the reference's error->one, UCG/pair_table_ucgld.cpp:436-444) must not go
+        // unnoticed while the trajectory runs on: the sticky flag is read where the stream is drained anyway
+        if (int e = ucg_pair_check_errors(ctx->md_pair)) return e;
         rebuild(ctx);
         // FixClusterSwitch::pre_exchange (UCG/fix_cluster_switch.cpp:452-469): its own exchange /
         // borders / build and Verlet's see the same positions, so one rebuild serves both
@@ -1543,8 +1549,9 @@ int ucg_md_run(ucg_ctx *ctx, long long nsteps, int thermo_every)
     initial_done = fuse_next;
     // end_of_step: the lambda temperature is a diagnostic (compute_scalar); evaluated on thermo steps
     if (ev && ctx->md_lang && (rc = ucg_fix_langevin_end_of_step(ctx, ctx->groupbit, nullptr))) return rc;
+    if (ev && (rc = ucg_pair_check_errors(ctx->md_pair))) return rc;
   }
-  return UCG_OK;
+  return ucg_pair_check_errors(ctx->md_pair);
 }
 
 int ucg_md_info(ucg_ctx *ctx, long long *out)

@@ -5,11 +5,13 @@ Replaces, for the resident path, what upstream LAMMPS' CommBrick does with the f
 (``borders``) and the per-step forward halo (``forward_comm``: x, ucgstate, ucgl, ucgp).
 The gather kernels accumulate nothing on ghosts, so there is NO reverse halo.
 
-Device work (count / pack / unpack, sorting, binning, lists, forces, fixes) is the C ABI's;
-this module only sequences it and moves the packed buffers with ``torch.distributed``:
-backend ``nccl`` (= RCCL over xGMI) on a multi-GPU node -- one ``all_to_all_single`` per halo,
-i.e. direct neighbour exchange on the point-to-point links, not LAMMPS' staged x/y/z
-forwarding -- or, for tests on a single GPU shared by the ranks, ``gloo`` with host staging.
+Device work (count / pack / unpack, sorting, binning, lists, forces, fixes) AND the rank-level
+step loop are the library's (csrc/ucg_comm.hip: ucg_md_setup / ucg_md_run with a communicator
+attached).  On a multi-GPU node the communicator is RCCL, called directly from that C++ loop
+(grouped ncclSend / ncclRecv to the <= 7 peers: direct neighbour exchange on the point-to-point
+xGMI links, not LAMMPS' staged x/y/z forwarding).  This module only attaches the communicator
+and, for ranks that share a GPU (tests, rehearsals), provides the callback form of it over
+``torch.distributed`` (gloo) with host staging.
 """
 from __future__ import annotations
 
@@ -182,225 +184,136 @@ class Transport:
         return x.cpu().numpy()
 
 
+class HostStagedComm:
+    """The callbacks of include/ucg_hip.h's ucg_comm_ops over torch.distributed (gloo), with the device buffers staged
+    through the host: for ranks that SHARE a GPU (tests, rehearsals on a one-GPU box), where RCCL cannot be used.  A
+    LAMMPS build would put MPI calls in the same four callbacks."""
+
+    def __init__(self, dist, world, rank):
+        import ctypes as C
+
+        import torch
+
+        self.C, self.torch, self.dist, self.world, self.rank = C, torch, dist, world, rank
+        self.hip = C.CDLL("libamdhip64.so")
+        self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+        self.failed = None
+
+    def _guard(self, fn):
+        try:
+            fn()
+            return 0
+        except Exception as exc:  # noqa: BLE001  (an exception must not cross the C ABI)
+            self.failed = exc
+            return 1
+
+    def alltoallv(self, user, send, sendbytes, recv, recvbytes, stream):
+        def go():
+            t, C = self.torch, self.C
+            sb = [int(sendbytes[r]) for r in range(self.world)]
+            rb = [int(recvbytes[r]) for r in range(self.world)]
+            if self.hip.hipStreamSynchronize(stream):
+                raise RuntimeError("hipStreamSynchronize failed")
+            hs = t.empty(max(sum(sb), 1), dtype=t.uint8)
+            hr = t.empty(max(sum(rb), 1), dtype=t.uint8)
+            if sum(sb) and self.hip.hipMemcpy(hs.data_ptr(), send, sum(sb), 2):  # hipMemcpyDeviceToHost
+                raise RuntimeError("hipMemcpy d2h failed")
+            self.dist.all_to_all_single(hr[: sum(rb)], hs[: sum(sb)], rb, sb)
+            if sum(rb) and self.hip.hipMemcpy(recv, hr.data_ptr(), sum(rb), 1):  # hipMemcpyHostToDevice
+                raise RuntimeError("hipMemcpy h2d failed")
+        return self._guard(go)
+
+    def alltoall_ll(self, user, send, recv):
+        def go():
+            t = self.torch
+            s = t.tensor([int(send[r]) for r in range(self.world)], dtype=t.int64)
+            r = t.empty_like(s)
+            self.dist.all_to_all_single(r, s)
+            for i in range(self.world):
+                recv[i] = int(r[i])
+        return self._guard(go)
+
+    def _allreduce(self, buf, n, op, dtype):
+        t = self.torch
+        x = t.tensor([buf[i] for i in range(n)], dtype=dtype)
+        self.dist.all_reduce(x, op=(self.dist.ReduceOp.SUM, self.dist.ReduceOp.MAX, self.dist.ReduceOp.MIN)[op])
+        for i in range(n):
+            buf[i] = x[i].item()
+
+    def allreduce_ll(self, user, buf, n, op):
+        return self._guard(lambda: self._allreduce(buf, n, op, self.torch.int64))
+
+    def allreduce_f64(self, user, buf, n, op):
+        return self._guard(lambda: self._allreduce(buf, n, op, self.torch.float64))
+
+
 class RankSim:
-    """The Verlet step order of SURVEY.md section 3.1 on one rank of a decomposed run."""
+    """One rank of a decomposed run.  The rank-level Verlet loop (SURVEY.md section 3.1 with CommBrick's exchange /
+    borders / forward_comm and the MPI_Allreduce steps around it) runs INSIDE the library (csrc/ucg_comm.hip, ucg_md_setup
+    / ucg_md_run with a communicator attached); this class only attaches the communicator:
+      * `rccl_id` given: the built-in RCCL transport (one process per GPU, grouped ncclSend / ncclRecv over xGMI);
+      * else: torch.distributed (gloo) callbacks with host staging -- ranks sharing one GPU."""
 
     def __init__(self, ctx, pair, transport: Transport, grid, use_langevin=True, use_ucgstate=True, groupbit=1,
-                 integrator="nve"):
+                 integrator="nve", rccl_id=None):
         """integrator: "nve" = fix nve/ucgld, "wall" = fix nve/ucgld/wall/hard (Context.fix_nve_ucgld_wall_hard)"""
         self.ctx, self.pair, self.tr = ctx, pair, transport
-        self.nve_kind = 2 if integrator == "wall" else 1
-        self.density = getattr(pair, "style", "") == "table_ucg_bethe_density"
-        self._aux_send = None
-        self.cluster = False
-        self.overlap = os.environ.get("UCG_HALO_OVERLAP", "0") == "1"  # measured: not a gain yet (see DESIGN.md section 5)
         self.grid = list(grid)
-        self.me = transport.rank
-        self.world = transport.world
+        self.me, self.world = transport.rank, transport.world
         self.use_langevin, self.use_ucgstate = use_langevin, use_ucgstate
-        self.groupbit = groupbit
-        self.atom_bytes, self.halo_bytes = ctx.record_bytes()
         ctx.decomp_set(self.grid, self.me)
-        if transport.device.type == "cuda":
-            # run the library's kernels on torch's current stream so that they are ordered with the
-            # collectives (RCCL) and with torch's own copies (host-staged gloo)
-            ctx.set_stream(transport.torch.cuda.current_stream().cuda_stream)
-        self.ntimestep = self.beginstep = self.endstep = 0
-        self.nrebuild = 0
-        self.halo_send_counts = self.halo_recv_counts = None
-        self._halo_send = None
-        self._halo_plan = None
-
-    def _buf(self, nbytes):
-        t = self.tr.torch
-        return t.empty(max(int(nbytes), 16), dtype=t.uint8, device=self.tr.device)
-
-    def rebuild(self):
-        ctx, tr = self.ctx, self.tr
-        # exchange: every bead goes to the rank that owns its (wrapped) position
-        sc = ctx.exchange_count()
-        rc = tr.alltoall_counts(sc)
-        sb = self._buf(sc.sum() * self.atom_bytes)
-        ctx.exchange_pack(sb.data_ptr())
-        rb = tr.alltoall_bytes(sb, sc, rc, self.atom_bytes)
-        ctx.exchange_unpack(rb.data_ptr(), int(rc.sum()))
-        # borders: periodic / neighbour-rank images inside each rank's extended brick
-        sc = ctx.border_count()
-        rc = tr.alltoall_counts(sc)
-        sb = self._buf(sc.sum() * self.halo_bytes)
-        ctx.border_pack(sb.data_ptr())
-        rb = tr.alltoall_bytes(sb, sc, rc, self.halo_bytes)
-        ctx.border_unpack(rb.data_ptr(), int(rc.sum()))
-        self.halo_send_counts, self.halo_recv_counts = sc, rc
-        self._halo_send = sb  # reused every step: same counts until the next rebuild
-        self._keep = rb
-        if self.cluster:
-            # ghosts' group bits and molecule ids, for fix cluster_switch
-            mb = self._buf(8 * int(sc.sum()))
-            ctx.halo_molmask_pack(mb.data_ptr())
-            rb2 = tr.alltoall_bytes(mb, sc, rc, 8)
-            ctx.halo_molmask_unpack(rb2.data_ptr())
-        self.nrebuild += 1
-
-    # ---- fix cluster_switch across ranks: the reductions the reference does with MPI_Allreduce
-    def cluster_switch(self, mol_seed, mol_offset, cutoff, seed, switch_freq, rate_file, contact_file):
-        """fix ID all cluster_switch ... (every rank calls this after its beads and molecule ids are uploaded)"""
-        ctx, tr = self.ctx, self.tr
-        ctx.md_set_timestep(self.ntimestep)
-        ctx.fix_cluster_switch(mol_seed, mol_offset, cutoff, seed, switch_freq, rate_file, contact_file, self.groupbit)
-        s = ctx.cs_scalars()
-        ctx.cs_set_scalars(tr.allreduce_array([s[0]], "max")[0], tr.allreduce_array([s[1]], "sum")[0],
-                           tr.allreduce_array([s[2]], "sum")[0])
-        for which in (1, 2, 4):  # mol_state, mol_restrict, presence
-            ctx.cs_set_array(which, tr.allreduce_array(ctx.cs_array(which), "max"))
-        self.cluster = True
-
-    def _cluster_step(self):
-        """check_cluster + attempt_switch on fresh lists (UCG/fix_cluster_switch.cpp:452-469)"""
-        ctx, tr = self.ctx, self.tr
-        changed = ctx.cs_sweep(1)
-        while True:
-            ctx.cs_set_array(5, tr.allreduce_array(ctx.cs_array(5), "min"))
-            if not tr.allreduce_max(changed):
-                break
-            changed = ctx.cs_sweep(0)
-        ctx.cs_finalize()
-        ctx.cs_attempt_local()
-        ctx.cs_set_array(3, tr.allreduce_array(ctx.cs_array(3), "max"))
-        ctx.cs_attempt_apply()
-        ctx.cs_advance()
-        self.halo_forward()  # the ghosts' new atom types
-
-    def halo_forward(self):
-        ctx, tr = self.ctx, self.tr
-        ctx.halo_pack(self._halo_send.data_ptr())
-        if tr.staged:
-            rb = tr.alltoall_bytes(self._halo_send, self.halo_send_counts, self.halo_recv_counts, self.halo_bytes)
+        if rccl_id is not None:
+            ctx.comm_attach_rccl(rccl_id, self.me, self.world)
+            self.host_comm = None
         else:
-            # same counts until the next rebuild: the split lists and the receive buffer are made once per rebuild
-            # (the unpack of a step is ordered before the next step's collective on the stream, so one buffer does)
-            plan = self._halo_plan
-            if plan is None or plan[0] != self.nrebuild:
-                ins = [int(c) * self.halo_bytes for c in self.halo_send_counts]
-                outs = [int(c) * self.halo_bytes for c in self.halo_recv_counts]
-                rbuf = tr.torch.empty(max(sum(outs), 1), dtype=tr.torch.uint8, device=tr.device)
-                plan = self._halo_plan = (self.nrebuild, ins, outs, rbuf, self._halo_send[: sum(ins)], rbuf[: sum(outs)])
-            tr.dist.all_to_all_single(plan[5], plan[4], plan[2], plan[1])
-            rb = plan[3]
-        ctx.halo_unpack(rb.data_ptr())
-        self._keep = rb
+            self.host_comm = HostStagedComm(transport.dist, self.world, self.me)
+            ctx.comm_attach(self.me, self.world, self.host_comm.alltoallv, self.host_comm.alltoall_ll,
+                            self.host_comm.allreduce_ll, self.host_comm.allreduce_f64)
+        ctx.md_attach(pair, nve="wall" if integrator == "wall" else True, langevin=use_langevin, ucgstate=use_ucgstate)
 
-    def halo_forward_and_pair(self):
-        """a step without re-neighbouring and without energy output: the halo travels while the workgroups
-        that touch no ghost are computed (ucg_pair_compute_part 1), the rest follows the unpack (part 2)"""
-        ctx, tr = self.ctx, self.tr
-        ctx.halo_pack(self._halo_send.data_ptr())
-        work, rb = tr.alltoall_bytes_begin(self._halo_send, self.halo_send_counts, self.halo_recv_counts, self.halo_bytes)
-        self.pair.compute_part(1)
-        if work is not None:
-            work.wait()
-        ctx.halo_unpack(rb.data_ptr())
-        self.pair.compute_part(2)
-        self._keep = rb
+    @property
+    def nrebuild(self):
+        return self.ctx.comm_info()["nrebuild"]
 
-    def _aux_halo(self, which):
-        """forward one double2 per ghost (the density style's priors / CV forces) from the owner ranks"""
-        ctx, tr = self.ctx, self.tr
-        if self._aux_send is None or self._aux_send.numel() < 16 * int(self.halo_send_counts.sum()):
-            self._aux_send = self._buf(16 * int(self.halo_send_counts.sum()))
-        field = self.pair.density_buffer(which)
-        ctx.halo_aux_pack(field, self._aux_send.data_ptr())
-        rb = tr.alltoall_bytes(self._aux_send, self.halo_send_counts, self.halo_recv_counts, 16)
-        ctx.halo_aux_unpack(field, rb.data_ptr())
-        self._keep_aux = rb
+    def _chk(self, fn, *a):
+        try:
+            return fn(*a)
+        except Exception:
+            if self.host_comm is not None and self.host_comm.failed is not None:
+                raise self.host_comm.failed
+            raise
 
-    def _pair_compute(self, ev):
-        if not self.density:
-            return self.pair.compute(ev, ev)
-        # table_ucg_bethe_density: its two mid-compute halos cross ranks
-        self.pair.density_phase(1, ev, ev)
-        self._aux_halo(0)
-        self.pair.density_phase(2, ev, ev)
-        self._aux_halo(1)
-        return self.pair.density_phase(3, ev, ev)
+    def cluster_switch(self, mol_seed, mol_offset, cutoff, seed, switch_freq, rate_file, contact_file):
+        """fix ID all cluster_switch ... (every rank, after its beads and molecule ids are uploaded); the reductions the
+        reference does with MPI_Allreduce at creation are made by the library at the next setup()"""
+        self.ctx.fix_cluster_switch(mol_seed, mol_offset, cutoff, seed, switch_freq, rate_file, contact_file)
 
-    def _forces_and_post_force(self, ev):
-        out = self._pair_compute(ev)
-        if self.use_langevin:
-            self.ctx.fix_ucgld_langevin_post_force(self.ntimestep, self.beginstep, self.endstep, self.groupbit)
-        if self.use_ucgstate:
-            self.ctx.fix_ucgstate_post_force()
-        return out
+    def _last(self):
+        th = self.ctx.md_thermo()
+        return th["eng_vdwl"], th["virial"]
+
+    def setup(self, nsteps, ntypes=2):
+        self._chk(self.ctx.md_setup, nsteps)
+        return self._last()  # totals over the ranks
+
+    def run(self, nsteps, thermo_every=0):
+        self._chk(self.ctx.md_run, nsteps, thermo_every)
+        return self._last() if thermo_every > 0 else None
 
     def thermo(self, last=None, mass=None, mvv2e=1.0):
-        """One all-reduce per output step: E_pair, virial[6] of the last energy evaluation (`last` =
-        what setup() / run() returned on this rank), the state-1 population, sum of lambda, the kinetic energy of x and
-        of lambda, the bead count.  Host arithmetic on downloaded arrays: output steps are rare."""
+        """One all-reduce per output step: E_pair, virial[6] of the last energy evaluation (already totals:
+        `last` = what setup() / run() returned), the state-1 population, sum of lambda, the kinetic energy of x and of
+        lambda, the bead count.  Host arithmetic on downloaded arrays: output steps are rare."""
         a = self.ctx.atoms_download()
         n = a["nlocal"]
         m = np.ones(n) if mass is None else np.asarray(mass, float)[a["type"][:n]]
         ke = 0.5 * mvv2e * float(np.sum(m * np.sum(a["v"][:n] ** 2, axis=1)))
         kel = 0.5 * mvv2e * float(np.sum(a["ucgml"][:n] * a["ucgvl"][:n] ** 2))
         e, vir = (last[0], list(last[1])) if last is not None else (0.0, [0.0] * 6)
-        tot = self.tr.allreduce_sum([e] + vir + [float(a["ucgstate"][:n].sum()), float(a["ucgl"][:n].sum()), ke, kel, float(n)])
-        return dict(eng_vdwl=tot[0], virial=np.array(tot[1:7]), state1=tot[7], sum_lambda=tot[8], ke=tot[9], ke_lambda=tot[10],
-                    natoms=int(tot[11]))
-
-    def setup(self, nsteps, ntypes=2):
-        self.beginstep = self.ntimestep
-        self.endstep = self.ntimestep + nsteps
-        self.rebuild()
-        if self.use_langevin:
-            # Fix_UCGLD_Langevin::init() reads atom->ucgml[1..ntypes] of the local bead order (App. B #5)
-            ml = self.ctx.atoms_download()["ucgml"]
-            pad = np.full(ntypes + 1, ml[0] if len(ml) else 1.0)
-            pad[: min(len(ml), ntypes + 1)] = ml[: ntypes + 1]
-            self.ctx.fix_ucgld_langevin_init(ntypes, pad)
-        return self._forces_and_post_force(1)
-
-    def run(self, nsteps, thermo_every=0):
-        ctx = self.ctx
-        last = None
-        initial_done = False
-        for s in range(nsteps):
-            self.ntimestep += 1
-            ev = 1 if (thermo_every > 0 and self.ntimestep % thermo_every == 0) else 0
-            if not initial_done:
-                if self.nve_kind == 2:
-                    ctx.fix_nve_ucgld_wall_hard_initial_integrate(self.groupbit)
-                else:
-                    ctx.fix_nve_ucgld_initial_integrate(self.groupbit)
-            if self.cluster:
-                ctx.md_set_timestep(self.ntimestep)
-            due, flag = ctx.decide_local()
-            fuse_next = (not ev) and (s + 1 < nsteps)
-            rebuilt = bool(due and self.tr.allreduce_max(flag))
-            if rebuilt:
-                self.rebuild()
-                if self.cluster and ctx.cs_due()[1]:
-                    self._cluster_step()
-            elif self.overlap and not ev and not self.density:
-                self.halo_forward_and_pair()
-                ctx.md_post_fused(self.use_langevin, self.use_ucgstate, self.nve_kind, fuse_next, self.ntimestep,
-                                  self.beginstep, self.endstep, self.groupbit)
-                initial_done = fuse_next
-                continue
-            else:
-                self.halo_forward()
-            # pair force, then langevin -> ucgstate -> final_integrate (-> next initial_integrate): one launch (the
-            # gather kernel's epilogue) where that applies, else two
-            if fuse_next and not self.density and ctx.md_pair_post(self.pair, self.use_langevin, self.use_ucgstate,
-                                                                     self.nve_kind, self.ntimestep, self.beginstep,
-                                                                     self.endstep, self.groupbit):
-                pass
-            else:
-                out = self._pair_compute(ev)
-                if ev:
-                    last = out
-                ctx.md_post_fused(self.use_langevin, self.use_ucgstate, self.nve_kind, fuse_next, self.ntimestep,
-                                  self.beginstep, self.endstep, self.groupbit)
-            initial_done = fuse_next
-        return last
+        tot = self.ctx.comm_allreduce_sum([float(a["ucgstate"][:n].sum()), float(a["ucgl"][:n].sum()), ke, kel, float(n)])
+        return dict(eng_vdwl=e, virial=np.array(vir), state1=tot[0], sum_lambda=tot[1], ke=tot[2], ke_lambda=tot[3],
+                    natoms=int(tot[4]))
 
 
 def run_bench(args, deck, beads, cs, rank, world, device_index, dist, shared, make_pair, attach_fixes, apply_options):
@@ -428,9 +341,15 @@ def run_bench(args, deck, beads, cs, rank, world, device_index, dist, shared, ma
     apply_options(ctx)
     pair = make_pair(ctx)
     use_lang, use_st = attach_fixes(ctx)
-    tr = Transport(dist, device, staged=shared)
+    tr = Transport(dist, device, staged=True)  # torch.distributed (gloo): rendezvous, barriers, host-side sums only
     wall = getattr(args, "integrator", "wall") == "wall"
-    sim = RankSim(ctx, pair, tr, grid, use_langevin=use_lang, use_ucgstate=use_st, integrator="wall" if wall else "nve")
+    rccl_id = None
+    if not shared:  # one GPU per rank: the library's RCCL transport; rank 0's id travels over the gloo group
+        box = [capi.Context.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        rccl_id = box[0]
+    sim = RankSim(ctx, pair, tr, grid, use_langevin=use_lang, use_ucgstate=use_st, integrator="wall" if wall else "nve",
+                  rccl_id=rccl_id)
     if cs:
         sim.cluster_switch(cs["mol_seed"], 0, cs["cutoff"], cs["seed"], cs["switch_freq"], cs["rates"], cs["contacts"])
     sim.setup(args.warmup + args.steps, ntypes=beads.ntypes)
@@ -450,7 +369,7 @@ def run_bench(args, deck, beads, cs, rank, world, device_index, dist, shared, ma
     launches, pair_ms = ctx.profile_read(reset=True)
     ctx.profile_enable(False)
     pair.check_errors()
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if shared else device)
+    t = torch.tensor([elapsed], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     info = ctx.md_info()
     tot = tr.allreduce_sum([info["list_entries"], info["nghost"], info["nlocal"]])
@@ -458,9 +377,8 @@ def run_bench(args, deck, beads, cs, rank, world, device_index, dist, shared, ma
     out = dict(elapsed=float(t.item()), n=beads.n, pair_launches=launches, pair_ms=pair_ms, list_entries=int(tot[0]),
                nghost=int(tot[1]), rebuilds=sim.nrebuild - nre0, maxrow=info["maxrow"], grid=grid,
                nlocal_sum=int(tot[2]), rank0_list_entries=info["list_entries"], rank0_nlocal=info["nlocal"],
-               transport=(f"gloo, host-staged: {world} ranks share {torch.cuda.device_count()} GPU(s) (rehearsal of the N > 1 path)"
-                          if shared else "RCCL (torch.distributed nccl backend) over xGMI"),
-               small_messages=dict(route="gloo side group" if tr.use_host else "main backend", timed_us=tr.small_msg_us))
+               transport=(f"gloo callbacks, host-staged: {world} ranks share {torch.cuda.device_count()} GPU(s) (rehearsal of the N > 1 path)"
+                          if shared else "RCCL called from the library's C++ step loop (grouped ncclSend / ncclRecv over xGMI)"))
     if cs:
         out["cluster_switch_vector"] = [float(v) for v in ctx.fix_cluster_switch_vector()]
     return out

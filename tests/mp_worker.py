@@ -150,7 +150,7 @@ def main():
         sim.run(30)
         pair.check_errors()
         A = ctx.atoms_download()
-        result = dict(tag0=A0["tag"], f0=A0["f"], p0=A0["ucgp"], st0=A0["ucgstate"], e0=tr.allreduce_sum([e0])[0],
+        result = dict(tag0=A0["tag"], f0=A0["f"], p0=A0["ucgp"], st0=A0["ucgstate"], e0=e0,
                       labels=labels, tag=A["tag"], type=A["type"], st=A["ucgstate"], x=A["x"], mol=ctx.download_molecule(),
                       vec=ctx.fix_cluster_switch_vector(), mol_seed=mol_seed, nrebuild=sim.nrebuild, nghost=A["nghost"])
         pair.close()
@@ -179,7 +179,7 @@ def main():
         last = sim.run(40, thermo_every=40)
         pair.check_errors()
         A1 = ctx.atoms_download()
-        etot = tr.allreduce_sum([e0, last[0]])
+        etot = [e0, last[0]]  # setup() / run() return the totals over the ranks
         th = sim.thermo(last, mass=beads.mass)
         result = dict(thermo=th, tag0=A0["tag"], f0=A0["f"], uf0=A0["ucgforce"], s0=A0["scores"], p0=A0["ucgp"], inside=inside, tag1=A1["tag"],
                       x1=A1["x"], l1=A1["ucgl"], e0=etot[0], e1=etot[1], nrebuild=sim.nrebuild, nghost=A1["nghost"])
