@@ -155,6 +155,11 @@ int ucg_pair_check_errors(ucg_pair *p);
  * (double2 per owned + ghost bead). */
 int ucg_pair_density_phase(ucg_pair *p, int phase, int eflag, int vflag, double *eng_vdwl, double *virial);
 void *ucg_pair_density_buffer(ucg_pair *p, int which);
+/* host access to `count` entries (two doubles each) of buffer `which` starting at bead `first`, for a caller that
+ * moves them itself between the phases (LAMMPS' comm->forward_comm(Pair *): the glue downloads the owned entries,
+ * forwards them and uploads the ghosts') */
+int ucg_pair_density_aux_download(ucg_pair *p, int which, double *host, int first, int count);
+int ucg_pair_density_aux_upload(ucg_pair *p, int which, const double *host, int first, int count);
 
 /* ------------------------------------------------------------- atoms (AtomVecUCG)
  * replaces the per-atom fields of atom style "ucg": UCG/atom_vec_ucg.cpp:48-90,

@@ -59,7 +59,7 @@ SYMBOLS = [
     "ucg_md_attach", "ucg_md_post_fused", "ucg_md_pair_post", "ucg_md_setup", "ucg_md_run", "ucg_md_info", "ucg_md_thermo",
     "ucg_profile_enable", "ucg_profile_read",
     "ucg_comm_attach", "ucg_comm_rccl_unique_id", "ucg_comm_attach_rccl", "ucg_comm_detach", "ucg_comm_info",
-    "ucg_comm_allreduce_f64",
+    "ucg_comm_allreduce_f64", "ucg_pair_density_aux_download", "ucg_pair_density_aux_upload",
 ]
 
 # communicator callbacks of a decomposed run (include/ucg_hip.h: ucg_comm_ops)
@@ -213,6 +213,8 @@ def lib():
     L.ucg_comm_detach.argtypes = [vp]
     L.ucg_comm_info.argtypes = [vp, c_int_p, c_int_p, c_int_p, c_ll_p]
     L.ucg_comm_allreduce_f64.argtypes = [vp, c_double_p, C.c_int, C.c_int]
+    L.ucg_pair_density_aux_download.argtypes = [vp, C.c_int, c_double_p, C.c_int, C.c_int]
+    L.ucg_pair_density_aux_upload.argtypes = [vp, C.c_int, c_double_p, C.c_int, C.c_int]
     _LIB = L
     return L
 

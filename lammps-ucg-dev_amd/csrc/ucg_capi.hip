@@ -659,6 +659,32 @@ void *ucg_pair_density_buffer(ucg_pair *p, int which)
   return which == 0 ? (void *) p->d_prior.get() : which == 1 ? (void *) p->d_cv.get() : nullptr;
 }
 
+int ucg_pair_density_aux_download(ucg_pair *p, int which, double *host, int first, int count)
+{
+  if (!p || !p->ctx || !host || first < 0 || count < 0 || (which != 0 && which != 1)) return UCG_ERR_INVALID;
+  ucg_ctx *ctx = p->ctx;
+  return guarded(ctx, [&]() -> int {
+    DevBuf<double2> &B = which == 0 ? p->d_prior : p->d_cv;
+    if ((size_t) first + (size_t) count > B.capacity()) return fail(ctx, UCG_ERR_INVALID, "density buffer range");
+    if (count) d2h(ctx, (double2 *) host, B.get() + first, (size_t) count);
+    sync(ctx);
+    return UCG_OK;
+  });
+}
+
+int ucg_pair_density_aux_upload(ucg_pair *p, int which, const double *host, int first, int count)
+{
+  if (!p || !p->ctx || !host || first < 0 || count < 0 || (which != 0 && which != 1)) return UCG_ERR_INVALID;
+  ucg_ctx *ctx = p->ctx;
+  return guarded(ctx, [&]() -> int {
+    DevBuf<double2> &B = which == 0 ? p->d_prior : p->d_cv;
+    if ((size_t) first + (size_t) count > B.capacity()) return fail(ctx, UCG_ERR_INVALID, "density buffer range");
+    if (count) h2d(ctx, B.get() + first, (const double2 *) host, (size_t) count);
+    sync(ctx);
+    return UCG_OK;
+  });
+}
+
 int ucg_pair_check_errors(ucg_pair *p)
 {
   if (!p || !p->ctx) return UCG_ERR_INVALID;

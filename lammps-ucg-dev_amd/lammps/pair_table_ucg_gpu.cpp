@@ -87,6 +87,11 @@ void PairTableUCGGPU::init_style()
 {
   // full list, ghosts included as neighbours (they are never row owners)
   neighbor->add_request(this, NeighConst::REQ_FULL);
+  if (ucg_style == 2) {
+    comm_forward = 2;
+    if (comm->nprocs == 1 && atom->map_style == Atom::MAP_NONE)
+      error->all(FLERR, "USER-UCG/GPU: pair_style table_ucg_bethe_density needs an atom map (atom_modify map yes)");
+  }
   // thermostat temperature, found like the reference does (UCG/pair_table_ucgld.cpp:873-881)
   double *pT = nullptr;
   int pdim;
@@ -138,7 +143,42 @@ void PairTableUCGGPU::upload_list()
     }
   }
   check(ucg_neigh_upload_full(ctx, inum, numneigh.data(), first.data(), flat.data()), false);
-  last_list_build = neighbor->lastcall;
+  if (ucg_style == 2 && comm->nprocs == 1 && nghost > 0) {
+    // one rank: every ghost is a periodic image of an owned atom; the density style gives it its owner's prior and CV
+    // force on the device (the forward_comm the reference declares, UCG/pair_table_ucg_bethe_density.cpp:280)
+    std::vector<int> src((size_t) nghost);
+    for (int g = 0; g < nghost; g++) {
+      const int o = atom->map(tag[nlocal + g]);
+      if (o < 0 || o >= nlocal) error->one(FLERR, "USER-UCG/GPU: ghost atom without an owned image (atom_modify map needed)");
+      src[(size_t) g] = o;
+    }
+    check(ucg_ghosts_upload(ctx, src.data(), nghost), false);
+  }
+  // a list is stale when Neighbor has built since (ncalls counts every build, also the one setup() of a second
+  // `run` makes on an unchanged timestep) or when the atom counts changed
+  last_list_build = neighbor->ncalls;
+  last_nlocal = nlocal;
+  last_nghost = nghost;
+}
+
+int PairTableUCGGPU::pack_forward_comm(int n, int *list, double *buf, int /*pbc_flag*/, int * /*pbc*/)
+{
+  int m = 0;
+  for (int i = 0; i < n; i++) {
+    const int j = list[i];
+    buf[m++] = aux[2 * (size_t) j];
+    buf[m++] = aux[2 * (size_t) j + 1];
+  }
+  return m;
+}
+
+void PairTableUCGGPU::unpack_forward_comm(int n, int first, double *buf)
+{
+  int m = 0;
+  for (int i = first; i < first + n; i++) {
+    aux[2 * (size_t) i] = buf[m++];
+    aux[2 * (size_t) i + 1] = buf[m++];
+  }
 }
 
 void PairTableUCGGPU::compute(int eflag, int vflag)
@@ -146,11 +186,27 @@ void PairTableUCGGPU::compute(int eflag, int vflag)
   ev_init(eflag, vflag);
   auto avec = AtomVecUCG::get(lmp);
   const int nlocal = atom->nlocal;
-  if (neighbor->lastcall != last_list_build) upload_list();
+  if (neighbor->ncalls != last_list_build || nlocal != last_nlocal || atom->nghost != last_nghost) upload_list();
   else check(ucg_atoms_upload_comm(ctx, &atom->x[0][0], avec->ucgstate, avec->ucgl, avec->ucgp), false);
 
   double eng = 0.0, vir[6] = {0, 0, 0, 0, 0, 0};
-  check(ucg_pair_compute(gpair, eflag_global, vflag_global, &eng, vir), false);
+  if (ucg_style == 2 && comm->nprocs > 1) {
+    // the three passes of compute() one at a time; between them the ghosts' priors (after pass 1) and CV forces
+    // (after pass 2) come from their owner ranks through LAMMPS' own forward communication
+    const int nall = nlocal + atom->nghost;
+    aux.assign(2 * (size_t) nall, 0.0);
+    comm_forward = 2;
+    for (int phase = 1; phase <= 3; phase++) {
+      check(ucg_pair_density_phase(gpair, phase, eflag_global, vflag_global, phase == 3 ? &eng : nullptr,
+                                   phase == 3 ? vir : nullptr), false);
+      if (phase == 3) break;
+      check(ucg_pair_density_aux_download(gpair, phase - 1, aux.data(), 0, nlocal), false);
+      comm->forward_comm(this);
+      check(ucg_pair_density_aux_upload(gpair, phase - 1, aux.data() + 2 * (size_t) nlocal, nlocal, atom->nghost), false);
+    }
+  } else {
+    check(ucg_pair_compute(gpair, eflag_global, vflag_global, &eng, vir), false);
+  }
   check(ucg_pair_check_errors(gpair), false);    // "Pair distance < table inner cutoff" etc.
 
   std::vector<double> f((size_t) nlocal * 3), uf((size_t) nlocal), sc((size_t) nlocal * 2), up;

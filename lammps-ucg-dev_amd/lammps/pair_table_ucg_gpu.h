@@ -18,6 +18,8 @@ PairStyle(table_ucg_bethe_density,PairTableUCGBetheDensityGPU);
 
 #include "pair.h"
 
+#include <vector>
+
 struct ucg_ctx;
 struct ucg_pair;
 
@@ -38,12 +40,18 @@ class PairTableUCGGPU : public Pair {
   void read_restart(FILE *) override;
   void write_restart_settings(FILE *) override;
   void read_restart_settings(FILE *) override;
+  // table_ucg_bethe_density under MPI: the forward communication the reference declares and never performs
+  // (UCG/pair_table_ucg_bethe_density.h:107-110, .cpp:280): two doubles per atom, between the passes of compute()
+  int pack_forward_comm(int, int *, double *, int, int *) override;
+  void unpack_forward_comm(int, int, double *) override;
 
  protected:
   int ucg_style;
   ucg_ctx *ctx = nullptr;
   ucg_pair *gpair = nullptr;
   bigint last_list_build = -1;
+  int last_nlocal = -1, last_nghost = -1;
+  std::vector<double> aux;    // [nall][2]: priors, then CV forces, of owned + ghost atoms (density style under MPI)
   double T = 0.0;
   int tabstyle = 0, tablength = 0;    // as given to pair_style: what the reference keeps in restart files
   void check(int rc, bool all);

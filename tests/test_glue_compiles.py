@@ -1,0 +1,33 @@
+"""The LAMMPS-side glue (lammps-ucg-dev_amd/lammps/*.cpp: atom style ucg, the three pair styles, the five fixes) is
+checked by a C++ compiler: `g++ -std=c++17 -fsyntax-only -Wall -Werror` against include/ucg_hip.h and against
+tests/lammps_api_decl/ -- declarations of the upstream API subset the glue uses (there is no LAMMPS tree in this
+container; the declarations are not implementations, are never linked and build nothing of the reference).  This catches
+wrong prototypes of the C ABI, missing overrides and type errors in the glue; behaviour is covered through the ABI
+(tests/test_c_abi.py)."""
+import os
+import subprocess
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GLUE = os.path.join(ROOT, "lammps-ucg-dev_amd", "lammps")
+
+
+@pytest.mark.parametrize("src", ["atom_vec_ucg_gpu.cpp", "pair_table_ucg_gpu.cpp", "fix_ucg_gpu.cpp"])
+def test_glue_passes_the_compiler(src):
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I", os.path.join(HERE, "lammps_api_decl"),
+                        "-I", os.path.join(ROOT, "include"), "-I", GLUE, os.path.join(GLUE, src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-4000:]
+
+
+def test_style_registration_names_match_the_reference():
+    """PairStyle / FixStyle / AtomStyle names are the reference's (UCG/pair_table_ucgld.h:1-3, UCG/pair_table_ucg_bethe.h:31-33,
+    UCG/pair_table_ucg_bethe_density.h:27-29, UCG/fix_nve_ucgld.h:15-16, UCG/fix_nve_ucgld_wall_hard.h:12,
+    UCG/fix_ucgld_langevin.h:14-17, UCG/fix_ucgstate.h:1-3, UCG/fix_cluster_switch.h, UCG/atom_vec_ucg.h:20-23)"""
+    text = "".join(open(os.path.join(GLUE, f)).read() for f in ("pair_table_ucg_gpu.h", "fix_ucg_gpu.h", "atom_vec_ucg_gpu.h"))
+    for name in ("PairStyle(table_ucgld,", "PairStyle(table_ucg_bethe,", "PairStyle(table_ucg_bethe_density,",
+                 "FixStyle(nve/ucgld,", "FixStyle(nve/ucgld/wall/hard,", "FixStyle(ucgld/langevin,", "FixStyle(ucgstate,",
+                 "FixStyle(cluster_switch,", "AtomStyle(ucg,"):
+        assert name in text, name
