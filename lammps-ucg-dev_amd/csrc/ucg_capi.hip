@@ -537,6 +537,11 @@ static int pair_compute_impl(ucg_pair *p, int eflag, int vflag, double *eng_vdwl
     if (!p->uploaded) return fail(ctx, UCG_ERR_INVALID, "ucg_pair_compute before ucg_pair_init");
     if (ctx->list_inum != ctx->nlocal) return fail(ctx, UCG_ERR_INVALID, "neighbour list does not match the resident atoms");
     const bool ev = (eflag || vflag);
+    if (ctx->list_from_builder)
+      for (int i = 1; i < 4; i++)
+        if (ctx->special_lj[i] != 1.0)
+          return fail(ctx, UCG_ERR_UNSUPPORTED, "the device list builder knows no bond topology (no special-bond bits): "
+                                                "special_lj other than 1 needs a list uploaded with ucg_neigh_upload_full");
     if (ctx->list_once_beads > 0 && !p->once)
       return fail(ctx, UCG_ERR_INVALID, "the neighbour rows were built for option pair_once (own-block pairs in one row only); "
                                         "this pair style cannot sweep them");
@@ -943,6 +948,7 @@ int ucg_neigh_upload_full(ucg_ctx *ctx, int inum, const int *numneigh, const lon
     ctx->list_maxrow = maxrow;
     ctx->list_entries = total;
     ctx->list_stored = total;
+    ctx->list_from_builder = false;
     ctx->list_once_beads = 0;  // a caller's full list holds every pair in both rows
     return UCG_OK;
   });

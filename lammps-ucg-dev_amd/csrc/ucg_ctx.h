@@ -152,6 +152,7 @@ struct ucg_ctx {
   int list_pitch = 0, list_maxrow = 0, list_inum = 0;
   long long list_entries = 0;  // as a FULL list (an own-block pair kept in one row of pair_once rows counts twice)
   long long list_stored = 0;   // entries actually stored in the rows
+  bool list_from_builder = false;  // rows made by the device builder (which sets no special-bond bits)
   int list_once_beads = 0;   // > 0: the rows hold own-block pairs once (workgroups of this many beads)
   int list_once_maxin = 0;   // ... and no bead is the partner of more than this many such pairs kept elsewhere
   // shared RanMars jump table

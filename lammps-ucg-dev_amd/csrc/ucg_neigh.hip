@@ -462,6 +462,7 @@ struct __attribute__((aligned(16))) TileCand {
 // the bead are skipped; candidates are fetched four at a time and committed in order: class 0
 // (inside the force cutoff) straight to the front of the bead's row, the skin classes -- tagged
 // in bits 30-31 -- to a side buffer from which the caller appends them class by class.
+template <bool ONCE>
 __device__ __forceinline__ void tile_walk(const DomainDev &D, const double3 &binsize, const int k, const double4 &pk,
                                           const int tk, const int bx, const int by, const int bz, const int r0x,
                                           const int r0y, const int r0z, const int *s_start, const TileCand *s_cand,
@@ -514,9 +515,9 @@ __device__ __forceinline__ void tile_walk(const DomainDev &D, const double3 &bin
           // branch-free bookkeeping (plain integer adds and selects: keeps the counters in registers); the
           // skin classes are only tagged here and counted when the side buffer is read back
           const bool inlist = (j + u < j1) && (pm[u].idx != k) && (rsq[u] < D.cutneighsq);
-          const bool drop = inlist && once_drops(D, k, pm[u].idx);
+          const bool drop = ONCE && inlist && once_drops(D, k, pm[u].idx);  // plain rows: compiled out
           const bool ok = inlist && !drop;
-          ndrop += drop ? 1 : 0;
+          if (ONCE) ndrop += drop ? 1 : 0;
           const int in0 = rsq[u] < D.cls_sq[0], in1 = rsq[u] < D.cls_sq[1], in2 = rsq[u] < D.cls_sq[2];
           const int cls = 3 - in0 - in1 - in2;
           const int orient = (tk <= pm[u].tag) ? 1 : 0;
@@ -533,6 +534,7 @@ __device__ __forceinline__ void tile_walk(const DomainDev &D, const double3 &bin
   }
 }
 
+template <bool ONCE>
 __global__ __launch_bounds__(TILE_B) void k_rows_tile(const DomainDev D, const double4 *pos4, const int *tag,
                                                       const int *bin_of, const int4 *cells, int *rowcount, int *neigh,
                                                       int *skin, int pitch, int cap, int capskin, const double3 binsize,
@@ -624,7 +626,7 @@ __global__ __launch_bounds__(TILE_B) void k_rows_tile(const DomainDev D, const d
     const int b = bin_of[k];
     const int bx = b % D.nbin[0], by = (b / D.nbin[0]) % D.nbin[1], bz = b / (D.nbin[0] * D.nbin[1]);
     int c0, ns, nd;
-    tile_walk(D, binsize, k, pk, tk, bx, by, bz, r0x, r0y, r0z, s_start, s_cand, c0, ns, nd, neigh, skin, pitch, cap, capskin);
+    tile_walk<ONCE>(D, binsize, k, pk, tk, bx, by, bz, r0x, r0y, r0z, s_start, s_cand, c0, ns, nd, neigh, skin, pitch, cap, capskin);
     const int cnt = c0 + ns;
     mxd = max(mxd, nd);
     totd += nd;
@@ -773,6 +775,10 @@ __global__ __launch_bounds__(1024) void k_flags_any(int nflags, const int *block
 void setup_bins(Domain &D)
 {
   // identical host arithmetic to the specification (oracle/orc_md.c: orc_sim_setup_bins)
+  // single-rank rebuild and decomposed borders alike enumerate ONE layer of periodic images (shifts -1, 0, +1)
+  for (int d = 0; d < 3; d++)
+    if (D.prd[d] < D.cutneigh)
+      throw InputError{"periodic box shorter than the ghost cutoff: more than one image layer would be needed"};
   const double target = 0.5 * D.cutneigh;
   D.nbins = 1;
   for (int d = 0; d < 3; d++) {
@@ -852,9 +858,6 @@ void rebuild(ucg_ctx *ctx)
   hipStream_t st = ctx->stream;
   const int n = ctx->nlocal;
   if (n <= 0) throw InputError{"ucg_neigh_rebuild: no beads uploaded"};
-  for (int d = 0; d < 3; d++)
-    if (D.prd[d] < 2.0 * D.cutneigh * 0.5)
-      throw InputError{"periodic box shorter than the ghost cutoff: more than one image layer would be needed"};
   setup_bins(D);
   if (D.nbin[0] > 512 || D.nbin[1] > 512 || D.nbin[2] > 512) throw InputError{"more than 512 bins per dimension: too many for the sort key"};
   const DomainDev dd = make_dev(D);
@@ -959,9 +962,14 @@ void build_bins_and_rows(ucg_ctx *ctx)
       D.blockdrop.reserve((size_t) nblocks + 1);
       UCG_HIP(hipMemsetAsync(D.blockstat.get(), 0, (size_t) nblocks * sizeof(int4), st));
       UCG_HIP(hipMemsetAsync(D.blockdrop.get(), 0, (size_t) nblocks * sizeof(int2), st));
-      hipLaunchKernelGGL(k_rows_tile, dim3((unsigned) nblocks), dim3(TILE_B), 0, st, dd, ctx->pos4.get(), ctx->tag.get(),
-                         D.bin_of.get(), D.cells.get(), ctx->numneigh.get(), ctx->neigh.get(), D.scratch.get(), pitch, cap,
-                         capskin, bs, nbrick, D.blockstat.get(), D.blockdrop.get(), (int *) (D.rowstat.get() + 2));
+      if (once_beads)
+        hipLaunchKernelGGL(k_rows_tile<true>, dim3((unsigned) nblocks), dim3(TILE_B), 0, st, dd, ctx->pos4.get(), ctx->tag.get(),
+                           D.bin_of.get(), D.cells.get(), ctx->numneigh.get(), ctx->neigh.get(), D.scratch.get(), pitch, cap,
+                           capskin, bs, nbrick, D.blockstat.get(), D.blockdrop.get(), (int *) (D.rowstat.get() + 2));
+      else
+        hipLaunchKernelGGL(k_rows_tile<false>, dim3((unsigned) nblocks), dim3(TILE_B), 0, st, dd, ctx->pos4.get(), ctx->tag.get(),
+                           D.bin_of.get(), D.cells.get(), ctx->numneigh.get(), ctx->neigh.get(), D.scratch.get(), pitch, cap,
+                           capskin, bs, nbrick, D.blockstat.get(), D.blockdrop.get(), (int *) (D.rowstat.get() + 2));
       hipLaunchKernelGGL(k_rowstat_fold, dim3(1), dim3(1024), 0, st, (int) nblocks, D.blockstat.get(), D.blockdrop.get(),
                          D.rowstat.get());
       unsigned long long stat[6];
@@ -1018,6 +1026,7 @@ void build_bins_and_rows(ucg_ctx *ctx)
   ctx->list_maxrow = maxrow;
   ctx->list_entries = total + totdrop;  // as a FULL list: an own-block pair kept in one row stands for two entries
   ctx->list_stored = total;
+  ctx->list_from_builder = true;
   ctx->list_once_beads = once_beads;
   ctx->list_once_maxin = maxdrop;
 

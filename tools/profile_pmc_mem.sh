@@ -12,9 +12,14 @@ pass() {
      --output-format csv -d "$OUT/$name" -- $BENCH > "$OUT/$name.log" 2>&1
   echo "$name rc=$?" >> "$OUT/passes.log"
 }
-pass ta TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_FLAT_READ_WAVEFRONTS_sum
+# TA / TD: at most TWO counters of the block per pass.  Round 1 asked for four TA_* (three TD_*) in one pass;
+# rocprofiler_create_counter_config then fails with "error code 38: Request exceeds the capabilities of the hardware to
+# collect" and the process aborts (SIGABRT under the first kernel launch) -- an over-subscribed counter block, not a hang.
+pass ta1 TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum
+pass ta2 TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum
 pass tcp1 TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum
 pass tcp2 TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_GATE_EN1_sum TCP_GATE_EN2_sum
-pass td TD_TD_BUSY_sum TD_TC_STALL_sum TD_LOAD_WAVEFRONT_sum
+pass td1 TD_TD_BUSY_sum TD_TC_STALL_sum
+pass td2 TD_LOAD_WAVEFRONT_sum
 pass grbm GRBM_GUI_ACTIVE GRBM_COUNT
 cat "$OUT/passes.log"
