@@ -45,6 +45,7 @@ import __graft_entry__ as entry  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 SIMDS = 256 * 4        # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs
 CLOCK_GHZ = 2.4        # max clock; a wave64 fp64 instruction holds its SIMD for 4 cycles (16 lanes / cycle)
+MEASURED_CLOCK_GHZ = 2.0  # effective shader clock under the pair kernel (profiles/README.md, round 2: 1.92-2.10)
 
 CLUSTER_SWITCH = dict(prob_on=0.35, cutoff=1.2, seed=4711, switch_freq=50, molecule_size=2)
 
@@ -53,7 +54,11 @@ def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000, help="timed steps (SURVEY.md 8d: >= 1000, re-neighbouring included)")
-    ap.add_argument("--warmup", type=int, default=200, help="untimed steps first (SURVEY.md 8d: 200 warm-up steps on the path itself)")
+    ap.add_argument("--warmup", type=int, default=200, help="untimed steps directly before the timed ones")
+    ap.add_argument("--equilibrate", type=int, default=200,
+                    help="steps run on the path itself while PREPARING the synthetic input (SURVEY.md 8d: 'simple-cubic lattice ... "
+                         "jitter ... then 200 warm-up steps on the CPU/GPU path itself'): the workload is the equilibrated melt, "
+                         "not the jittered lattice (which has 10 %% more list entries); untimed, before --warmup")
     ap.add_argument("--config", type=int, default=0, choices=[0, 2, 3, 4, 5],
                     help="a configuration of BASELINE.json: 2 = 262 144 beads table_ucgld + langevin; 3 = 1 M beads "
                          "table_ucg_bethe; 4 = the default workload (1 M beads table_ucgld, decomposed for --gpus > 1); "
@@ -301,8 +306,9 @@ def run_single(args, pkg, capi, deck, beads, cs, local_rank, steps, warmup, inte
     if cs:
         ctx.fix_cluster_switch(cs["mol_seed"], 0, cs["cutoff"], cs["seed"], cs["switch_freq"], cs["rates"], cs["contacts"])
     ctx.md_attach(pair, nve="wall" if integrator == "wall" else True, langevin=use_lang, ucgstate=use_st)
-    ctx.md_setup(warmup + steps)
-    ctx.md_run(warmup, 0)
+    equil = getattr(args, "equilibrate", 0)
+    ctx.md_setup(equil + warmup + steps)
+    ctx.md_run(equil + warmup, 0)  # input preparation (melt the lattice), then the warm-up
     ctx.synchronize()
     ctx.profile_enable(True)
     ctx.profile_read(reset=True)
@@ -456,8 +462,8 @@ def main():
         "config": {
             "workload": f"{n} beads ({args.lattice} lattice {args.ncell}^3 + jitter), rho*=0.8, rc=2.5, skin=0.3, dt=0.002, "
                         f"pair_style {args.style} {args.tabstyle} {args.tablength} (2-state, LJ-like tables) + " + wl_fix +
-                        "neigh_modify every 10 check yes; rebuilds inside the timed region: "
-                        f"{result['rebuilds']}",
+                        f"neigh_modify every 10 check yes; input = the lattice after {args.equilibrate} steps of this same path "
+                        f"(SURVEY.md 8d); rebuilds inside the timed region: {result['rebuilds']}",
             "beads": n,
             "full_list_entries": int(result["list_entries"]),
             "ghosts": int(result["nghost"]),
@@ -508,8 +514,10 @@ def main():
             out["roofline"]["valu"] = {
                 "bound": "fp64 VALU issue", "wave_instructions_per_launch": v, "min_us": t_valu * 1e6,
                 "frac": t_valu / pair_avg_s if pair_avg_s > 0 else 0.0,
-                "note": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz) over the measured launch time: the bound that "
-                        "binds this kernel (its HBM traffic is a quarter of the algorithmic bytes)"}
+                "frac_at_measured_clock": t_valu * (CLOCK_GHZ / MEASURED_CLOCK_GHZ) / pair_avg_s if pair_avg_s > 0 else 0.0,
+                "note": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz) over the measured launch time: the on-chip bound that "
+                        "binds this kernel together with the LDS (HBM traffic is a third of the algorithmic bytes); under this "
+                        f"kernel the chip holds {MEASURED_CLOCK_GHZ} GHz (GRBM_GUI_ACTIVE, tools/profile_clock.sh), hence the second figure"}
     if nve_leg:
         out["integrator_nve"] = nve_leg
     if not args.no_cpu_baseline and args.style == "table_ucgld" and world == 1 and not cs:  # rank 0 at N = 1 only

@@ -352,8 +352,9 @@ def run_bench(args, deck, beads, cs, rank, world, device_index, dist, shared, ma
                   rccl_id=rccl_id)
     if cs:
         sim.cluster_switch(cs["mol_seed"], 0, cs["cutoff"], cs["seed"], cs["switch_freq"], cs["rates"], cs["contacts"])
-    sim.setup(args.warmup + args.steps, ntypes=beads.ntypes)
-    sim.run(args.warmup)
+    equil = getattr(args, "equilibrate", 0)
+    sim.setup(equil + args.warmup + args.steps, ntypes=beads.ntypes)
+    sim.run(equil + args.warmup)  # input preparation (melt the lattice), then the warm-up
     ctx.synchronize()
     ctx.profile_enable(True)
     ctx.profile_read(reset=True)

@@ -164,3 +164,33 @@ def test_resident_loop_variants_give_the_same_bits(fresh_ctx, pkg, orc, style, u
     assert np.array_equal(G["tag"], O["tag"]) and np.array_equal(G["ucgstate"], O["ucgstate"])
     for k in ("x", "v", "f", "ucgl", "ucgvl", "ucgforce", "scores", "ucgp"):
         assert util.bits_equal(G[k], O[k]), k
+
+
+def test_md_run_reports_table_range_errors(fresh_ctx, pkg):
+    """a bead driven inside the tables' inner cutoff DURING a resident run: ucg_md_run itself returns the reference's
+    error (UCG/pair_table_ucgld.cpp:436-444, error->one) -- the sticky device flag is polled at every re-neighbouring,
+    on thermo steps and after the last step, not only when the caller remembers ucg_pair_check_errors"""
+    deck = util.make_deck("spline", 1024)
+    beads = pkg.synth.make_beads(8, seed=3)
+    # bead 0 and its nearest neighbour approach head-on, far too fast for the repulsion to stop them: ~1 apart, 0.48
+    # closer after every step of 0.004 at relative speed 120, so inside the tables' inner cutoff 0.6 within two steps
+    d = beads.x - beads.x[0]
+    d -= np.round(d / beads.boxhi) * beads.boxhi
+    r = np.sqrt((d * d).sum(axis=1))
+    r[0] = 1e9
+    j = int(np.argmin(r))
+    u = d[j] / r[j]
+    beads.v[0] = 60.0 * u
+    beads.v[j] = -60.0 * u
+    beads.ucgml[:] = 1.0e9  # lambda stays put
+    ctx = fresh_ctx
+    ctx.set_units(1.0, 1.0, 1.0, 0.004)
+    ctx.upload_beads(beads)
+    ctx.domain_set(beads.boxlo, beads.boxhi, 2.5, 0.3, every=1, delay=0, check=1)
+    gp = util.gpu_pair(ctx, "table_ucgld", deck)
+    ctx.md_attach(gp, nve=True, langevin=False, ucgstate=False)
+    ctx.md_setup(200)
+    with pytest.raises(pkg.capi.UcgError) as ei:
+        ctx.md_run(200, 0)
+    assert ei.value.code in (4, 5) and "table" in str(ei.value)
+    assert ctx.md_info()["ntimestep"] < 200  # stopped at a re-neighbouring, not at the end

@@ -303,3 +303,27 @@ def test_world2_config5_density_with_cluster_switch_vs_oracle(pkg, orc):
     assert (typ != mb.type[tag - 1]).sum() > 0
     assert all(r["nrebuild"] >= 6 and r["nghost"] > 0 for r in res)
     assert np.all(np.isfinite(np.concatenate([r["x"] for r in res])))
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks_and_prints_one_json_line():
+    """`python bench.py --gpus 2 ...` exactly as the driver calls it (no torchrun, no rendezvous environment): the parent
+    starts the ranks before touching the GPU, relays rank 0's single JSON line, and fails when a rank fails.  On this
+    one-GPU box the two ranks share the device through the callback communicator (flagged in config.parallelism)."""
+    import json
+
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--ncell", "14", "--steps", "20",
+                        "--warmup", "5", "--equilibrate", "10"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["unit"] == "timesteps/s" and d["value"] > 0
+    assert d["scaling"] == "strong" and d["config"]["beads"] == 14 ** 3 and "2x1x1" in d["config"]["parallelism"]
+    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    # a wrong option makes a rank fail: the launcher must not hang and must return non-zero
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--ncell", "3", "--steps", "2",
+                        "--warmup", "1", "--equilibrate", "0"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0

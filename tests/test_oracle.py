@@ -433,3 +433,34 @@ def test_cluster_switch_acceptance_rates(orc, pkg):
     assert att == att_on + att_off and suc == suc_on + suc_off and att > 300
     # probON = 0.25 for OFF -> ON, probOFF = 0.75 for ON -> OFF (RanPark draws)
     assert abs(suc_on / att_on - 0.25) < 0.08 and abs(suc_off / att_off - 0.75) < 0.08
+
+
+def test_pair_once_order_agrees_with_the_reference_loop(orc, pkg):
+    """the canonical order of the library's option pair_once (orc_pair_set_once: own-block pairs swept from one row,
+    the partner's share accumulated as integers in units of 2^-40) against the reference's half-list loop"""
+    deck = util.make_deck("spline", 1024)
+    beads = pkg.synth.make_beads(11, seed=8)  # 1331 beads: blocks of 512 / 512 / 307
+    op = util.oracle_pair("table_ucgld", deck, slots=2)
+    op.set_once(512)
+    sim = util.oracle_sim(beads, op, mode=1)
+    sim.rebuild()
+    assert sim.compute_forces(1, 1) == 0
+    A = sim.arrays()
+    op0 = util.oracle_pair("table_ucgld", deck)
+    sim0 = util.oracle_sim(beads, op0, mode=0)
+    sim0.rebuild()
+    assert sim0.compute_forces(1, 1) == 0
+    B = sim0.arrays()
+    for k in ("f", "ucgforce", "scores"):
+        assert np.max(np.abs(A[k] - B[k])) <= 1e-11 * np.max(np.abs(B[k])), k
+    assert abs(sim.ev()["eng_vdwl"] - sim0.ev()["eng_vdwl"]) <= 1e-12 * abs(sim0.ev()["eng_vdwl"])
+    assert np.max(np.abs(A["f"].sum(axis=0))) < 1e-8
+    # and it is a different order from the plain gather (the integer images round at 2^-40)
+    op1 = util.oracle_pair("table_ucgld", deck, slots=2)
+    sim1 = util.oracle_sim(beads, op1, mode=1)
+    sim1.rebuild()
+    assert sim1.compute_forces(1, 1) == 0
+    assert not util.bits_equal(A["f"], sim1.arrays()["f"])
+    # a term beyond the accumulators' range is reported, not wrapped
+    op.set_once(512, 1e-3)
+    assert sim.compute_forces(1, 1) != 0
