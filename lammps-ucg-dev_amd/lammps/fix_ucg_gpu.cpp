@@ -11,6 +11,7 @@
 #include "force.h"
 #include "modify.h"
 #include "pair.h"
+#include "respa.h"
 #include "update.h"
 #include "utils.h"
 
@@ -77,19 +78,41 @@ FixNVEUCGLDGPU::FixNVEUCGLDGPU(LAMMPS *lmp, int narg, char **arg) : FixUCGGPUBas
 
 int FixNVEUCGLDGPU::setmask()
 {
-  return INITIAL_INTEGRATE | FINAL_INTEGRATE;    // rRESPA hooks of the reference are not offered
+  return INITIAL_INTEGRATE | FINAL_INTEGRATE | INITIAL_INTEGRATE_RESPA | FINAL_INTEGRATE_RESPA;    // UCG/fix_nve_ucgld.cpp:27-34
 }
 
 void FixNVEUCGLDGPU::init()
 {
   FixUCGGPUBase::init();
-  if (utils::strmatch(update->integrate_style, "^respa")) error->all(FLERR, "USER-UCG/GPU integrators do not support rRESPA");
-  if (atom->rmass) error->all(FLERR, "USER-UCG/GPU integrators use per-type masses (the reference's else branch)");
+  if (utils::strmatch(update->integrate_style, "^respa")) step_respa = (dynamic_cast<Respa *>(update->integrate))->step;
+  // atom style ucg has per-type masses (mass_type = PER_TYPE, UCG/atom_vec_ucg.cpp:36), so the reference's rmass branch
+  // (UCG/fix_nve_ucgld.cpp:64-78, 124-138) is reachable only through atom_style hybrid with a per-atom-mass style
+  if (atom->rmass) error->all(FLERR, "USER-UCG/GPU integrators use the per-type masses of atom style ucg");
+}
+
+void FixNVEUCGLDGPU::set_step(double dt)
+{
+  // dtv = dt, dtf = 0.5 * dt * ftm2v are formed inside the library from the context's dt
+  check(ucg_ctx_set_units(ctx, force->boltz, force->ftm2v, force->mvv2e, dt, force->special_lj));
 }
 
 void FixNVEUCGLDGPU::reset_dt()
 {
-  check(ucg_ctx_set_units(ctx, force->boltz, force->ftm2v, force->mvv2e, update->dt, force->special_lj));
+  set_step(update->dt);
+}
+
+// rRESPA (UCG/fix_nve_ucgld.cpp:155-173): the level's step; the innermost level moves x and lambda, the others only kick
+void FixNVEUCGLDGPU::initial_integrate_respa(int vflag, int ilevel, int /*iloop*/)
+{
+  set_step(step_respa[ilevel]);
+  if (ilevel == 0) initial_integrate(vflag);
+  else final_integrate();
+}
+
+void FixNVEUCGLDGPU::final_integrate_respa(int ilevel, int /*iloop*/)
+{
+  set_step(step_respa[ilevel]);
+  final_integrate();
 }
 
 void FixNVEUCGLDGPU::initial_integrate(int)

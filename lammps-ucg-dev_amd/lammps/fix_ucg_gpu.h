@@ -58,10 +58,14 @@ class FixNVEUCGLDGPU : public FixUCGGPUBase {
   void init() override;
   void initial_integrate(int) override;
   void final_integrate() override;
+  void initial_integrate_respa(int, int, int) override;
+  void final_integrate_respa(int, int) override;
   void reset_dt() override;
 
  protected:
   bool wall = false;
+  double *step_respa = nullptr;
+  void set_step(double dt);
 };
 
 class FixNVEUCGLDWallHardGPU : public FixNVEUCGLDGPU {

@@ -138,12 +138,24 @@ class AtomVec : protected Pointers {
   void setup_fields();
 };
 
+class Integrate : protected Pointers {
+ public:
+  Integrate(LAMMPS *, int, char **);
+};
+class Respa : public Integrate {
+ public:
+  Respa(LAMMPS *, int, char **);
+  int nlevels;
+  double *step;
+};
+
 class Update : protected Pointers {
  public:
   Update(LAMMPS *);
   double dt;
   bigint ntimestep, beginstep, endstep;
   char *integrate_style;
+  Integrate *integrate;
 };
 
 class Force : protected Pointers {
@@ -222,7 +234,8 @@ namespace FixConst {
 enum {
   INITIAL_INTEGRATE = 1 << 0, POST_INTEGRATE = 1 << 1, PRE_EXCHANGE = 1 << 2, PRE_NEIGHBOR = 1 << 3,
   POST_NEIGHBOR = 1 << 4, PRE_FORCE = 1 << 5, PRE_REVERSE = 1 << 6, POST_FORCE = 1 << 7, FINAL_INTEGRATE = 1 << 8,
-  END_OF_STEP = 1 << 9, POST_RUN = 1 << 10, MIN_PRE_EXCHANGE = 1 << 16, MIN_PRE_NEIGHBOR = 1 << 17,
+  END_OF_STEP = 1 << 9, POST_RUN = 1 << 10, INITIAL_INTEGRATE_RESPA = 1 << 11, POST_INTEGRATE_RESPA = 1 << 12,
+  PRE_FORCE_RESPA = 1 << 13, POST_FORCE_RESPA = 1 << 14, FINAL_INTEGRATE_RESPA = 1 << 15, MIN_PRE_EXCHANGE = 1 << 16, MIN_PRE_NEIGHBOR = 1 << 17,
   MIN_POST_NEIGHBOR = 1 << 18, MIN_PRE_FORCE = 1 << 19, MIN_PRE_REVERSE = 1 << 20, MIN_POST_FORCE = 1 << 21
 };
 }
@@ -240,6 +253,8 @@ class Fix : protected Pointers {
   virtual void initial_integrate(int) {}
   virtual void post_force(int) {}
   virtual void final_integrate() {}
+  virtual void initial_integrate_respa(int, int, int) {}
+  virtual void final_integrate_respa(int, int) {}
   virtual void end_of_step() {}
   virtual void pre_exchange() {}
   virtual void reset_dt() {}
