@@ -116,8 +116,8 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass1(const PairDev P, c
     prior[k] = make_double2(p0, 1.0 - p0);
     partial0[k] = 0.5 * (1.0 - th * th) / (0.1 * cth);
   } else {
-    const double e0 = ucg_exp(-P.mu[tk * 2 + 0] / P.kT);
-    const double e1 = ucg_exp(-P.mu[tk * 2 + 1] / P.kT);
+    const double e0 = ucg_exp_nb(-P.mu[tk * 2 + 0] / P.kT);
+    const double e1 = ucg_exp_nb(-P.mu[tk * 2 + 1] / P.kT);
     double den = 0.0;
     den += e0;
     den += e1;
@@ -139,7 +139,7 @@ __device__ __forceinline__ void closure_shipped(const double kT, const double rk
                                                 double &p00, double &p01, double &p10, double &p11)
 {
   const double Jij = u11 + u00 - u01 - u10;
-  const double bij = ucg_exp(FAST ? div_kT(-Jij, kT, rkT, kTp2) : -Jij / kT);
+  const double bij = ucg_exp_nb(FAST ? div_kT(-Jij, kT, rkT, kTp2) : -Jij / kT);
   const double aij = bij - 1.;
   const double Qij = (pi1 + pj1) * aij + 1.;
   const double Dij = sqrt(Qij * Qij - 4. * aij * bij * pi1 * pj1);
@@ -224,8 +224,8 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass2(const PairDev P, c
       const double jnum_f = 1. - n;
       const double mu0 = P.mu[tk * 2 + 0], mu1 = P.mu[tk * 2 + 1];
       if (P.dens_flags[tk * 2 + 1]) {
-        G0 -= kT * ucg_log(prk.x) * jnum_f;
-        G1 -= kT * ucg_log(prk.y) * jnum_f;
+        G0 -= kT * ucg_log_nb(prk.x) * jnum_f;
+        G1 -= kT * ucg_log_nb(prk.y) * jnum_f;
       }
       G0 -= mu0;
       s0 -= mu0 / kT;
@@ -303,8 +303,8 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass2(const PairDev P, c
           ev[6] += sc * (dy * dz * fpair);
         }
         if (dens_k) {
-          G0 -= (q.u10 - q.u00 + kT * ucg_log(p10 / p00));
-          G1 -= (q.u11 - q.u01 + kT * ucg_log(p11 / p01));
+          G0 -= (q.u10 - q.u00 + kT * ucg_log_nb(p10 / p00));
+          G1 -= (q.u11 - q.u01 + kT * ucg_log_nb(p11 / p01));
         }
       }
       ent = ent_n;
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass2(const PairDev P, c
     A.num_ucgstates[k] = 2;
     // posterior (:678-689), index fixed to the bead's type (App. B #8)
     {
-      const double e0 = ucg_exp(s0), e1 = ucg_exp(s1);
+      const double e0 = ucg_exp_nb(s0), e1 = ucg_exp_nb(s1);
       double den = 0.0;
       den += e0;
       den += e1;

@@ -125,8 +125,8 @@ __global__ __launch_bounds__(FIX_BLOCK) void k_ucgstate(const AtomsDev A, const 
     ucgp = 1.0;
   } else {
     const double2 s = A.scores[i];
-    const double e0 = ucg_exp((700.0 < s.x) ? 700.0 : s.x);
-    const double e1 = ucg_exp((700.0 < s.y) ? 700.0 : s.y);
+    const double e0 = ucg_exp_nb((700.0 < s.x) ? 700.0 : s.x);
+    const double e1 = ucg_exp_nb((700.0 < s.y) ? 700.0 : s.y);
     double softmax_denom = 0.0;
     softmax_denom += e0;
     softmax_denom += e1;
@@ -204,8 +204,8 @@ __global__ __launch_bounds__(FIX_BLOCK) void k_post_fused(const AtomsDev A, cons
       ucgp = 1.0;
     } else {
       const double2 s = A.scores[i];
-      const double e0 = ucg_exp((700.0 < s.x) ? 700.0 : s.x);
-      const double e1 = ucg_exp((700.0 < s.y) ? 700.0 : s.y);
+      const double e0 = ucg_exp_nb((700.0 < s.x) ? 700.0 : s.x);
+      const double e1 = ucg_exp_nb((700.0 < s.y) ? 700.0 : s.y);
       double softmax_denom = 0.0;
       softmax_denom += e0;
       softmax_denom += e1;

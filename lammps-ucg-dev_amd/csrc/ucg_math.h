@@ -12,7 +12,7 @@
  * off they produce the same bits under gcc and under hipcc.
  *
  * Every translation unit that includes this header must be compiled with
- * -ffp-contract=off.  tests/test_math.py checks each function against libm
+ * -ffp-contract=off.  tests/test_oracle.py checks each function against libm
  * (<= 1 ulp) so a wrong constant cannot hide behind the shared definition.
  */
 #ifndef UCG_MATH_H
@@ -152,10 +152,37 @@ UCG_HD double ucg_expm1(double x)
   return y;
 }
 
+/* exp(x) without k-dependent control flow for -708 < x <= 709.78 (the rest -- NaN, overflow, the subnormal results --
+ * through ucg_exp): |x| <= ln2/2 is the general formula with k = 0 (see ucg_exp_expm1), the scaling by 2^k is exponent
+ * arithmetic.  Bit for bit ucg_exp (tests/test_oracle.py). */
+UCG_HD double ucg_exp_nb(double x0)
+{
+  const double ln2HI = 6.93147180369123816490e-01;
+  const double ln2LO = 1.90821492927058770002e-10;
+  const double invln2 = 1.44269504088896338700e+00;
+  const double P1 = 1.66666666666666019037e-01;
+  const double P2 = -2.77777777770155933842e-03;
+  const double P3 = 6.61375632143793436117e-05;
+  const double P4 = -1.65339022054652515390e-06;
+  const double P5 = 4.13813679705723846039e-08;
+  if (!(x0 > -708.0 && x0 <= 7.09782712893383973096e+02)) return ucg_exp(x0);
+  const double ax = x0 < 0.0 ? -x0 : x0;
+  const int k = (ax > 0.34657359027997264) ? (int)(invln2 * x0 + (x0 < 0.0 ? -0.5 : 0.5)) : 0; /* -1021 ... 1024 */
+  const double t = (double)k;
+  const double hi = x0 - t * ln2HI;
+  const double lo = t * ln2LO;
+  const double x = hi - lo;
+  const double tt = x * x;
+  const double c = x - tt * (P1 + tt * (P2 + tt * (P3 + tt * (P4 + tt * P5))));
+  const double y = 1.0 - ((lo - (x * c) / (2.0 - c)) - hi);
+  if (k > 1023) return ucg_scalbn_(y, k); /* x within 0.35 of the overflow threshold */
+  return UCG_BITS_U2D(UCG_BITS_D2U(y) + ((uint64_t)(int64_t)k << 52));
+}
+
 /* exp(x) and expm1(x) of the SAME argument (the Bethe closure needs both, UCG/pair_table_ucg_bethe.cpp:550-551), with
  * one shared argument reduction and almost no control flow -- on a GPU the two functions' many early exits and
  * k-dependent formulas make a wavefront run every path one of its 64 lanes takes.  Every result is bit for bit that of
- * ucg_exp / ucg_expm1 above (tests/test_math.py compares them on millions of arguments, all branches included):
+ * ucg_exp / ucg_expm1 above (tests/test_oracle.py compares them on millions of arguments, all branches included):
  *   - |x| <= ln2/2 is the general path with k = 0: then t = 0, hi = x - 0 = x, lo = 0, c = 0, and the k = 0 formulas
  *     are the general ones ((x c)/(c - 2) = -((x c)/(2 - c)) exactly; scaling by 2^0 adds 0 to the exponent);
  *   - expm1's k = 0 and k = -1 results are formed from the shared x - e and selected; the other k (|x| > 1.04) and the
@@ -271,7 +298,129 @@ UCG_HD double ucg_log(double x)
   return dk * ln2_hi - ((s * (f - R) - dk * ln2_lo) - f);
 }
 
+/* log(x) with one fixed instruction sequence for normal positive x not within 2^-20 of a power of two's 1.0 image (the
+ * rest -- zero, negative, subnormal, inf, NaN, |f| < 2^-20 -- through ucg_log): k = 0 is the general formula with dk = 0,
+ * and fdlibm's two polynomial combinations (i > 0 or not) are both formed and one is selected.  Bit for bit ucg_log. */
+UCG_HD double ucg_log_nb(double x0)
+{
+  const double ln2_hi = 6.93147180369123816490e-01;
+  const double ln2_lo = 1.90821492927058770002e-10;
+  const double Lg1 = 6.666666666666735130e-01;
+  const double Lg2 = 3.999999999940941908e-01;
+  const double Lg3 = 2.857142874366239149e-01;
+  const double Lg4 = 2.222219843214978396e-01;
+  const double Lg5 = 1.818357216161805012e-01;
+  const double Lg6 = 1.531383769920937332e-01;
+  const double Lg7 = 1.479819860511658591e-01;
+  uint64_t u = UCG_BITS_D2U(x0);
+  int32_t hx = (int32_t)(u >> 32);
+  if (hx < 0x00100000 || hx >= 0x7ff00000) return ucg_log(x0);
+  int k = (hx >> 20) - 1023;
+  hx &= 0x000fffff;
+  if ((0x000fffff & (2 + hx)) < 3) return ucg_log(x0); /* |f| < 2^-20 */
+  int32_t i = (hx + 0x95f64) & 0x100000;
+  u = (u & 0xffffffffULL) | ((uint64_t)(uint32_t)(hx | (i ^ 0x3ff00000)) << 32);
+  const double x = UCG_BITS_U2D(u);
+  k += (i >> 20);
+  const double f = x - 1.0;
+  const double dk = (double)k;
+  const double s = f / (2.0 + f);
+  const double z = s * s;
+  i = hx - 0x6147a;
+  const double w = z * z;
+  const int32_t j = 0x6b851 - hx;
+  const double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+  const double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+  i |= j;
+  const double R = t2 + t1;
+  const double hfsq = 0.5 * f * f;
+  const double ra = dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+  const double rb = dk * ln2_hi - ((s * (f - R) - dk * ln2_lo) - f);
+  return (i > 0) ? ra : rb;
+}
+
+/* expm1(x) without k-dependent control flow, for 2^-54 <= |x| < 44 (anything else goes through ucg_expm1 in one rarely
+ * taken branch): the reduction is done with k = 0 for |x| <= ln2/2 (then hi = x, lo = 0, c = 0), ALL of fdlibm's
+ * result formulas (k = 0, -1, 1, |k| large, k < 20, k >= 20) are formed from the shared e and one of them is selected.
+ * On a GPU the lanes of a wavefront take different k, and the branchy form runs every formula a lane needs one after
+ * the other, masks and scalar control flow included; this one runs a fixed instruction sequence.  Every result is bit
+ * for bit that of ucg_expm1 (tests/test_oracle.py).  Used by ucg_tanh, whose arguments spread over k = -3 ... 63. */
+UCG_HD double ucg_expm1_nb(double x0)
+{
+  const double ln2_hi = 6.93147180369123816490e-01;
+  const double ln2_lo = 1.90821492927058770002e-10;
+  const double invln2 = 1.44269504088896338700e+00;
+  const double Q1 = -3.33333333333331316428e-02;
+  const double Q2 = 1.58730158725481460165e-03;
+  const double Q3 = -7.93650757867487942473e-05;
+  const double Q4 = 4.00821782732936239552e-06;
+  const double Q5 = -2.01099218183624371326e-07;
+
+  const double ax = x0 < 0.0 ? -x0 : x0;
+  if (!(ax >= 5.551115123125783e-17 && ax < 44.0) || x0 < -38.816242111356935) return ucg_expm1(x0);
+  const int k = (ax > 0.34657359027997264) ? (int)(invln2 * x0 + (x0 < 0.0 ? -0.5 : 0.5)) : 0; /* -56 ... 64 */
+  const double tk = (double)k;
+  const double hi = x0 - tk * ln2_hi;
+  const double lo = tk * ln2_lo;
+  const double x = hi - lo;
+  const double c = (hi - x) - lo;
+  const double hfx = 0.5 * x;
+  const double hxs = x * hfx;
+  const double r1 = 1.0 + hxs * (Q1 + hxs * (Q2 + hxs * (Q3 + hxs * (Q4 + hxs * Q5))));
+  const double t3 = 3.0 - r1 * hfx;
+  double e = hxs * ((r1 - t3) / (6.0 - x * t3));
+  e = (x * (e - c) - c);
+  e -= hxs;
+  const double d = x - e;   /* k = 0: x - (x e - hxs) */
+  const double g = e - x;
+  const uint64_t kbits = (uint64_t)(int64_t)k << 52; /* scaling by 2^k: exponent arithmetic (|k| <= 64, y in [0.25, 4)) */
+  /* k = -1 */
+  const double rm1 = 0.5 * d - 0.5;
+  /* k = 1 */
+  const double r1a = -2.0 * (e - (x + 0.5));
+  const double r1b = 1.0 + 2.0 * d;
+  const double rp1 = (x < -0.25) ? r1a : r1b;
+  /* k <= -2 or k > 56 */
+  const double yA = 1.0 - g;
+  const double rA = UCG_BITS_U2D(UCG_BITS_D2U(yA) + kbits) - 1.0;
+  /* 2 <= k < 20: t = 1 - 2^-k */
+  const int kb = k < 0 ? 0 : (k > 31 ? 31 : k);
+  const double tB = UCG_BITS_U2D(((uint64_t)(0x3ff00000u - (0x200000u >> kb))) << 32);
+  const double yB = tB - g;
+  const double rB = UCG_BITS_U2D(UCG_BITS_D2U(yB) + kbits);
+  /* 20 <= k <= 56: t = 2^-k */
+  const int kc = k < 0 ? 0 : k;
+  const double tC = UCG_BITS_U2D(((uint64_t)(0x3ff - kc)) << 52);
+  double yC = x - (e + tC);
+  yC += 1.0;
+  const double rC = UCG_BITS_U2D(UCG_BITS_D2U(yC) + kbits);
+  double r = (k < 20) ? rB : rC;
+  r = (k <= -2 || k > 56) ? rA : r;
+  r = (k == 1) ? rp1 : r;
+  r = (k == -1) ? rm1 : r;
+  r = (k == 0) ? d : r;
+  return r;
+}
+
+/* tanh as fdlibm forms it from expm1 (the statements of the original, kept below as ucg_tanh_branchy for the regression
+ * test), with the two |x| ranges sharing one division: z = 1 - 2/(t + 2) for |x| >= 1 (t = expm1(2|x|)), z = -t/(t + 2)
+ * below (t = expm1(-2|x|)); same bits. */
 UCG_HD double ucg_tanh(double x)
+{
+  const double ax = x < 0.0 ? -x : x;
+  if (!(ax >= 2.7755575615628914e-17 && ax < 22.0)) {
+    if (x != x) return x;
+    if (ax < 22.0) return x * (1.0 + x); /* |x| < 2^-55 */
+    return x < 0.0 ? -1.0 : 1.0;
+  }
+  const int big = ax >= 1.0;
+  const double t = ucg_expm1_nb(big ? 2.0 * ax : -2.0 * ax);
+  const double q = (big ? 2.0 : -t) / (t + 2.0);
+  const double z = big ? 1.0 - q : q;
+  return x < 0.0 ? -z : z;
+}
+
+UCG_HD double ucg_tanh_branchy(double x)
 {
   if (x != x) return x;
   const double ax = x < 0.0 ? -x : x;

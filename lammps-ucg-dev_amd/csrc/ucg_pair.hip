@@ -471,8 +471,8 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
         }
         if (Q.ucgst) {
           // num_ucgstates is 2 for every bead these kernels handle (set right here in the plain path)
-          const double e0 = ucg_exp((700.0 < s0) ? 700.0 : s0);
-          const double e1 = ucg_exp((700.0 < s1) ? 700.0 : s1);
+          const double e0 = ucg_exp_nb((700.0 < s0) ? 700.0 : s0);
+          const double e1 = ucg_exp_nb((700.0 < s1) ? 700.0 : s1);
           double softmax_denom = 0.0;
           softmax_denom += e0;
           softmax_denom += e1;

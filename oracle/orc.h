@@ -48,6 +48,7 @@ double orc_exp(double x);
 double orc_expm1(double x);
 double orc_log(double x);
 double orc_tanh(double x);
+long long orc_math_selfcheck(long long n, unsigned long long seed);
 
 /* --------------------------------------------------------------- tables */
 

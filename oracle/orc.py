@@ -80,6 +80,8 @@ def lib():
     for fn in ("orc_exp", "orc_expm1", "orc_log", "orc_tanh"):
         getattr(L, fn).argtypes = [C.c_double]
         getattr(L, fn).restype = C.c_double
+    L.orc_math_selfcheck.argtypes = [C.c_longlong, C.c_ulonglong]
+    L.orc_math_selfcheck.restype = C.c_longlong
     L.orc_pair_create.argtypes = [C.c_int]
     L.orc_pair_create.restype = C.c_void_p
     L.orc_pair_destroy.argtypes = [C.c_void_p]

@@ -464,3 +464,11 @@ def test_pair_once_order_agrees_with_the_reference_loop(orc, pkg):
     # a term beyond the accumulators' range is reported, not wrapped
     op.set_once(512, 1e-3)
     assert sim.compute_forces(1, 1) != 0
+
+
+def test_branch_light_math_kernels_equal_the_originals_bit_for_bit(orc):
+    """csrc/ucg_math.h: ucg_exp_nb / ucg_expm1_nb / ucg_exp_expm1 / ucg_tanh (fixed instruction sequences, what the HIP
+    kernels run) against ucg_exp / ucg_expm1 / ucg_tanh_branchy (fdlibm's control flow, what the oracle runs) on 8 M
+    arguments over every range and k boundary of the argument reduction"""
+    assert orc.lib().orc_math_selfcheck(8_000_000, 12345) == 0
+    assert orc.lib().orc_math_selfcheck(2_000_000, 987654321) == 0
