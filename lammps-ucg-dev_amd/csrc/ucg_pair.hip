@@ -327,26 +327,23 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
           const double cf01 = k_is_i ? q.f01 : q.f10, cf10 = k_is_i ? q.f10 : q.f01;
           double pm_as_i1, pm_as_i0, pm_as_j1, pm_as_j0;
           {
+            // the usual case first (every bead has been through fix ucgstate: ucgp is set), the first-call rules
+            // (:179-205, :227-253) in ONE rarely taken branch behind it
             const double upm = A.ucgp[m];
-            const bool firstm = upm < -0.999;
-            if (firstm && P.prior_flag == 0) {
-              pm_as_i0 = P.prior_type[tm * 2 + 0];
-              pm_as_i1 = P.prior_type[tm * 2 + 1];
-            } else {
-              pm_as_i1 = lm;
-              pm_as_i0 = 1.0 - lm;
-            }
-            if (firstm) {
+            pm_as_i1 = lm;
+            pm_as_i0 = 1.0 - lm;
+            pm_as_j1 = upm;
+            pm_as_j0 = 1.0 - upm;
+            if (upm < -0.999) {
               if (P.prior_flag == 0) {
+                pm_as_i0 = P.prior_type[tm * 2 + 0];
+                pm_as_i1 = P.prior_type[tm * 2 + 1];
                 pm_as_j0 = P.prior_type[tk * 2 + 0];  // row owner's type, as shipped
                 pm_as_j1 = P.prior_type[tk * 2 + 1];
               } else {
                 pm_as_j0 = 1.0 - lm;
                 pm_as_j1 = lm;
               }
-            } else {
-              pm_as_j1 = upm;
-              pm_as_j0 = 1.0 - upm;
             }
           }
           double kj0 = pk_as_j0, kj1 = pk_as_j1;
@@ -365,13 +362,16 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
           const double Qij = (pi1 + pj1) * aij + 1.;
           double Dij = Qij * Qij - 4. * aij * bij * pi1 * pj1;
           Dij = (Dij > 0.0) ? Dij : 0.0;
-          double pij11;
+          double pij11 = pi1 * pj1;
           if (P.method_flag == 1) {
-            if (fabs(aij) < 1.0e-6) pij11 = pi1 * pj1;
-            else if (Qij < 0.0) pij11 = (Qij - sqrt(Dij)) / (2. * aij);
-            else pij11 = (2. * bij * pi1 * pj1) / (Qij + sqrt(Dij));
-          } else {
-            pij11 = pi1 * pj1;
+            // the closure's two quotient forms (:566-575) share the square root and ONE division: numerator and
+            // denominator are selected, not the branch (same operations on the selected operands: same bits)
+            const double sD = sqrt(Dij);
+            const bool neg = Qij < 0.0;
+            const double num = neg ? (Qij - sD) : (2. * bij * pi1 * pj1);
+            const double den = neg ? (2. * aij) : (Qij + sD);
+            const double quo = num / den;
+            pij11 = (fabs(aij) < 1.0e-6) ? pij11 : quo;
           }
           const double pij00 = 1. + pij11 - pi1 - pj1;
           const double pij10 = pi1 - pij11;
