@@ -402,6 +402,10 @@ int poll_pair_errors(ucg_ctx *ctx)
 // ---- the step loop of one rank (upstream Verlet::setup / run), called by ucg_md_setup / ucg_md_run
 int md_setup_multi(ucg_ctx *ctx)
 {
+  if (ctx->dom_world != ctx->comm->world) {
+    ctx->err = "the processor grid of ucg_decomp_set and the attached communicator have different rank counts";
+    return UCG_ERR_INVALID;
+  }
   return guarded_comm(ctx, [&]() -> int {
     if (ctx->cs && !ctx->comm->cluster_synced) UCG_RC(multi_cluster_sync_after_create(ctx));
     UCG_RC(multi_rebuild(ctx));
