@@ -440,7 +440,7 @@ def main():
     if cs:
         wl_fix += (f"2 actual atom types (ON / OFF), molecules of {cs['molecule_size']} beads, fix cluster_switch {cs['mol_seed']} 0 "
                    f"{cs['cutoff']} {cs['seed']} {cs['switch_freq']} (probON {cs['prob_on']}); ")
-    if world > 1:
+    if world > 1 or "grid" in result:  # (UCG_FORCE_MULTI=1: the decomposed path with one rank)
         par = (f"spatial decomposition {'x'.join(map(str, result['grid']))} bricks, one process per GPU, forward halo = one "
                "neighbour all-to-all per step, no reverse halo; transport: " + result.get("transport", "RCCL"))
     else:

@@ -247,6 +247,7 @@ int ucg_decide_local(ucg_ctx *ctx, int *due, int *flag);
  *   ucg_comm_attach_rccl   built in: RCCL called directly on the context's stream (grouped ncclSend / ncclRecv to the
  *                          <= 7 peers, ncclAllReduce for the small host reductions); the caller only distributes the
  *                          128-byte id of rank 0 (ucg_comm_rccl_unique_id) -- MPI_Bcast in a LAMMPS build;
+ *                          librccl.so.1 is loaded at the first use (environment UCG_RCCL_LIBRARY: another build of it);
  *   ucg_comm_attach        the caller's callbacks (MPI in a LAMMPS build without RCCL, gloo in the tests):
  *     alltoallv      DEVICE buffers; sendbytes[r] bytes for rank r lie in consecutive blocks of `send` in rank
  *                    order, the block received from rank r goes to `recv` in rank order; must be ordered after the

@@ -17,6 +17,7 @@
 // per-molecule arrays of fix cluster_switch) go through the same communicator.
 #include <dlfcn.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -42,9 +43,18 @@ struct Rccl {
   bool load()
   {
     if (lib) return true;
-    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-      lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-      if (lib) break;
+    // UCG_RCCL_LIBRARY: a site's own build of RCCL (or, in the tests, a name that does not exist)
+    if (const char *own = getenv("UCG_RCCL_LIBRARY")) {
+      lib = dlopen(own, RTLD_NOW | RTLD_LOCAL);
+      if (!lib) {
+        err = std::string("UCG_RCCL_LIBRARY=") + own + " could not be loaded";
+        return false;
+      }
+    } else {
+      for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (lib) break;
+      }
     }
     if (!lib) {
       err = "librccl.so.1 could not be loaded";

@@ -263,10 +263,29 @@ class RankSim:
         self.me, self.world = transport.rank, transport.world
         self.use_langevin, self.use_ucgstate = use_langevin, use_ucgstate
         ctx.decomp_set(self.grid, self.me)
+        self.host_comm = None
+        self.transport_note = None
         if rccl_id is not None:
-            ctx.comm_attach_rccl(rccl_id, self.me, self.world)
-            self.host_comm = None
-        else:
+            # every rank reports whether RCCL came up (and a first all-reduce gives the rank count); if any did not,
+            # ALL ranks fall back to the host-staged callbacks together, and the caller is told (transport_note)
+            why = None
+            try:
+                ctx.comm_attach_rccl(rccl_id, self.me, self.world)
+                if int(round(float(ctx.comm_allreduce_sum([1.0])[0]))) != self.world:
+                    why = "first ncclAllReduce returned a wrong rank count"
+            except Exception as e:  # noqa: BLE001 -- reported below, by every rank
+                why = f"{type(e).__name__}: {e}"
+            reasons = [None] * self.world
+            transport.dist.all_gather_object(reasons, why)
+            bad = [f"rank {r}: {w}" for r, w in enumerate(reasons) if w]
+            if bad:
+                try:
+                    ctx.comm_detach()
+                except Exception:  # noqa: BLE001
+                    pass
+                rccl_id = None
+                self.transport_note = "RCCL transport unavailable (" + "; ".join(bad[:2]) + "): host-staged gloo callbacks used instead"
+        if rccl_id is None:
             self.host_comm = HostStagedComm(transport.dist, self.world, self.me)
             ctx.comm_attach(self.me, self.world, self.host_comm.alltoallv, self.host_comm.alltoall_ll,
                             self.host_comm.allreduce_ll, self.host_comm.allreduce_f64)
@@ -343,11 +362,16 @@ def run_bench(args, deck, beads, cs, rank, world, device_index, dist, shared, ma
     use_lang, use_st = attach_fixes(ctx)
     tr = Transport(dist, device, staged=True)  # torch.distributed (gloo): rendezvous, barriers, host-side sums only
     wall = getattr(args, "integrator", "wall") == "wall"
-    rccl_id = None
+    rccl_id = rccl_why = None
     if not shared:  # one GPU per rank: the library's RCCL transport; rank 0's id travels over the gloo group
-        box = [capi.Context.rccl_unique_id() if rank == 0 else None]
+        box = [None, None]
+        if rank == 0:
+            try:
+                box[0] = capi.Context.rccl_unique_id()
+            except Exception as e:  # noqa: BLE001 -- librccl missing: every rank takes the host-staged transport
+                box[1] = f"{type(e).__name__}: {e}"
         dist.broadcast_object_list(box, src=0)
-        rccl_id = box[0]
+        rccl_id, rccl_why = box
     sim = RankSim(ctx, pair, tr, grid, use_langevin=use_lang, use_ucgstate=use_st, integrator="wall" if wall else "nve",
                   rccl_id=rccl_id)
     if cs:
@@ -380,6 +404,8 @@ def run_bench(args, deck, beads, cs, rank, world, device_index, dist, shared, ma
                nlocal_sum=int(tot[2]), rank0_list_entries=info["list_entries"], rank0_nlocal=info["nlocal"],
                transport=(f"gloo callbacks, host-staged: {world} ranks share {torch.cuda.device_count()} GPU(s) (rehearsal of the N > 1 path)"
                           if shared else "RCCL called from the library's C++ step loop (grouped ncclSend / ncclRecv over xGMI)"))
+    if not shared and not ctx.comm_info()["rccl"]:
+        out["transport"] = sim.transport_note or f"RCCL transport unavailable ({rccl_why}): host-staged gloo callbacks used instead"
     if cs:
         out["cluster_switch_vector"] = [float(v) for v in ctx.fix_cluster_switch_vector()]
     return out

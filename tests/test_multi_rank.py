@@ -327,3 +327,21 @@ def test_bench_starts_its_own_ranks_and_prints_one_json_line():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--ncell", "3", "--steps", "2",
                         "--warmup", "1", "--equilibrate", "0"], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode != 0
+
+
+@pytest.mark.gpu
+def test_bench_falls_back_to_host_staged_callbacks_when_rccl_is_missing():
+    """One GPU per rank but no usable librccl (here: UCG_RCCL_LIBRARY names a file that does not exist): every rank
+    takes the callback communicator together, the run completes, and the JSON line says which transport moved the
+    halo -- the driver's N > 1 run must not die on a box whose RCCL does not come up."""
+    import json
+
+    root = os.path.dirname(HERE)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(UCG_FORCE_MULTI="1", UCG_RCCL_LIBRARY="/nonexistent/librccl.so.1", MASTER_PORT="29571")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--ncell", "14", "--steps", "20", "--warmup", "5",
+                        "--equilibrate", "10", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
+    assert d["value"] > 0
+    assert "RCCL transport unavailable" in d["config"]["parallelism"] and "host-staged" in d["config"]["parallelism"]
