@@ -140,3 +140,97 @@ def test_full_size_properties_1M_beads(fresh_ctx, pkg):
     assert np.array_equal(A1["tag"], B1["tag"])
     # the hard walls keep lambda in [0, 1]; posteriors stay inside the clamp of fix ucgstate
     assert np.all((A1["ucgl"] >= 0.0) & (A1["ucgl"] <= 1.0)) and np.all((A1["ucgp"] >= 1e-6) & (A1["ucgp"] <= 1 - 1e-6))
+
+
+def test_full_size_properties_1M_beads_bethe(fresh_ctx, pkg):
+    """BASELINE.json config 3 at its full size: 1,000,000 beads, table_ucg_bethe (method bethe, pseudo yes, prior ucgl)
+    + fix ucgstate + fix nve/ucgld/wall/hard.  No oracle at this size: Newton's third law, posteriors inside the clamp of
+    fix ucgstate, states = round(posterior), and run-to-run bitwise reproducibility across re-neighbourings."""
+    beads = pkg.synth.make_beads(100, seed=12345)
+    deck = util.make_deck("spline", 1024, extra_keywords=("method", "bethe", "pseudo", "yes", "prior", "ucgl"))
+    ctx = fresh_ctx
+    ctx.set_units(1.0, 1.0, 1.0, 0.002)
+    ran = []
+
+    def run(nsteps):
+        nre0 = ctx.md_info()["nrebuild"] if ran else 0
+        ran.append(1)
+        ctx.upload_beads(beads)
+        ctx.domain_set(beads.boxlo, beads.boxhi, 2.5, 0.3, every=10, delay=0, check=1)
+        gp = util.gpu_pair(ctx, "table_ucg_bethe", deck)
+        ctx.fix_ucgstate(None)
+        ctx.fix_nve_ucgld_wall_hard(False, 0.1)
+        ctx.md_attach(gp, nve="wall", langevin=False, ucgstate=True)
+        ctx.md_setup(nsteps)
+        first = ctx.atoms_download()
+        ctx.md_run(nsteps, 0)
+        gp.check_errors()
+        return first, ctx.atoms_download(), ctx.md_info()["nrebuild"] - nre0
+
+    A0, A1, nre = run(25)
+    n = beads.n
+    assert A0["nlocal"] == n and np.array_equal(np.sort(A0["tag"]), np.arange(1, n + 1))
+    f = A0["f"]
+    assert np.all(np.isfinite(f)) and np.all(np.isfinite(A0["scores"]))
+    assert np.max(np.abs(f.sum(axis=0))) < 1e-9 * np.abs(f).sum() / n * np.sqrt(n) + 1e-7
+    assert np.all(A0["ucgforce"] == 0.0)  # table_ucg_bethe never touches ucgforce (UCG/pair_table_ucg_bethe.cpp:457-620)
+    # fix ucgstate without a keyword: state = round(ucgp), lambda = ucgp (UCG/fix_ucgstate.cpp:88-132)
+    assert np.all((A1["ucgp"] >= 1e-6) & (A1["ucgp"] <= 1 - 1e-6))
+    assert np.array_equal(A1["ucgstate"], np.round(A1["ucgp"]).astype(np.int32))
+    B0, B1, nre2 = run(25)
+    assert nre2 == nre >= 2
+    for k in ("x", "v", "f", "ucgl", "ucgp", "scores"):
+        assert util.bits_equal(A1[k], B1[k]), k
+    assert np.array_equal(A1["tag"], B1["tag"]) and np.array_equal(A1["ucgstate"], B1["ucgstate"])
+
+
+def test_full_size_properties_4M_beads_density_cluster_switch(fresh_ctx, pkg):
+    """BASELINE.json config 5 at its full size on one GPU: 4,000,000 beads (fcc), table_ucg_bethe_density + fix ucgstate mc
+    + fix cluster_switch on two actual atom types, molecules of two beads.  Size-independent properties: the molecules
+    stay wholly ON or OFF through the switches, switching attempts happen, every bead keeps its identity, the posteriors
+    stay inside fix ucgstate's clamp, and a second run from the same input gives the same bits (the Monte-Carlo draws of
+    fix ucgstate and the RanPark draws of fix cluster_switch included)."""
+    beads = pkg.synth.make_beads(100, seed=12345, lattice="fcc")
+    n = beads.n
+    assert n == 4_000_000
+    deck = util.make_multi_deck(2, "spline", 1024, density=(11.3, 1.5), extra11=0.05, n_file=2000)
+    beads.ntypes = 4
+    beads.mass = np.array([0.0, 1.0, 1.0, 1.0, 1.0])
+    beads.molecule = ((beads.tag - 1) // 2 + 1).astype(np.int32)
+    rng = np.random.default_rng(777)
+    mtype = rng.integers(1, 3, size=int(beads.molecule.max()) + 1)
+    beads.type = mtype[beads.molecule].astype(np.int32)
+    wd = util._tmpdir("ucgcs_")
+    rates, contacts = pkg.synth.write_cluster_switch_files(wd, 0.35, [1], [2], [(1, 1)])
+    mol_seed = int(beads.molecule[np.flatnonzero(beads.type == 1)[0]])
+    ctx = fresh_ctx
+    ctx.set_units(1.0, 1.0, 1.0, 0.002)
+
+    def run(nsteps):
+        ctx.upload_beads(beads)
+        ctx.domain_set(beads.boxlo, beads.boxhi, 2.5, 0.3, every=10, delay=0, check=1)
+        gp = util.gpu_pair_multi(ctx, "table_ucg_bethe_density", deck)
+        ctx.fix_ucgstate("mc", 9127, 0.01)
+        ctx.fix_nve_ucgld_wall_hard(False, 0.1)
+        ctx.fix_cluster_switch(mol_seed, 0, 1.2, 4711, 10, rates, contacts)
+        ctx.md_attach(gp, nve="wall", langevin=False, ucgstate=True)
+        ctx.md_setup(nsteps)
+        ctx.md_run(nsteps, 0)
+        gp.check_errors()
+        return ctx.atoms_download(), ctx.fix_cluster_switch_vector()
+
+    A, va = run(22)
+    assert A["nlocal"] == n and np.array_equal(np.sort(A["tag"]), np.arange(1, n + 1))
+    # types by tag: both beads of a molecule carry the same type, and some molecules changed theirs
+    t = np.empty(n, dtype=np.int32)
+    t[A["tag"] - 1] = A["type"]
+    assert np.array_equal(t[0::2], t[1::2])
+    assert set(np.unique(t)) <= {1, 2}
+    assert int((t != beads.type).sum()) > 0
+    assert np.all(np.isfinite(A["f"])) and np.all((A["ucgp"] >= 1e-6) & (A["ucgp"] <= 1 - 1e-6))
+    B, vb = run(22)
+    for k in ("x", "v", "f", "ucgl", "ucgp"):
+        assert util.bits_equal(A[k], B[k]), k
+    for k in ("tag", "type", "ucgstate"):
+        assert np.array_equal(A[k], B[k]), k
+    assert np.array_equal(va, vb)
