@@ -425,6 +425,15 @@ int ucg_pair_init(ucg_pair *p, int ntypes, double T)
       } else if (ctx->pair_once) {
         ctx->once_beads_wanted = 0;
       }
+      D.hot_type = 0;
+      D.hot_ent = 0;
+      D.tab_hot = nullptr;
+      p->host_tab.clear();
+      p->hot_checked = -1;
+      if (fast && !D.tab_in_lds && !bitmap && M.n_actual > 1 && ctx->hot_block) {
+        p->host_tab = tab;
+        p->host_pairtab = pairtab;
+      }
       D.gather_slots = slots0;
       p->tab_lds_bytes = bytes;
       const size_t own = (size_t) (1024 / slots0) * 36;
@@ -515,6 +524,69 @@ int ucg_pair_tabindex(const ucg_pair *p, int *out, int cap)
 static int pair_compute_impl(ucg_pair *p, int eflag, int vflag, double *eng_vdwl, double *virial, int part,
                              const PostDev *post = nullptr);
 
+namespace {
+__global__ __launch_bounds__(256) void k_type_hist(int n, const int *meta, int *hist)
+{
+  __shared__ int s_h[UCG_MAX_ACTUAL + 1];
+  if (threadIdx.x <= UCG_MAX_ACTUAL) s_h[threadIdx.x] = 0;
+  __syncthreads();
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int t = UCG_META_TYPE(meta[i]);
+    if (t <= UCG_MAX_ACTUAL) atomicAdd(&s_h[t], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x <= UCG_MAX_ACTUAL && s_h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_h[threadIdx.x]);
+}
+}  // namespace
+
+// Tables read through L1 / L2 (several actual types): the block {t00, t01 = t10, t11} of the pairs of the most populous
+// actual type with itself goes to LDS (PairDev::hot_type).  Chosen again after every re-neighbouring (fix cluster_switch
+// changes the populations there); `own_bytes` is what the calling kernel stages next to it.
+static void choose_hot_block(ucg_ctx *ctx, ucg_pair *p, size_t own_bytes)
+{
+  if (p->host_tab.empty() || p->hot_checked == ctx->nrebuild) return;
+  p->hot_checked = ctx->nrebuild;
+  PairDev &D = p->dev;
+  const int na1 = D.n_actual + 1, tl = D.tablength;
+  const int ent = (tl * 7 + 1) / 2;
+  int best = 0;
+  if ((size_t) ent * sizeof(double4) + own_bytes + 6 * 1024 <= 160 * 1024 && ctx->nlocal > 0) {
+    p->d_typehist.reserve(UCG_MAX_ACTUAL + 1);
+    UCG_HIP(hipMemsetAsync(p->d_typehist.get(), 0, (UCG_MAX_ACTUAL + 1) * sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(k_type_hist, dim3(256), dim3(256), 0, ctx->stream, ctx->nlocal, ctx->meta.get(), p->d_typehist.get());
+    int h[UCG_MAX_ACTUAL + 1];
+    d2h(ctx, h, p->d_typehist.get(), UCG_MAX_ACTUAL + 1);
+    sync(ctx);
+    for (int a = 1; a <= D.n_actual && a <= UCG_MAX_ACTUAL; a++) {
+      const int *pt = &p->host_pairtab[((size_t) a * na1 + a) * 4];
+      if (pt[1] != pt[2]) continue;  // (never after init_one: tabindex is symmetric)
+      if (h[a] > (best ? h[best] : 0)) best = a;
+    }
+  }
+  if (best == D.hot_type) return;
+  if (best) {
+    const int *pt = &p->host_pairtab[((size_t) best * na1 + best) * 4];
+    const int ids[3] = {pt[0], pt[1], pt[3]};
+    std::vector<double2> tf((size_t) ent * 2, make_double2(0, 0));
+    for (int k = 0; k < tl; k++)
+      for (int q = 0; q < 3; q++) {
+        const double4 v = p->host_tab[(size_t) ids[q] * tl + k];
+        tf[(size_t) k * 7 + 2 * q] = make_double2(v.x, v.y);
+        tf[(size_t) k * 7 + 2 * q + 1] = make_double2(v.z, v.w);
+      }
+    sync(ctx);  // no launch may still read the block that is replaced
+    p->d_tab_hot.reserve((size_t) ent);
+    h2d(ctx, (double2 *) p->d_tab_hot.get(), tf.data(), tf.size());
+    sync(ctx);
+    D.tab_hot = p->d_tab_hot.get();
+    D.hot_ent = ent;
+  } else {
+    D.tab_hot = nullptr;
+    D.hot_ent = 0;
+  }
+  D.hot_type = best;
+}
+
 int ucg_pair_compute(ucg_pair *p, int eflag, int vflag, double *eng_vdwl, double *virial)
 {
   return pair_compute_impl(p, eflag, vflag, eng_vdwl, virial, 0);
@@ -564,6 +636,13 @@ static int pair_compute_impl(ucg_pair *p, int eflag, int vflag, double *eng_vdwl
       p->dev.gather_slots = slots;
       const size_t own = (size_t) (1024 / slots) * 36;
       p->dev.stage_own = (ctx->stage_own && (p->dev.tab_in_lds ? p->tab_lds_bytes : 0) + own + 6 * 1024 <= 160 * 1024) ? 1 : 0;
+    }
+    if (!p->host_tab.empty()) {
+      // density: its pass 2 stages 1024 beads; the gather kernels 1024 / lanes-per-bead
+      const size_t own = p->model.style == STYLE_BETHE_DENSITY ? (size_t) 1024 * 36 : (size_t) (1024 / p->dev.gather_slots) * 36;
+      choose_hot_block(ctx, p, ctx->stage_own ? own : 0);
+      const size_t hot = (size_t) p->dev.hot_ent * sizeof(double4);
+      p->dev.stage_own = (ctx->stage_own && hot + (size_t) (1024 / p->dev.gather_slots) * 36 + 6 * 1024 <= 160 * 1024) ? 1 : 0;
     }
     const int nb = pair_gather_blocks(ctx->nlocal, p->dev.gather_slots);
     if (ev) p->d_evpart.reserve((size_t) nb * 8 + 8);
@@ -642,6 +721,7 @@ int ucg_pair_density_phase(ucg_pair *p, int phase, int eflag, int vflag, double 
       p->d_partial.reserve((size_t) ctx->nlocal + 1);
       p->d_evpart.reserve((size_t) density_evpart_doubles(ctx->nlocal));
     }
+    if (!p->host_tab.empty()) choose_hot_block(ctx, p, ctx->stage_own ? (size_t) 1024 * 36 : 0);
     UCG_HIP(launch_density_phase(p->dev, ctx->atoms_dev(), ctx->list_dev(), phase, ev, p->d_prior.get(), p->d_partial.get(),
                                  p->d_cv.get(), p->d_evpart.get(), p->d_evout.get(), p->d_err.get(), ctx->stream));
     if (phase == 3 && ev) {
@@ -1423,6 +1503,10 @@ int ucg_ctx_set_option(ucg_ctx *ctx, const char *name, int value)
   if (std::strcmp(name, "pair_once") == 0) {
     ctx->pair_once = value != 0;
     if (!ctx->pair_once) ctx->once_beads_wanted = 0;
+    return UCG_OK;
+  }
+  if (std::strcmp(name, "hot_block") == 0) {
+    ctx->hot_block = value != 0;
     return UCG_OK;
   }
   if (std::strcmp(name, "stage_own") == 0) {

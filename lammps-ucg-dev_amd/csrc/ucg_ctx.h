@@ -140,6 +140,7 @@ struct ucg_ctx {
   ucg::DevBuf<int> meta_alt;
   ucg::DevBuf<double> ucgp_alt;
   bool post_in_pair = true;       // option "post_in_pair"
+  bool hot_block = true;          // option "hot_block": PairDev::hot_type
   ucg::DevBuf<double2> scores;
   ucg::DevBuf<int> meta, tag, mask, num_ucgstates;
   ucg::DevBuf<int> mol;  // atom->molecule of the owned beads (optional: ucg_atoms_upload_molecule)
@@ -213,6 +214,13 @@ struct ucg_pair {
   std::string err;
   size_t tab_lds_bytes = 0;
   bool once = false;  // option pair_once applies: gather_slots 2, rows with own-block pairs once
+  // tables read through L2 (several actual types): host copy of the device tables and the table ids of every
+  // (type, type) pair, from which the LDS block of the most populous type is made (PairDev::hot_type)
+  std::vector<double4> host_tab;
+  std::vector<int> host_pairtab;
+  ucg::DevBuf<double4> d_tab_hot;
+  ucg::DevBuf<int> d_typehist;
+  long long hot_checked = -1;  // ctx->nrebuild at the last choice
   double host_boltz = 1.0;  // used by host-only pairs (no context)
   explicit ucg_pair(int style) : model(style) {}
 };

@@ -169,12 +169,15 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass2(const PairDev P, c
     if (LDS_TAB)
       for (int t = threadIdx.x; t < ntabent; t += blockDim.x) s_tab[t] = (FAST ? P.tab_fast : P.tab)[t];
   }
+  // tables through L1 / L2 with one actual type's block in LDS all the same (PairDev::hot_type)
+  const int hot_ent = (!LDS_TAB && FAST && TS != 3) ? P.hot_ent : 0;
+  for (int t = threadIdx.x; t < hot_ent; t += blockDim.x) s_tab[t] = P.tab_hot[t];
   // the workgroup's own beads behind the tables, as in k_pair_gather; the 4th component carries
   // the bead's prior p1 (lambda is not used by this style)
   const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
   const int k0 = chunk * PAIR_BLOCK;
   const bool stage_own = P.stage_own != 0;
-  double4 *s_ownpos = s_tab + (LDS_TAB ? ntabent : 0);
+  double4 *s_ownpos = s_tab + (LDS_TAB ? ntabent : hot_ent);
   int *s_ownmeta = reinterpret_cast<int *>(s_ownpos + PAIR_BLOCK);
   if (stage_own) {
     for (int t = threadIdx.x; t < PAIR_BLOCK; t += blockDim.x)
@@ -259,7 +262,8 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass2(const PairDev P, c
         const int *pt = s_pairtab + (tk * na1 + tm) * 4;
         Quad q;
         if (LDS_TAB) eval_quad<TS, FAST>(s_tab, s_par, pt, P.tablength, P.tlm1, P.fast_stride, rsq, factor_lj, q, err, rtrack);
-        else eval_quad<TS, FAST>(FAST ? P.tab_fast : P.tab, s_par, pt, P.tablength, P.tlm1, P.fast_stride, rsq, factor_lj, q, err, rtrack);
+        else eval_quad<TS, FAST>(FAST ? P.tab_fast : P.tab, s_par, pt, P.tablength, P.tlm1, P.fast_stride, rsq, factor_lj, q, err, rtrack,
+                                 hot_ent ? reinterpret_cast<const double2 *>(s_tab) : nullptr, tk == P.hot_type && tm == P.hot_type);
         // scores: only the row owner's (:597-603)
         if (FAST) {
           s0 -= div_kT(sm ? q.u01 : q.u00, kT, rkT, kTp2);
@@ -463,13 +467,19 @@ hipError_t launch_pass2(const PairDev &Pin, const AtomsDev &A, const ListDev &L,
     // fewer beads per block)
     const size_t tb = P.fast ? ((size_t) (P.tablength * P.fast_stride + 1) / 2) * sizeof(double4)
                              : (size_t) P.ntab * P.tablength * sizeof(double4);
-    const size_t used = (P.tab_in_lds ? tb : 0) + (size_t) PAIR_BLOCK * (sizeof(double4) + sizeof(int)) + 6 * 1024;
+    const size_t hot = (!P.tab_in_lds && P.fast) ? (size_t) P.hot_ent * sizeof(double4) : 0;
+    size_t used = (P.tab_in_lds ? tb : hot) + (size_t) PAIR_BLOCK * (sizeof(double4) + sizeof(int)) + 6 * 1024;
+    if (hot && used > 160 * 1024) {  // the hot block and the full 1024-bead staging do not both fit: the staging stays
+      P.hot_type = 0;
+      P.hot_ent = 0;
+      used -= hot;
+    }
     P.stage_own = (Pin.stage_own_allowed && used <= 160 * 1024) ? 1 : 0;
   }
   const size_t tabbytes = P.fast ? ((size_t) (P.tablength * P.fast_stride + 1) / 2) * sizeof(double4)
                                  : (size_t) P.ntab * P.tablength * sizeof(double4);
   const size_t ownbytes = P.stage_own ? (size_t) PAIR_BLOCK * (sizeof(double4) + sizeof(int)) : 0;
-  const size_t ldsbytes = (P.tab_in_lds ? tabbytes : 0) + ownbytes;
+  const size_t ldsbytes = (P.tab_in_lds ? tabbytes : (P.fast ? (size_t) P.hot_ent * sizeof(double4) : 0)) + ownbytes;
 #define UCG_LAUNCH(EVF, LDSF, FASTF)                                                                     \
   do {                                                                                                   \
     auto kern = k_density_pass2<TS, EVF, LDSF, FASTF>;                                                   \

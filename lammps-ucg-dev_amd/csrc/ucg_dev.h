@@ -46,6 +46,12 @@ struct PairDev {
   int stage_own;       // 1: k_pair_gather keeps its workgroup's own beads in LDS behind the tables
   int stage_own_allowed;  // the context option "stage_own" (kernels with other block shapes decide the fit themselves)
   int fast;            // 1: one shared r^2 grid, all special_lj == 1, kT usable for div_by_const
+  // FAST tables that do not fit the LDS (several actual types: read through L1 / L2): the three tables of the pairs of
+  // ONE actual type with itself -- the most populous one, chosen by the host -- are staged in LDS all the same, and a lane
+  // whose pair is of that kind reads them there (per-lane generic pointers); 0 = none
+  int hot_type;
+  int hot_ent;            // double4 entries of the hot block: (tablength * 7 + 1) / 2 (the one-type FAST layout, stride 7)
+  const double4 *tab_hot;
   double special_lj[4];
 };
 

@@ -108,7 +108,9 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
   // read from LDS instead of through the vector L1, whose tag rate (one line per lane per load) is
   // what bounds this kernel otherwise.  Same values either way.
   const bool stage_own = ONCE || P.stage_own != 0;
-  double4 *s_ownpos = s_tab + (LDS_TAB ? ntabent : 0);
+  // tables through L1 / L2 with one actual type's block in LDS all the same (PairDev::hot_type)
+  const int hot_ent = (!LDS_TAB && FAST && !ONCE && TS != 3) ? P.hot_ent : 0;
+  double4 *s_ownpos = s_tab + (LDS_TAB ? ntabent : hot_ent);
   int *s_ownmeta = reinterpret_cast<int *>(s_ownpos + PAIR_BLOCK / SLOTS);
   // ONCE: six accumulators per bead, field-major (a wavefront's adds to one field spread over all banks)
   unsigned long long *s_acc = reinterpret_cast<unsigned long long *>(s_ownmeta + PAIR_BLOCK / SLOTS);
@@ -131,6 +133,7 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
     for (int t = threadIdx.x; t < na1sq; t += blockDim.x) s_cutsq[t] = P.cutsq[t];
     if (LDS_TAB)
       for (int t = threadIdx.x; t < ntabent; t += blockDim.x) s_tab[t] = (FAST ? P.tab_fast : P.tab)[t];
+    for (int t = threadIdx.x; t < hot_ent; t += blockDim.x) s_tab[t] = P.tab_hot[t];
     __syncthreads();
   }
 
@@ -268,7 +271,8 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
         }
         Quad q;
         if (LDS_TAB) eval_quad<TS, FAST>(s_tab, s_par, pt, P.tablength, P.tlm1, P.fast_stride, rsq, factor_lj, q, err, rtrack);
-        else eval_quad<TS, FAST>(FAST ? P.tab_fast : P.tab, s_par, pt, P.tablength, P.tlm1, P.fast_stride, rsq, factor_lj, q, err, rtrack);
+        else eval_quad<TS, FAST>(FAST ? P.tab_fast : P.tab, s_par, pt, P.tablength, P.tlm1, P.fast_stride, rsq, factor_lj, q, err, rtrack,
+                                 hot_ent ? reinterpret_cast<const double2 *>(s_tab) : nullptr, tk == P.hot_type && tm == P.hot_type);
 
         double evdwl = 0.0, fpair;
         if (STYLE == 0 || pseudo_flag == 0) {
@@ -594,7 +598,7 @@ hipError_t launch_style_ts(const PairDev &P, const AtomsDev &A, const ListDev &L
   const size_t tabbytes = P.fast ? ((size_t) (P.tablength * P.fast_stride + 1) / 2) * sizeof(double4)
                                  : (size_t) P.ntab * P.tablength * sizeof(double4);
   const size_t ownbytes = P.stage_own ? (size_t) (PAIR_BLOCK / SLOTS) * (sizeof(double4) + sizeof(int)) : 0;
-  const size_t ldsbytes = (P.tab_in_lds ? tabbytes : 0) + ownbytes;
+  const size_t ldsbytes = (P.tab_in_lds ? tabbytes : (P.fast ? (size_t) P.hot_ent * sizeof(double4) : 0)) + ownbytes;
   if (L.once_beads) {
     // rows built for the ONCE variant can only be swept by it (own-block pairs are in one row only)
     if constexpr (STYLE == 0 && SLOTS == 2) {

@@ -173,23 +173,30 @@ __device__ __forceinline__ void table_eval(TabPtr tab, const double4 par, const 
 template <int TS, bool FAST, typename TabPtr>
 __device__ __forceinline__ void eval_quad(TabPtr tab, const double4 *s_par, const int *pt, const int tablength,
                                           const int tlm1, const int fast_stride, const double rsq,
-                                          const double factor_lj, Quad &q, int &err, RangeTrack &rt)
+                                          const double factor_lj, Quad &q, int &err, RangeTrack &rt,
+                                          const double2 *lds_hot = nullptr, const bool hot = false)
 {
   const int t00 = pt[0], t01 = pt[1], t10 = pt[2], t11 = pt[3];
   if (FAST) {
     const double4 par = s_par[0];
     const int it = grid_locate_track(par, tlm1, rsq, rt);
     const Basis B = grid_basis<TS>(par, it, rsq);
-    const double2 *rec = reinterpret_cast<const double2 *>(tab) + it * fast_stride;
-    knot_eval_fast<TS>(rec + 2 * t00, fast_stride, par.w, B, q.f00, q.u00);
-    knot_eval_fast<TS>(rec + 2 * t01, fast_stride, par.w, B, q.f01, q.u01);
+    // hot lanes (PairDev::hot_type: both beads of the actual type whose three tables are staged in LDS) read the LDS
+    // copy {t00, t01 = t10, t11} at stride 7, the others the full layout through L1 / L2: one instruction stream, the
+    // two pointers selected per lane (generic-address loads).  Same values either way.
+    const bool h = lds_hot != nullptr && hot;
+    const double2 *rec = h ? lds_hot + it * 7 : reinterpret_cast<const double2 *>(tab) + it * fast_stride;
+    const int st = h ? 7 : fast_stride;
+    const int o00 = h ? 0 : 2 * t00, o01 = h ? 2 : 2 * t01, o10 = h ? 2 : 2 * t10, o11 = h ? 4 : 2 * t11;
+    knot_eval_fast<TS>(rec + o00, st, par.w, B, q.f00, q.u00);
+    knot_eval_fast<TS>(rec + o01, st, par.w, B, q.f01, q.u01);
     if (t10 == t01) {
       q.f10 = q.f01;
       q.u10 = q.u01;
     } else {
-      knot_eval_fast<TS>(rec + 2 * t10, fast_stride, par.w, B, q.f10, q.u10);
+      knot_eval_fast<TS>(rec + o10, st, par.w, B, q.f10, q.u10);
     }
-    knot_eval_fast<TS>(rec + 2 * t11, fast_stride, par.w, B, q.f11, q.u11);
+    knot_eval_fast<TS>(rec + o11, st, par.w, B, q.f11, q.u11);
   } else {
     table_eval<TS>(tab + t00 * tablength, s_par[t00], tlm1, rsq, err, q.f00, q.u00);
     table_eval<TS>(tab + t01 * tablength, s_par[t01], tlm1, rsq, err, q.f01, q.u01);

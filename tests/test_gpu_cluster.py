@@ -16,10 +16,11 @@ def _setup_gpu(ctx, beads, dt, every):
 
 
 @pytest.mark.parametrize("style", ["table_ucgld", "table_ucg_bethe"])
-@pytest.mark.parametrize("n_actual,tablength", [(2, 256), (3, 128), (2, 1024)])
-def test_several_actual_types_forces_bitwise(fresh_ctx, pkg, orc, style, n_actual, tablength):
+@pytest.mark.parametrize("n_actual,tablength,hot_block", [(2, 256, 1), (3, 128, 1), (2, 1024, 1), (2, 1024, 0), (3, 1024, 1)])
+def test_several_actual_types_forces_bitwise(fresh_ctx, pkg, orc, style, n_actual, tablength, hot_block):
     """tables per actual pair, cutoffs and mu per type: the general (not one-type) path of the pair kernels;
-    2 x 1024-knot decks do not fit LDS and read their tables through L2"""
+    2 x 1024-knot decks do not fit LDS and read their tables through L2, with (option hot_block, the default) the block
+    of the most populous type in LDS next to that path"""
     deck = util.make_multi_deck(n_actual, "spline", tablength)
     beads = util.multi_type_beads(pkg, 9, n_actual, seed=17)
     beads.ucgp = np.clip(np.random.default_rng(3).uniform(size=beads.n), 1e-6, 1 - 1e-6)
@@ -30,6 +31,7 @@ def test_several_actual_types_forces_bitwise(fresh_ctx, pkg, orc, style, n_actua
     O = sim.arrays()
     assert len(np.unique(O["type"])) == n_actual
     ctx = fresh_ctx
+    ctx.set_option("hot_block", hot_block)
     _setup_gpu(ctx, beads, 0.002, 1)
     ctx.neigh_rebuild()
     gp = util.gpu_pair_multi(ctx, style, deck)
@@ -46,6 +48,37 @@ def test_several_actual_types_forces_bitwise(fresh_ctx, pkg, orc, style, n_actua
     sim0.rebuild()
     assert sim0.compute_forces(0, 0) == 0
     assert np.max(np.abs(sim0.arrays()["f"] - G["f"])) < 1e-10
+
+
+@pytest.mark.parametrize("hot_block", [1, 0])
+@pytest.mark.parametrize("tablength", [256, 1024])
+def test_several_actual_types_density_style_bitwise(fresh_ctx, pkg, orc, tablength, hot_block):
+    """table_ucg_bethe_density on two actual types (BASELINE config 5's deck): 256 knots fit the LDS; with 1024 knots
+    the ten tables are read through L2 and -- option hot_block, the default -- the block of the most populous type is
+    staged in LDS next to that path.  Bit for bit the oracle's canonical order either way."""
+    deck = util.make_multi_deck(2, "spline", tablength, density=(11.3, 1.5), extra11=0.05, n_file=2000)
+    beads = util.multi_type_beads(pkg, 9, 2, seed=23)
+    op = util.oracle_pair_multi("table_ucg_bethe_density", deck)
+    sim = util.oracle_sim(beads, op, mode=1)
+    sim.rebuild()
+    ctx = fresh_ctx
+    ctx.set_option("hot_block", hot_block)
+    util.upload_from_oracle(ctx, sim, beads)
+    gp = util.gpu_pair_multi(ctx, "table_ucg_bethe_density", deck)
+    eng, vir = gp.compute(1, 1)
+    gp.check_errors()
+    G = ctx.atoms_download()
+    assert sim.compute_forces(1, 1) == 0
+    O = sim.arrays()
+    assert len(np.unique(O["type"])) == 2 and not np.isnan(G["f"]).any()
+    for k in ("f", "scores", "ucgp"):
+        assert util.bits_equal(G[k], O[k]), k
+    ev = sim.ev()
+    assert abs(eng - ev["eng_vdwl"]) <= 1e-12 * abs(ev["eng_vdwl"])
+    # and without energies (the kernels of an ordinary step)
+    gp.compute(0, 0)
+    G2 = ctx.atoms_download()
+    assert util.bits_equal(G2["f"], O["f"]) and util.bits_equal(G2["scores"], O["scores"])
 
 
 def _cluster_case(pkg, ncell, seed, molecule_size, prob_on, cutoff):
