@@ -78,8 +78,9 @@ int ucg_ctx_set_units(ucg_ctx *ctx, double boltz, double ftm2v, double mvv2e, do
  *                   part of the canonical summation order (ucg_pair_gather_slots reports the value in use)
  *   "rng_batch"     steps of per-bead RanMars draws generated per launch, 1..64 (default 10)
  *   "stage_own"     own-block staging of the gather kernels in LDS (default 1)
- *   "hot_block"     tables too large for the LDS (several actual types): the three tables of the pairs of the most
- *                   populous actual type with itself are staged in LDS all the same (default 1; before ucg_pair_init)
+ *   "hot_block"     tables too large for the LDS: with several actual types the three tables of the pairs of the most
+ *                   populous type with itself, with one type the far end of the r^2 grid, are staged in LDS all the
+ *                   same and read there by the lanes they serve (default 1; set before ucg_pair_init)
  *   "post_in_pair"  per-bead hooks in the gather kernel's epilogue (default 1), "md_no_fuse" = 1 runs every hook as
  *                   its own kernel
  *   "rows_untiled"  = 1 builds neighbour rows with the one-lane-per-bead kernels (the fallback of the tiled builder)

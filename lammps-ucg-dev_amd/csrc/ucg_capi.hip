@@ -427,6 +427,7 @@ int ucg_pair_init(ucg_pair *p, int ntypes, double T)
       }
       D.hot_type = 0;
       D.hot_ent = 0;
+      D.hot_k0 = -1;
       D.tab_hot = nullptr;
       p->host_tab.clear();
       p->hot_checked = -1;
@@ -434,10 +435,25 @@ int ucg_pair_init(ucg_pair *p, int ntypes, double T)
         p->host_tab = tab;
         p->host_pairtab = pairtab;
       }
+      if (fast && !D.tab_in_lds && !bitmap && M.n_actual == 1 && ctx->hot_block) {
+        // one actual type, tables too long for the LDS: the knots of the far end of the r^2 grid -- as many as fit next
+        // to 1024 staged beads -- are kept there (PairDev::hot_k0); the window starts at an even knot so that it is a
+        // double4-aligned piece of the FAST layout
+        const size_t budget = 160 * 1024 - 6 * 1024 - (ctx->stage_own ? (size_t) 1024 * 36 : 0) - 1024;
+        int nk = (int) (budget / ((size_t) D.fast_stride * sizeof(double2)));
+        int k0 = tl - nk;
+        if (k0 < 0) k0 = 0;
+        k0 += k0 & 1;
+        if (tl - k0 >= 64) {
+          D.hot_k0 = k0;
+          D.hot_ent = (int) (((size_t) (tl - k0) * D.fast_stride + 1) / 2);
+          D.tab_hot = p->d_tab_fast.get() + ((size_t) k0 * D.fast_stride) / 2;
+        }
+      }
       D.gather_slots = slots0;
-      p->tab_lds_bytes = bytes;
+      p->tab_lds_bytes = D.tab_in_lds ? bytes : (size_t) D.hot_ent * sizeof(double4);
       const size_t own = (size_t) (1024 / slots0) * 36;
-      const size_t used = (D.tab_in_lds ? bytes : 0) + own + 6 * 1024;  // + the static model arrays
+      const size_t used = p->tab_lds_bytes + own + 6 * 1024;  // + the static model arrays
       D.stage_own = (ctx->stage_own && used <= 160 * 1024) ? 1 : 0;
       D.stage_own_allowed = ctx->stage_own ? 1 : 0;
     }
@@ -635,13 +651,14 @@ static int pair_compute_impl(ucg_pair *p, int eflag, int vflag, double *eng_vdwl
       }
       p->dev.gather_slots = slots;
       const size_t own = (size_t) (1024 / slots) * 36;
-      p->dev.stage_own = (ctx->stage_own && (p->dev.tab_in_lds ? p->tab_lds_bytes : 0) + own + 6 * 1024 <= 160 * 1024) ? 1 : 0;
+      p->dev.stage_own = (ctx->stage_own && p->tab_lds_bytes + own + 6 * 1024 <= 160 * 1024) ? 1 : 0;
     }
     if (!p->host_tab.empty()) {
       // density: its pass 2 stages 1024 beads; the gather kernels 1024 / lanes-per-bead
       const size_t own = p->model.style == STYLE_BETHE_DENSITY ? (size_t) 1024 * 36 : (size_t) (1024 / p->dev.gather_slots) * 36;
       choose_hot_block(ctx, p, ctx->stage_own ? own : 0);
       const size_t hot = (size_t) p->dev.hot_ent * sizeof(double4);
+      p->tab_lds_bytes = hot;
       p->dev.stage_own = (ctx->stage_own && hot + (size_t) (1024 / p->dev.gather_slots) * 36 + 6 * 1024 <= 160 * 1024) ? 1 : 0;
     }
     const int nb = pair_gather_blocks(ctx->nlocal, p->dev.gather_slots);

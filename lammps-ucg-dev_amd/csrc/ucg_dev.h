@@ -51,6 +51,10 @@ struct PairDev {
   // whose pair is of that kind reads them there (per-lane generic pointers); 0 = none
   int hot_type;
   int hot_ent;            // double4 entries of the hot block: (tablength * 7 + 1) / 2 (the one-type FAST layout, stride 7)
+  // ... or, ONE actual type whose tables are too long for the LDS: hot_k0 >= 0 and the LDS holds the knots hot_k0 ..
+  // tablength - 1 of the FAST layout as it is (the far end of the r^2 grid, where most pairs are); a lane whose knot
+  // lies in that window reads it there
+  int hot_k0;
   const double4 *tab_hot;
   double special_lj[4];
 };

@@ -174,7 +174,7 @@ template <int TS, bool FAST, typename TabPtr>
 __device__ __forceinline__ void eval_quad(TabPtr tab, const double4 *s_par, const int *pt, const int tablength,
                                           const int tlm1, const int fast_stride, const double rsq,
                                           const double factor_lj, Quad &q, int &err, RangeTrack &rt,
-                                          const double2 *lds_hot = nullptr, const bool hot = false)
+                                          const double2 *lds_hot = nullptr, const bool hot = false, const int hot_k0 = -1)
 {
   const int t00 = pt[0], t01 = pt[1], t10 = pt[2], t11 = pt[3];
   if (FAST) {
@@ -184,10 +184,15 @@ __device__ __forceinline__ void eval_quad(TabPtr tab, const double4 *s_par, cons
     // hot lanes (PairDev::hot_type: both beads of the actual type whose three tables are staged in LDS) read the LDS
     // copy {t00, t01 = t10, t11} at stride 7, the others the full layout through L1 / L2: one instruction stream, the
     // two pointers selected per lane (generic-address loads).  Same values either way.
-    const bool h = lds_hot != nullptr && hot;
-    const double2 *rec = h ? lds_hot + it * 7 : reinterpret_cast<const double2 *>(tab) + it * fast_stride;
-    const int st = h ? 7 : fast_stride;
-    const int o00 = h ? 0 : 2 * t00, o01 = h ? 2 : 2 * t01, o10 = h ? 2 : 2 * t10, o11 = h ? 4 : 2 * t11;
+    // (hot_k0 >= 0, one actual type with long tables: the LDS holds the knots from hot_k0 on in the same layout, and the
+    // lanes whose knot lies there are the hot ones)
+    const bool window = hot_k0 >= 0;  // uniform
+    const bool h = lds_hot != nullptr && (window ? it >= hot_k0 : hot);
+    const bool hb = h && !window;
+    const double2 *rec = h ? (window ? lds_hot + (it - hot_k0) * fast_stride : lds_hot + it * 7)
+                           : reinterpret_cast<const double2 *>(tab) + it * fast_stride;
+    const int st = hb ? 7 : fast_stride;
+    const int o00 = hb ? 0 : 2 * t00, o01 = hb ? 2 : 2 * t01, o10 = hb ? 2 : 2 * t10, o11 = hb ? 4 : 2 * t11;
     knot_eval_fast<TS>(rec + o00, st, par.w, B, q.f00, q.u00);
     knot_eval_fast<TS>(rec + o01, st, par.w, B, q.f01, q.u01);
     if (t10 == t01) {

@@ -166,6 +166,39 @@ def test_resident_loop_variants_give_the_same_bits(fresh_ctx, pkg, orc, style, u
         assert util.bits_equal(G[k], O[k]), k
 
 
+@pytest.mark.parametrize("hot_block", [1, 0])
+@pytest.mark.parametrize("style,tabstyle,tablength", [("table_ucgld", "spline", 2048), ("table_ucg_bethe", "spline", 4096),
+                                                      ("table_ucgld", "linear", 6000)])
+def test_tables_longer_than_the_lds_trajectories_bitwise(fresh_ctx, pkg, orc, style, tabstyle, tablength, hot_block):
+    """one actual type whose tables do not fit the LDS: the kernels read them through L2 and -- option hot_block, the
+    default -- keep the far end of the r^2 grid in LDS (PairDev::hot_k0); trajectories equal the oracle's bit for bit
+    with the window and without it"""
+    extra = ("method", "bethe", "pseudo", "yes", "prior", "ucgl") if style == "table_ucg_bethe" else ()
+    deck = util.make_deck(tabstyle, tablength, extra_keywords=extra)
+    beads = pkg.synth.make_beads(8, seed=31)
+    lang = (1.0, 1.0, 1.0, 48279) if style == "table_ucgld" else None
+    op = util.oracle_pair(style, deck)
+    sim = util.oracle_sim(beads, op, mode=1, dt=0.004, langevin=lang, nve=True, ucgstate="ld" if lang else "plain", every=2)
+    assert sim.setup(40) == 0 and sim.run(40, 20) == 0
+    ctx = fresh_ctx
+    ctx.set_option("hot_block", hot_block)
+    _setup_gpu(ctx, beads, 0.004, 2)
+    gp = util.gpu_pair(ctx, style, deck)
+    if lang:
+        ctx.fix_ucgld_langevin(*lang)
+        ctx.fix_ucgstate("ld")
+    else:
+        ctx.fix_ucgstate(None)
+    ctx.md_attach(gp, nve=True, langevin=lang is not None, ucgstate=True)
+    ctx.md_setup(40)
+    ctx.md_run(40, 20)
+    gp.check_errors()
+    G, O = ctx.atoms_download(), sim.arrays()
+    assert np.array_equal(G["tag"], O["tag"]) and np.array_equal(G["ucgstate"], O["ucgstate"])
+    for k in ("x", "v", "f", "ucgl", "ucgvl", "ucgforce", "scores", "ucgp"):
+        assert util.bits_equal(G[k], O[k]), k
+
+
 def test_md_run_reports_table_range_errors(fresh_ctx, pkg):
     """a bead driven inside the tables' inner cutoff DURING a resident run: ucg_md_run itself returns the reference's
     error (UCG/pair_table_ucgld.cpp:436-444, error->one) -- the sticky device flag is polled at every re-neighbouring,
