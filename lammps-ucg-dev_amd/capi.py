@@ -90,10 +90,12 @@ def lib():
     global _LIB
     if _LIB is not None:
         return _LIB
-    if not os.path.exists(LIB_PATH):
-        raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+    # UCG_HIP_LIBRARY: another build of the same sources (tools/asan_cpu.sh: host code under AddressSanitizer / UBSan)
+    path = os.environ.get("UCG_HIP_LIBRARY", LIB_PATH)
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the UCG hot path.")
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     vp = C.c_void_p
     L.ucg_abi_version.restype = C.c_int
     L.ucg_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
