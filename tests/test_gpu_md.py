@@ -199,6 +199,43 @@ def test_tables_longer_than_the_lds_trajectories_bitwise(fresh_ctx, pkg, orc, st
         assert util.bits_equal(G[k], O[k]), k
 
 
+@pytest.mark.parametrize("style,ncell,steps", [("table_ucgld", 64, 16), ("table_ucg_bethe", 64, 16), ("table_ucgld", 100, 12)])
+def test_baseline_size_trajectory_bitwise_vs_oracle(fresh_ctx, pkg, orc, style, ncell, steps):
+    """BASELINE.json config 2 at its full size -- 262 144 beads (64^3), pair_table_ucgld + fix ucgld/langevin (+ fix
+    ucgstate ld, fix nve/ucgld/wall/hard) -- against the ORACLE, bit for bit, over a re-neighbouring: 256 workgroups of the
+    gather kernel (one full round of the chip), ~1800 bricks of the row builder, 69 k periodic images.  The Bethe style
+    runs the same size once, and the headline workload (1 000 000 beads: 977 workgroups, 164 k images) a dozen steps."""
+    bethe = style == "table_ucg_bethe"
+    deck = util.make_deck("spline", 1024, extra_keywords=("method", "bethe", "pseudo", "yes", "prior", "ucgl") if bethe else ())
+    beads = pkg.synth.make_beads(ncell, seed=12345)
+    assert beads.n == ncell ** 3
+    lang = None if bethe else (1.0, 1.0, 1.0, 48279)
+    # at dt = 0.004 the fastest of these beads crosses half the skin after ~8 steps
+    op = util.oracle_pair(style, deck)
+    sim = util.oracle_sim(beads, op, mode=1, dt=0.004, langevin=lang, nve="wall", ucgstate="plain" if bethe else "ld", every=2)
+    assert sim.setup(steps) == 0 and sim.run(steps, 0) == 0
+    ctx = fresh_ctx
+    _setup_gpu(ctx, beads, 0.004, 2)
+    gp = util.gpu_pair(ctx, style, deck)
+    if lang:
+        ctx.fix_ucgld_langevin(*lang)
+        ctx.fix_ucgstate("ld")
+    else:
+        ctx.fix_ucgstate(None)
+    ctx.fix_nve_ucgld_wall_hard(False, 0.1)
+    ctx.md_attach(gp, nve="wall", langevin=lang is not None, ucgstate=True)
+    ctx.md_setup(steps)
+    ctx.md_run(steps, 0)
+    gp.check_errors()
+    info, oinfo = ctx.md_info(), sim.info()
+    assert info["nrebuild"] == oinfo["nrebuild"] >= 2  # setup + at least one re-neighbouring
+    assert info["nghost"] == oinfo["nghost"] and info["list_entries"] == oinfo["nfull"]
+    G, O = ctx.atoms_download(), sim.arrays()
+    assert np.array_equal(G["tag"], O["tag"]) and np.array_equal(G["ucgstate"], O["ucgstate"])
+    for k in ("x", "v", "f", "ucgl", "ucgvl", "ucgforce", "scores", "ucgp"):
+        assert util.bits_equal(G[k], O[k]), k
+
+
 def test_md_run_reports_table_range_errors(fresh_ctx, pkg):
     """a bead driven inside the tables' inner cutoff DURING a resident run: ucg_md_run itself returns the reference's
     error (UCG/pair_table_ucgld.cpp:436-444, error->one) -- the sticky device flag is polled at every re-neighbouring,
