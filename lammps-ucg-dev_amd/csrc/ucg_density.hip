@@ -416,8 +416,8 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass3(const PairDev P, c
         }
         if (in_m) {
           double w;
-          if (onetype && in_k) {
-            w = w_own;  // same type: same threshold radius, same value
+          if (tm == tk && in_k) {
+            w = w_own;  // same type: same threshold radius, same arithmetic (prox_arg is the IEEE quotient), same value
           } else {
             const double rth_m = P.dens_par[tm * 2 + 1];
             const double w_m = 0.1 * rth_m;
