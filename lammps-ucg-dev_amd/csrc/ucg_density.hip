@@ -132,15 +132,20 @@ __global__ __launch_bounds__(DENS_BLOCK) void k_ghost_copy2(int ng, int nlocal, 
   if (g < ng) arr[nlocal + g] = arr[ghost_src[g]];
 }
 
-// closure as shipped (:608-622): a = b - 1, no guards
+// closure as shipped (:608-622): a = b - 1, no guards.  In two parts: the coupling (b = exp(-J / kT), a = b - 1) depends on
+// the four energies only, the pair probabilities on it and on the two priors.
 template <bool FAST>
-__device__ __forceinline__ void closure_shipped(const double kT, const double rkT, const int kTp2, const double u00, const double u01,
-                                                const double u10, const double u11, const double pi1, const double pj1,
-                                                double &p00, double &p01, double &p10, double &p11)
+__device__ __forceinline__ void closure_coupling(const double kT, const double rkT, const int kTp2, const double u00,
+                                                 const double u01, const double u10, const double u11, double &aij, double &bij)
 {
   const double Jij = u11 + u00 - u01 - u10;
-  const double bij = ucg_exp_nb(FAST ? div_kT(-Jij, kT, rkT, kTp2) : -Jij / kT);
-  const double aij = bij - 1.;
+  bij = ucg_exp_nb(FAST ? div_kT(-Jij, kT, rkT, kTp2) : -Jij / kT);
+  aij = bij - 1.;
+}
+
+__device__ __forceinline__ void closure_probs(const double aij, const double bij, const double pi1, const double pj1, double &p00,
+                                              double &p01, double &p10, double &p11)
+{
   const double Qij = (pi1 + pj1) * aij + 1.;
   const double Dij = sqrt(Qij * Qij - 4. * aij * bij * pi1 * pj1);
   p11 = (Qij - Dij) / 2. / aij;
@@ -274,7 +279,9 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass2(const PairDev P, c
         }
         const double pm1 = pm.w;
         double p00, p01, p10, p11;
-        closure_shipped<FAST>(kT, rkT, kTp2, q.u00, q.u01, q.u10, q.u11, prk.y, pm1, p00, p01, p10, p11);
+        double aij, bij;
+        closure_coupling<FAST>(kT, rkT, kTp2, q.u00, q.u01, q.u10, q.u11, aij, bij);
+        closure_probs(aij, bij, prk.y, pm1, p00, p01, p10, p11);
         double evdwl = p00 * q.u00 + p01 * q.u01 + p10 * q.u10 + p11 * q.u11;
         double fpair = p00 * q.f00 + p01 * q.f01 + p10 * q.f10 + p11 * q.f11;
         const bool m_owned = m < nlocal;
@@ -287,8 +294,12 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass2(const PairDev P, c
         fz += dz * fpair;
         if (m_owned) {
           // what m's own visit of this pair sends to k: roles swapped (its u[a][b] is our u[b][a])
-          double t00, t01, t10, t11;
-          closure_shipped<FAST>(kT, rkT, kTp2, q.u00, q.u10, q.u01, q.u11, pm1, prk.y, t00, t01, t10, t11);
+          // With ONE table for both mixed states (pairs of one actual type: eval_quad copies u10 = u01) its J is our J
+          // bit for bit -- (u11 + u00 - x) - x either way -- and so are b = exp(-J / kT) and a: only a pair of two types
+          // evaluates the exponential a second time.
+          double t00, t01, t10, t11, am = aij, bm = bij;
+          if (pt[1] != pt[2]) closure_coupling<FAST>(kT, rkT, kTp2, q.u00, q.u10, q.u01, q.u11, am, bm);
+          closure_probs(am, bm, pm1, prk.y, t00, t01, t10, t11);
           double fpj = t00 * q.f00 + t01 * q.f10 + t10 * q.f01 + t11 * q.f11;
           fpj = fpj * 0.5;
           const double djx = pm.x - pk.x, djy = pm.y - pk.y, djz = pm.z - pk.z;
