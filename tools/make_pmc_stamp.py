@@ -24,12 +24,13 @@ for f in glob.glob(os.path.join(root, "*", "*", "*counter_collection.csv")):
             continue
         acc[r["Counter_Name"]][0] += float(r["Counter_Value"])
         acc[r["Counter_Name"]][1] += 1
-        names.add(r["Kernel_Name"].split("(")[0])
+        kn = r["Kernel_Name"]
+        names.add(kn[:kn.find("(ucg::PairDev")] if "(ucg::PairDev" in kn else kn[:120])
 mean = {k: v[0] / v[1] for k, v in acc.items() if v[1]}
 passes = 3 if style == "table_ucg_bethe_density" else 1  # the density style's three kernels per evaluation
 stamp = {
     "commit": subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or "unknown",
-    "kernel": sorted(names)[0][:120] if names else kernel_key,
+    "kernel": " + ".join(n.replace("void ", "").replace("ucg::(anonymous namespace)::", "") for n in sorted(names))[:200] if names else kernel_key,
     "workload": f"{style} spline 1024 sc 100",
     # FETCH_SIZE is in KB and reads half the bytes of a wide stream on gfx950 (MI355X_MICROARCH.md, HBM): x2
     "traffic_bytes_per_launch": passes * (2.0 * mean.get("FETCH_SIZE", 0.0) + mean.get("WRITE_SIZE", 0.0)) * 1024.0,
