@@ -22,6 +22,11 @@ for f in glob.glob(os.path.join(root, "*", "*", "*counter_collection.csv")):
         targs = r["Kernel_Name"].split("<", 1)[1].split(">")[0].split(",") if "<" in r["Kernel_Name"] else []
         if style != "table_ucg_bethe_density" and len(targs) > 2 and targs[2].strip() == "true":
             continue
+        if style == "table_ucg_bethe_density":  # k_density_pass2<TS, EV, ..>, k_density_pass3<EV>
+            if "k_density_pass2" in r["Kernel_Name"] and len(targs) > 1 and targs[1].strip() == "true":
+                continue
+            if "k_density_pass3" in r["Kernel_Name"] and targs and targs[0].strip() == "true":
+                continue
         acc[r["Counter_Name"]][0] += float(r["Counter_Value"])
         acc[r["Counter_Name"]][1] += 1
         kn = r["Kernel_Name"]
