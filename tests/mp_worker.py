@@ -121,7 +121,7 @@ def main():
         # BASELINE.json config 5 in small: table_ucg_bethe_density (two actual types, both density types) + fix ucgstate mc
         # + fix cluster_switch, decomposed: the density style's two mid-compute halos AND the cluster reductions
         capi = pkg.capi
-        deck = util.make_multi_deck(2, "spline", 256, density=(11.3, 1.5), extra11=0.05)
+        deck = util.make_multi_deck(2, "spline", 1024, density=(11.3, 1.5), extra11=0.05)  # ten tables: through L2 + the LDS hot block
         mb = util.multi_type_beads(pkg, 10, 2, seed=5, molecule_size=2)
         rates, contacts = pkg.synth.write_cluster_switch_files(deck.workdir, 0.35, [1], [2], [(1, 1)])
         mol_seed = int(mb.molecule[np.flatnonzero(mb.type == 1)[0]])

@@ -258,7 +258,7 @@ def test_world2_config5_density_with_cluster_switch_vs_oracle(pkg, orc):
     types), two ranks, against the ORACLE's single-rank run of the same beads: forces, posteriors and states at setup by
     tag, the cluster labels (independent of the decomposition), then 30 steps with switching every 5"""
     res = _launch("gpu_config5")
-    deck = util.make_multi_deck(2, "spline", 256, density=(11.3, 1.5), extra11=0.05)
+    deck = util.make_multi_deck(2, "spline", 1024, density=(11.3, 1.5), extra11=0.05)  # ten tables: through L2 + the LDS hot block
     mb = util.multi_type_beads(pkg, 10, 2, seed=5, molecule_size=2)
     rates, contacts = pkg.synth.write_cluster_switch_files(deck.workdir, 0.35, [1], [2], [(1, 1)])
     mol_seed = res[0]["mol_seed"]
