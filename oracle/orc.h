@@ -12,7 +12,7 @@
  * follows.  Pieces of upstream LAMMPS the path relies on (RanMars, RanPark,
  * ev_tally, Verlet ordering, table file reader) are restated from their
  * published algorithms; RanMars is pinned by the published RANMAR check
- * values (tests/test_oracle_ranmars.py).
+ * values (tests/test_oracle.py).
  *
  * Compile with -O2 -ffp-contract=off (no FMA fusion: the reference is plain
  * x86-64 code, and the HIP kernels are built the same way).
@@ -41,14 +41,15 @@ typedef struct { int seed; } orc_ranpark;
 void orc_ranpark_init(orc_ranpark *r, int seed);
 double orc_ranpark_uniform(orc_ranpark *r);
 
-/* math selection: 0 = ucg_math.h (bit-reproducible, shared with the GPU),
+/* math selection: 0 = the oracle's own fdlibm-shaped functions (orc_math.c: the written definition
+ *                     "ucg-math-v1", bit-reproducible; nothing of the product tree is included),
  *                 1 = libm (what the reference itself calls)             */
 void orc_set_math(int use_libm);
+int orc_get_math(void);
 double orc_exp(double x);
 double orc_expm1(double x);
 double orc_log(double x);
 double orc_tanh(double x);
-long long orc_math_selfcheck(long long n, unsigned long long seed);
 
 /* --------------------------------------------------------------- tables */
 

@@ -59,9 +59,6 @@ def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "liborc.so")
     srcs = [f for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
     newest = max(os.path.getmtime(os.path.join(_HERE, f)) for f in srcs)
-    mh = os.path.join(_HERE, "..", "lammps-ucg-dev_amd", "csrc", "ucg_math.h")
-    if os.path.exists(mh):
-        newest = max(newest, os.path.getmtime(mh))
     if force or not os.path.exists(so) or os.path.getmtime(so) < newest:
         subprocess.check_call(["make", "-s", "-C", _HERE, "liborc.so"])
     return so
@@ -80,8 +77,6 @@ def lib():
     for fn in ("orc_exp", "orc_expm1", "orc_log", "orc_tanh"):
         getattr(L, fn).argtypes = [C.c_double]
         getattr(L, fn).restype = C.c_double
-    L.orc_math_selfcheck.argtypes = [C.c_longlong, C.c_ulonglong]
-    L.orc_math_selfcheck.restype = C.c_longlong
     L.orc_pair_create.argtypes = [C.c_int]
     L.orc_pair_create.restype = C.c_void_p
     L.orc_pair_destroy.argtypes = [C.c_void_p]
