@@ -40,9 +40,14 @@ struct Rccl {
   int (*GroupEnd)() = nullptr;
   const char *(*GetErrorString)(int) = nullptr;
   std::string err;
+  bool loaded = false;  // every symbol resolved (a half-loaded library must not be called through)
   bool load()
   {
-    if (lib) return true;
+    if (loaded) return true;
+    if (lib) {
+      dlclose(lib);
+      lib = nullptr;
+    }
     // UCG_RCCL_LIBRARY: a site's own build of RCCL (or, in the tests, a name that does not exist)
     if (const char *own = getenv("UCG_RCCL_LIBRARY")) {
       lib = dlopen(own, RTLD_NOW | RTLD_LOCAL);
@@ -64,6 +69,8 @@ struct Rccl {
   field = reinterpret_cast<decltype(field)>(dlsym(lib, sym));      \
   if (!field) {                                                     \
     err = std::string("librccl lacks ") + sym;                      \
+    dlclose(lib);                                                   \
+    lib = nullptr;                                                  \
     return false;                                                   \
   }
     UCG_SYM(GetUniqueId, "ncclGetUniqueId");
@@ -76,6 +83,7 @@ struct Rccl {
     UCG_SYM(GroupEnd, "ncclGroupEnd");
     UCG_SYM(GetErrorString, "ncclGetErrorString");
 #undef UCG_SYM
+    loaded = true;
     return true;
   }
 };
@@ -99,7 +107,7 @@ struct CommState {
 void comm_destroy(ucg_ctx *ctx)
 {
   if (!ctx->comm) return;
-  if (ctx->comm->nccl && g_rccl.CommDestroy) (void) g_rccl.CommDestroy(ctx->comm->nccl);
+  if (ctx->comm->nccl && g_rccl.loaded) (void) g_rccl.CommDestroy(ctx->comm->nccl);
   delete ctx->comm;
   ctx->comm = nullptr;
 }

@@ -120,6 +120,8 @@ TRAJ = [
 def test_state_trajectories_against_libm(fresh_ctx, pkg, orc, style, extra, ucgstate, dt, every):
     steps, chunk = 100, 10
     dens = dict(density=(11.3, 1.5), extra11=0.05) if style.endswith("density") else {}
+    if ucgstate == "plain":
+        dens["mu"] = (0.0, 0.0)  # posteriors around 1/2: round(ucgp) keeps both states populated and is at its most sensitive
     deck = util.make_deck("spline", 1024, extra_keywords=extra, **dens)
     beads = pkg.synth.make_beads(8, seed=31)
     ctx = fresh_ctx
