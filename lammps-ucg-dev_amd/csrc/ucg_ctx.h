@@ -132,6 +132,7 @@ struct ucg_ctx {
   bool rows_untiled = false;           // option "rows_untiled": build rows with the one-lane-per-bead kernels
   bool pair_once = false;              // option "pair_once": own-block pairs evaluated once (see ucg_pair.hip, ONCE variants)
   int once_beads_wanted = 0;           // set by ucg_pair_init when the option applies to that pair: beads per workgroup
+  bool pair_vrow = false;              // option "pair_vrow": own-block pairs once on balanced virtual rows (ucg_pair_vrow.hip)
 
   // atoms
   int nlocal = 0, nghost = 0, ntypes = 0;
@@ -153,6 +154,7 @@ struct ucg_ctx {
   int list_pitch = 0, list_maxrow = 0, list_inum = 0;
   long long list_entries = 0;  // as a FULL list (an own-block pair kept in one row of pair_once rows counts twice)
   long long list_stored = 0;   // entries actually stored in the rows
+  long long list_gen = 0;      // changes whenever the rows change (device build or upload): what derived lists key on
   bool list_from_builder = false;  // rows made by the device builder (which sets no special-bond bits)
   int list_once_beads = 0;   // > 0: the rows hold own-block pairs once (workgroups of this many beads)
   int list_once_maxin = 0;   // ... and no bead is the partner of more than this many such pairs kept elsewhere
@@ -214,6 +216,13 @@ struct ucg_pair {
   std::string err;
   size_t tab_lds_bytes = 0;
   bool once = false;  // option pair_once applies: gather_slots 2, rows with own-block pairs once
+  // option pair_vrow applies: the virtual rows made from the resident full rows (ucg_pair_vrow.hip)
+  bool vrow = false;
+  long long vr_gen = -1;  // ctx->list_gen they were made from
+  int vr_pitch = 0, vr_capA = 0, vr_capB = 0;
+  ucg::DevBuf<int2> d_vr_beadoff, d_vr_lanemeta;
+  ucg::DevBuf<int4> d_vr_blockinfo;
+  ucg::DevBuf<int> d_vr_maxlen, d_vr_entA, d_vr_entB;
   // tables read through L2 (several actual types): host copy of the device tables and the table ids of every
   // (type, type) pair, from which the LDS block of the most populous type is made (PairDev::hot_type)
   std::vector<double4> host_tab;

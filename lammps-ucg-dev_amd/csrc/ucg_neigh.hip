@@ -1027,6 +1027,7 @@ void build_bins_and_rows(ucg_ctx *ctx)
   ctx->list_entries = total + totdrop;  // as a FULL list: an own-block pair kept in one row stands for two entries
   ctx->list_stored = total;
   ctx->list_from_builder = true;
+  ctx->list_gen++;
   ctx->list_once_beads = once_beads;
   ctx->list_once_maxin = maxdrop;
 

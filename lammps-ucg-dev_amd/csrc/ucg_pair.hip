@@ -32,13 +32,6 @@ namespace ucg {
 
 namespace {
 
-// bias_force of fix nve/ucgld/wall/hard (UCG/fix_nve_ucgld_wall_hard.cpp:216-221), as in csrc/ucg_fix.hip
-__device__ __forceinline__ double post_wall_bias(const double lmd, const double H)
-{
-  const double x = lmd - 0.5;
-  return (-7980.0 * x * x * x * x * x * x * x * x * x + 2.0 * x) * 10.0 * H;
-}
-
 // A neighbour's record {x, y, z, lambda | type, state}: from the workgroup's LDS copy when it is one of its own beads,
 // else through L1 / L2.  Written as one select of the two pointers, which the compiler turns into generic-address
 // (flat) loads.  Measured alternative (round 2): two branches, an LDS read and a global load each under its lane mask,
@@ -430,7 +423,6 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
   }
   if (ONCE) __syncthreads();  // every lane of the workgroup has made its adds
   if (active) {
-    const int tk = UCG_META_TYPE(mk);
     if (SLOTS > 1) {
       // fixed tree over the bead's lanes: s[l] += s[l + off], off = SLOTS/2 ... 1
 #pragma unroll
@@ -455,82 +447,9 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
     if (slot == 0) {
       const PostDev &Q = Lst.post;
       if (!EV && Q.enabled) {
-        // Epilogue: the statements of k_post_fused<.., NEXT = true> (csrc/ucg_fix.hip), in the same order, on
-        // the sums this lane holds: [wall/hard bias ->] ucgld/langevin -> ucgstate -> final_integrate -> the
-        // next step's initial_integrate.  f, ucgforce and the scores never reach HBM; x / lambda / state of the
-        // next step go to the second buffers (other workgroups still gather from the current ones).
-        const bool ingroup = (A.mask[k] & Q.groupbit) != 0;
-        int meta = mk;
-        double4 f = make_double4(fx, fy, fz, STYLE == 0 ? uf : 0.0);
-        double4 v = A.vel4[k];
-        double4 x = pk;
-        if (Q.nve == 3 && ingroup) f.w += post_wall_bias(x.w, Q.barrier);
-        if (Q.lang && ingroup) {
-          const double gamma1 = Q.gfactor1[tk];
-          const double gamma2 = Q.gfactor2[tk] * Q.tsqrt;
-          const double uni = (double) Q.lang_draws[k] * 5.9604644775390625e-08;
-          const double fran = gamma2 * (uni - 0.5);
-          const double fdrag = gamma1 * v.w;
-          f.w += fdrag + fran;
-        }
-        if (Q.ucgst) {
-          // num_ucgstates is 2 for every bead these kernels handle (set right here in the plain path)
-          const double e0 = ucg_exp_nb((700.0 < s0) ? 700.0 : s0);
-          const double e1 = ucg_exp_nb((700.0 < s1) ? 700.0 : s1);
-          double softmax_denom = 0.0;
-          softmax_denom += e0;
-          softmax_denom += e1;
-          const double r = e1 / softmax_denom;
-          const double lo = (1e-6 < r) ? r : 1e-6;
-          const double ucgp = (lo < 1.0 - 1e-6) ? lo : 1.0 - 1e-6;
-          if (!Q.ld_flag) {
-            int state;
-            if (Q.mc_flag) {
-              const int cur = UCG_META_STATE(meta);
-              double mc_factor;
-              if (cur == 0) mc_factor = ucgp / (1.0 - ucgp);
-              else mc_factor = (1.0 - ucgp) / ucgp;
-              mc_factor = ((1.0 < mc_factor) ? 1.0 : mc_factor) * Q.mc_rate;
-              const double mc_rand = (double) Q.mc_draws[k] * 5.9604644775390625e-08;
-              state = (mc_rand < mc_factor) ? 0 : 1;
-            } else {
-              state = (int) round(ucgp);
-            }
-            meta = (meta & 0xFFFF) | (state << 16);
-            x.w = ucgp;
-          }
-          Q.ucgp_out[k] = ucgp;  // second buffer: the Bethe variant gathers its neighbours' ucgp in this very launch
-        }
-        if (Q.nve && ingroup) {
-          const double dtfm = Q.dtf / A.mass[UCG_META_TYPE(meta)];
-          const double dtflm = Q.dtf / A.ucgml[k];
-          v.x += dtfm * f.x;
-          v.y += dtfm * f.y;
-          v.z += dtfm * f.z;
-          v.w += dtflm * f.w;
-          if (Q.nve >= 2) {
-            if (x.w < 0.0) {
-              x.w = -x.w;
-              v.w = -v.w;
-            } else if (x.w > 1.0) {
-              x.w = 2.0 - x.w;
-              v.w = -v.w;
-            }
-          }
-          v.x += dtfm * f.x;
-          v.y += dtfm * f.y;
-          v.z += dtfm * f.z;
-          x.x += Q.dtv * v.x;
-          x.y += Q.dtv * v.y;
-          x.z += Q.dtv * v.z;
-          v.w += dtflm * f.w;
-          x.w += Q.dtv * v.w;
-          if (Q.nve >= 2) meta = (meta & 0xFFFF) | ((x.w < 0.5 ? 0 : 1) << 16);
-          A.vel4[k] = v;
-        }
-        Q.pos_out[k] = x;
-        Q.meta_out[k] = meta;
-        A.num_ucgstates[k] = 2;
+        // Epilogue (pair_epilogue, ucg_pair_dev.h): [wall/hard bias ->] ucgld/langevin -> ucgstate -> final_integrate ->
+        // the next step's initial_integrate on the sums this lane holds; f, ucgforce and the scores never reach HBM
+        pair_epilogue<STYLE>(A, Q, k, mk, pk, fx, fy, fz, uf, s0, s1);
       } else {
         if (STYLE == 0) {
           A.frc4[k] = make_double4(fx, fy, fz, uf);
@@ -713,6 +632,12 @@ hipError_t launch_pair_gather(const PairDev &P, const AtomsDev &A, const ListDev
 }
 
 #ifndef UCG_FUSED
+hipError_t launch_ev_final(const double *part, int nblocks, double *out, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_ev_final, dim3(1), dim3(64), 0, st, part, nblocks, out);
+  return hipGetLastError();
+}
+
 hipError_t launch_block_classify(const AtomsDev &A, const ListDev &L, int slots, int *flags, hipStream_t st)
 {
   const int nblocks = pair_gather_blocks(A.nlocal, slots);

@@ -219,6 +219,103 @@ __device__ __forceinline__ void eval_quad(TabPtr tab, const double4 *s_par, cons
   }
 }
 
+// bias_force of fix nve/ucgld/wall/hard (UCG/fix_nve_ucgld_wall_hard.cpp:216-221), as in csrc/ucg_fix.hip
+__device__ __forceinline__ double post_wall_bias(const double lmd, const double H)
+{
+  const double x = lmd - 0.5;
+  return (-7980.0 * x * x * x * x * x * x * x * x * x + 2.0 * x) * 10.0 * H;
+}
+
+// The per-bead hooks that follow the pair force on a step whose next initial_integrate is fused in -- the statements of
+// k_post_fused<.., NEXT = true> (csrc/ucg_fix.hip), in the same order -- applied by the lane that holds a bead's summed
+// force, ucgforce and scores (the gather kernels' epilogue).  x / lambda / state / ucgp of the next step go to the second
+// buffers (other workgroups still gather from the current ones).
+template <int STYLE>
+__device__ __forceinline__ void pair_epilogue(const AtomsDev &A, const PostDev &Q, const int k, const int mk, const double4 pk,
+                                              const double fx, const double fy, const double fz, const double uf,
+                                              const double s0, const double s1)
+{
+  const int tk = UCG_META_TYPE(mk);
+  {
+    // Epilogue: the statements of k_post_fused<.., NEXT = true> (csrc/ucg_fix.hip), in the same order, on
+    // the sums this lane holds: [wall/hard bias ->] ucgld/langevin -> ucgstate -> final_integrate -> the
+    // next step's initial_integrate.  f, ucgforce and the scores never reach HBM; x / lambda / state of the
+    // next step go to the second buffers (other workgroups still gather from the current ones).
+    const bool ingroup = (A.mask[k] & Q.groupbit) != 0;
+    int meta = mk;
+    double4 f = make_double4(fx, fy, fz, STYLE == 0 ? uf : 0.0);
+    double4 v = A.vel4[k];
+    double4 x = pk;
+    if (Q.nve == 3 && ingroup) f.w += post_wall_bias(x.w, Q.barrier);
+    if (Q.lang && ingroup) {
+      const double gamma1 = Q.gfactor1[tk];
+      const double gamma2 = Q.gfactor2[tk] * Q.tsqrt;
+      const double uni = (double) Q.lang_draws[k] * 5.9604644775390625e-08;
+      const double fran = gamma2 * (uni - 0.5);
+      const double fdrag = gamma1 * v.w;
+      f.w += fdrag + fran;
+    }
+    if (Q.ucgst) {
+      // num_ucgstates is 2 for every bead these kernels handle (set right here in the plain path)
+      const double e0 = ucg_exp_nb((700.0 < s0) ? 700.0 : s0);
+      const double e1 = ucg_exp_nb((700.0 < s1) ? 700.0 : s1);
+      double softmax_denom = 0.0;
+      softmax_denom += e0;
+      softmax_denom += e1;
+      const double r = e1 / softmax_denom;
+      const double lo = (1e-6 < r) ? r : 1e-6;
+      const double ucgp = (lo < 1.0 - 1e-6) ? lo : 1.0 - 1e-6;
+      if (!Q.ld_flag) {
+        int state;
+        if (Q.mc_flag) {
+          const int cur = UCG_META_STATE(meta);
+          double mc_factor;
+          if (cur == 0) mc_factor = ucgp / (1.0 - ucgp);
+          else mc_factor = (1.0 - ucgp) / ucgp;
+          mc_factor = ((1.0 < mc_factor) ? 1.0 : mc_factor) * Q.mc_rate;
+          const double mc_rand = (double) Q.mc_draws[k] * 5.9604644775390625e-08;
+          state = (mc_rand < mc_factor) ? 0 : 1;
+        } else {
+          state = (int) round(ucgp);
+        }
+        meta = (meta & 0xFFFF) | (state << 16);
+        x.w = ucgp;
+      }
+      Q.ucgp_out[k] = ucgp;  // second buffer: the Bethe variant gathers its neighbours' ucgp in this very launch
+    }
+    if (Q.nve && ingroup) {
+      const double dtfm = Q.dtf / A.mass[UCG_META_TYPE(meta)];
+      const double dtflm = Q.dtf / A.ucgml[k];
+      v.x += dtfm * f.x;
+      v.y += dtfm * f.y;
+      v.z += dtfm * f.z;
+      v.w += dtflm * f.w;
+      if (Q.nve >= 2) {
+        if (x.w < 0.0) {
+          x.w = -x.w;
+          v.w = -v.w;
+        } else if (x.w > 1.0) {
+          x.w = 2.0 - x.w;
+          v.w = -v.w;
+        }
+      }
+      v.x += dtfm * f.x;
+      v.y += dtfm * f.y;
+      v.z += dtfm * f.z;
+      x.x += Q.dtv * v.x;
+      x.y += Q.dtv * v.y;
+      x.z += Q.dtv * v.z;
+      v.w += dtflm * f.w;
+      x.w += Q.dtv * v.w;
+      if (Q.nve >= 2) meta = (meta & 0xFFFF) | ((x.w < 0.5 ? 0 : 1) << 16);
+      A.vel4[k] = v;
+    }
+    Q.pos_out[k] = x;
+    Q.meta_out[k] = meta;
+    A.num_ucgstates[k] = 2;
+  }
+}
+
 // deterministic block sum of NV doubles per lane -> out[blockIdx.x*NV + c]
 template <int NV>
 __device__ __forceinline__ void block_sum_store(double (&v)[NV], double *red, double *out)
