@@ -286,7 +286,7 @@ def apply_env_options(ctx):
     ctx.set_option("gather_slots", int(os.environ.get("UCG_GATHER_SLOTS", "0")))
     if os.environ.get("UCG_FMA_CONTRACT"):  # NOT the bit-exact path: see DESIGN.md 4.1; never the default
         ctx.set_option("fma_contract", int(os.environ["UCG_FMA_CONTRACT"]))
-    for env, opt in (("UCG_POST_IN_PAIR", "post_in_pair"), ("UCG_STAGE_OWN", "stage_own"), ("UCG_PAIR_ONCE", "pair_once"), ("UCG_PAIR_VROW", "pair_vrow"),
+    for env, opt in (("UCG_POST_IN_PAIR", "post_in_pair"), ("UCG_STAGE_OWN", "stage_own"), ("UCG_PAIR_ONCE", "pair_once"),
                      ("UCG_HOT_BLOCK", "hot_block"), ("UCG_GENERIC_KERNELS", "generic_kernels")):
         if os.environ.get(env):
             ctx.set_option(opt, int(os.environ[env]))

@@ -425,34 +425,6 @@ int ucg_pair_init(ucg_pair *p, int ntypes, double T)
       } else if (ctx->pair_once) {
         ctx->once_beads_wanted = 0;
       }
-      {
-        // fixed-point sums: the smallest r^2 above which no term can reach 8192 (2^-38 units in 64 bits).  Terms are products of a mixing weight
-        // (|.| <= 2.8^2 for lambda in [-1.8, 2.8]; Bethe: probabilities) with F = (f/r) * r, an energy, or an energy / kT.
-        const double wmax = 8.0, ek = std::fmax(1.0, 1.0 / M.kT);
-        int ksafe = tl - 1;
-        for (int k = tl - 1; k >= 0; k--) {
-          double mag = 0.0;
-          for (int d = 0; d < ntab; d++) {
-            const Table &tb = M.tables[(size_t) order[(size_t) d]];
-            if (bitmap || k >= (int) tb.f.size() || k >= (int) tb.e.size()) continue;
-            mag = std::fmax(mag, std::fabs(tb.f[(size_t) k]) * std::sqrt(std::fmax(tb.innersq + k * tb.delta, 0.0)));
-            mag = std::fmax(mag, 2.0 * std::fabs(tb.e[(size_t) k]) * ek);
-          }
-          if (!(wmax * mag < 8192.0)) break;
-          ksafe = k;
-        }
-        const Table &t0 = M.tables[(size_t) order[0]];
-        const int kk = ksafe + 2 < tl ? ksafe + 2 : tl - 1;  // two knots of margin: the interpolant between knots
-        D.fixed_rsq_safe = bitmap ? 0.0 : t0.innersq + kk * t0.delta;
-      }
-      // option pair_vrow: both gather styles, tables + 512 own beads + their fixed-point accumulators in LDS
-      p->vrow = false;
-      p->vr_gen = -1;
-      if (ctx->pair_vrow && !p->once && (M.style == STYLE_UCGLD || M.style == STYLE_BETHE) && fast && D.tab_in_lds && !ctx->fma_contract) {
-        PairDev probe = D;
-        probe.fast = 1;
-        p->vrow = vrow_lds_bytes(probe) + 4608 <= 160 * 1024;
-      }
       D.hot_type = 0;
       D.hot_ent = 0;
       D.hot_k0 = -1;
@@ -689,31 +661,8 @@ static int pair_compute_impl(ucg_pair *p, int eflag, int vflag, double *eng_vdwl
       p->tab_lds_bytes = hot;
       p->dev.stage_own = (ctx->stage_own && hot + (size_t) (1024 / p->dev.gather_slots) * 36 + 6 * 1024 <= 160 * 1024) ? 1 : 0;
     }
-    const int nb = p->vrow ? vrow_blocks(ctx->nlocal) : pair_gather_blocks(ctx->nlocal, p->dev.gather_slots);
+    const int nb = pair_gather_blocks(ctx->nlocal, p->dev.gather_slots);
     if (ev) p->d_evpart.reserve((size_t) nb * 8 + 8);
-    if (p->vrow && p->vr_gen != ctx->list_gen && ctx->nlocal > 0) {
-      // the virtual rows of this list: count, size the buffers from the longest row, fill
-      const AtomsDev A = ctx->atoms_dev();
-      const ListDev L0 = ctx->list_dev();
-      p->d_vr_beadoff.reserve((size_t) ctx->nlocal + 1);
-      p->d_vr_blockinfo.reserve((size_t) nb + 1);
-      p->d_vr_maxlen.reserve(4);
-      p->vr_pitch = nb * 1024;
-      p->d_vr_lanemeta.reserve((size_t) p->vr_pitch * 2);
-      UCG_HIP(hipMemsetAsync(p->d_vr_maxlen.get(), 0, 4 * sizeof(int), ctx->stream));
-      UCG_HIP(launch_vrow_build(false, p->dev, A, L0, p->d_vr_beadoff.get(), p->d_vr_blockinfo.get(), p->d_vr_maxlen.get(),
-                                nullptr, nullptr, p->vr_pitch, p->d_vr_lanemeta.get(), ctx->stream));
-      int ml[2] = {0, 0};
-      d2h(ctx, ml, p->d_vr_maxlen.get(), 2);
-      sync(ctx);
-      p->vr_capA = ml[0] > 2 ? ml[0] : 2;
-      p->vr_capB = ml[1] > 2 ? ml[1] : 2;
-      p->d_vr_entA.reserve((size_t) p->vr_pitch * (size_t) p->vr_capA);
-      p->d_vr_entB.reserve((size_t) p->vr_pitch * (size_t) p->vr_capB);
-      UCG_HIP(launch_vrow_build(true, p->dev, A, L0, p->d_vr_beadoff.get(), p->d_vr_blockinfo.get(), p->d_vr_maxlen.get(),
-                                p->d_vr_entA.get(), p->d_vr_entB.get(), p->vr_pitch, p->d_vr_lanemeta.get(), ctx->stream));
-      p->vr_gen = ctx->list_gen;
-    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->prof_on) {
       UCG_HIP(hipEventCreate(&e0));
@@ -738,7 +687,7 @@ static int pair_compute_impl(ucg_pair *p, int eflag, int vflag, double *eng_vdwl
     } else {
       ListDev L = ctx->list_dev();
       if (part != 0) {
-        const int bslots = p->vrow ? 1024 / vrow_beads() : p->dev.gather_slots;  // beads per workgroup = 1024 / bslots
+        const int bslots = p->dev.gather_slots;  // beads per workgroup = 1024 / bslots
         if (p->blockflag_build != ctx->list_gen || p->blockflag_slots != bslots) {
           p->d_blockflag.reserve((size_t) nb + 1);
           UCG_HIP(launch_block_classify(ctx->atoms_dev(), L, bslots, p->d_blockflag.get(), ctx->stream));
@@ -749,10 +698,7 @@ static int pair_compute_impl(ucg_pair *p, int eflag, int vflag, double *eng_vdwl
         L.blockwant = part == 1 ? 0 : 1;
       }
       if (post) L.post = *post;
-      if (p->vrow)
-        UCG_HIP(launch_pair_vrow(p->dev, ctx->atoms_dev(), L, p->d_vr_entA.get(), p->d_vr_entB.get(), p->d_vr_lanemeta.get(),
-                                 p->vr_pitch, ev, p->d_evpart.get(), p->d_evout.get(), p->d_err.get(), ctx->stream));
-      else if (ctx->fma_contract)
+      if (ctx->fma_contract)
         UCG_HIP(launch_pair_gather_fused(p->dev, ctx->atoms_dev(), L, ev, p->d_evpart.get(), p->d_evout.get(),
                                          p->d_err.get(), ctx->stream));
       else
@@ -1576,10 +1522,6 @@ int ucg_ctx_set_option(ucg_ctx *ctx, const char *name, int value)
   if (std::strcmp(name, "pair_once") == 0) {
     ctx->pair_once = value != 0;
     if (!ctx->pair_once) ctx->once_beads_wanted = 0;
-    return UCG_OK;
-  }
-  if (std::strcmp(name, "pair_vrow") == 0) {
-    ctx->pair_vrow = value != 0;
     return UCG_OK;
   }
   if (std::strcmp(name, "hot_block") == 0) {

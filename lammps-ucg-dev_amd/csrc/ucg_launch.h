@@ -20,16 +20,6 @@ hipError_t launch_block_classify(const AtomsDev &A, const ListDev &L, int slots,
 
 hipError_t launch_ev_final(const double *part, int nblocks, double *out, hipStream_t st);
 
-// ---- ucg_pair_vrow.hip: own-block pairs once on balanced virtual rows
-int vrow_blocks(int nlocal);
-int vrow_beads();
-size_t vrow_lds_bytes(const PairDev &P);
-hipError_t launch_vrow_build(bool fill, const PairDev &P, const AtomsDev &A, const ListDev &L, int2 *beadoff, int4 *blockinfo,
-                             int *maxlen, int *entA, int *entB, int vpitch, int2 *lanemeta, hipStream_t st);
-hipError_t launch_pair_vrow(const PairDev &P, const AtomsDev &A, const ListDev &L, const int *entA, const int *entB,
-                            const int2 *lanemeta, int vpitch, bool ev, double *evpart, double *evout, int *errflag,
-                            hipStream_t st);
-
 hipError_t launch_selftest_div(double b, unsigned long long seed, int n, unsigned long long *d_mismatches, hipStream_t st);
 
 // ---- ucg_density.hip
