@@ -83,6 +83,10 @@ def parse_args(argv=None):
                          "cutoff' (tools/stability.py).  The hard-wall variant of the same integrator is stable.")
     ap.add_argument("--no-nve-leg", action="store_true", help="skip the short `fix nve/ucgld` leg printed beside the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dropin-steps", type=int, default=300,
+                    help="steps of the drop-in leg printed beside the headline (N = 1): the same workload hook by hook in upstream "
+                         "Verlet's order through the C ABI with the caller's (pinned) arrays bound as lazily synchronised host "
+                         "mirrors; 0 = skip")
     ap.add_argument("--cpu-ncell", type=int, default=64)
     ap.add_argument("--cpu-steps", type=int, default=10)
     ap.add_argument("--cpu-threads", type=int, default=0, help="host threads of the multi-core baseline (0 = min(cores, 16))")
@@ -292,7 +296,66 @@ def apply_env_options(ctx):
             ctx.set_option(opt, int(os.environ[env]))
 
 
-def run_single(args, pkg, capi, deck, beads, cs, local_rank, steps, warmup, integrator):
+def pinned_mirrors(n):
+    """the caller's arrays of the owned atoms (LAMMPS' atom->x ...), page-locked so that the mirror copies run at PCIe speed"""
+    import ctypes as C
+
+    M = dict(x=np.zeros((n, 3)), v=np.zeros((n, 3)), f=np.zeros((n, 3)), ucgstate=np.zeros(n, np.int32),
+             num_ucgstates=np.zeros(n, np.int32), ucgl=np.zeros(n), ucgvl=np.zeros(n), ucgp=np.zeros(n), ucgforce=np.zeros(n),
+             scores=np.zeros((n, 2)))
+    pinned = 0
+    try:
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipHostRegister.argtypes = [C.c_void_p, C.c_size_t, C.c_uint]
+        for a in M.values():
+            pinned += hip.hipHostRegister(a.ctypes.data, a.nbytes, 0) == 0
+    except OSError:
+        hip = None
+
+    def release():
+        if hip is not None:
+            for a in M.values():
+                hip.hipHostUnregister(C.c_void_p(a.ctypes.data))
+    return M, pinned == len(M), release
+
+
+def dropin_leg(ctx, pair, n, steps, integrator, use_lang, use_st, resident_ms_per_step):
+    """The SAME workload, continued on the same context, as a LAMMPS run would drive the package: one C-ABI call per hook in
+    upstream Verlet's order (ucg_verlet_hooks_run, csrc/ucg_host.hip), device arrays authoritative between the hooks, the
+    caller's arrays bound as host mirrors and synchronised before every re-neighbouring (what exchange / borders read) and
+    every 100 steps (a thermo / dump step)."""
+    M, pinned, release = pinned_mirrors(n)
+    ctx.host_bind(M)
+    kw = dict(nve="wall" if integrator == "wall" else True, langevin=use_lang, ucgstate=use_st)
+    legs = {}
+    for name, on_re in (("host_reneighbour", True), ("device_reneighbour", False)):
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        st = ctx.verlet_hooks_run(pair, steps, sync_every=100, sync_on_reneighbour=on_re, **kw)
+        ctx.synchronize()
+        el = time.perf_counter() - t0
+        legs[name] = dict(value=steps / el, ms_per_step=1e3 * el / steps, vs_resident=resident_ms_per_step / (1e3 * el / steps),
+                          rebuilds=st["rebuilds"], host_syncs=st["syncs"], downloads=st["downloads"], uploads=st["uploads"])
+    t2 = time.perf_counter()
+    ctx.host_sync(type(ctx).F_ALL)
+    t3 = time.perf_counter()
+    ctx.host_bind(None)
+    release()
+    a = legs["host_reneighbour"]
+    return {"value": a["value"], "unit": "timesteps/s", "steps": steps, "ms_per_step": a["ms_per_step"], "vs_resident": a["vs_resident"],
+            "rebuilds": a["rebuilds"], "host_syncs": a["host_syncs"], "downloads": a["downloads"], "uploads": a["uploads"],
+            "pinned_host_arrays": bool(pinned), "one_full_sync_ms": 1e3 * (t3 - t2),
+            "device_reneighbour": legs["device_reneighbour"],
+            "note": "hook by hook in upstream Verlet's order through the C ABI (initial_integrate, re-neighbour decision on the "
+                    "device, re-neighbouring or forward halo, Pair::compute, post_force hooks, final_integrate: one call and at "
+                    "least one kernel each, no epilogue fusion); the caller's pinned arrays are bound as host mirrors "
+                    "(ucg_host_bind): nothing crosses PCIe on an ordinary step.  `value`: mirrors synchronised before every "
+                    "re-neighbouring (x v ucgstate ucgl ucgvl ucgp, what LAMMPS' host-side exchange / borders read) and completely "
+                    "every 100 steps (thermo / dump); `device_reneighbour`: only the latter (the package re-neighbours on its own). "
+                    "The re-neighbouring itself runs on the device in both.  A reported leg: the headline `value` is the resident loop"}
+
+
+def run_single(args, pkg, capi, deck, beads, cs, local_rank, steps, warmup, integrator, dropin_steps=0):
     """the resident single-GPU loop (ucg_md_run); returns the measurement dict"""
     import torch
 
@@ -329,6 +392,8 @@ def run_single(args, pkg, capi, deck, beads, cs, local_rank, steps, warmup, inte
                once_beads=info.get("once_beads", 0), lanes_per_bead=pair.gather_slots)
     if cs:
         out["cluster_switch_vector"] = [float(v) for v in ctx.fix_cluster_switch_vector()]
+    if dropin_steps > 0 and not cs:
+        out["dropin"] = dropin_leg(ctx, pair, beads.n, dropin_steps, integrator, use_lang, use_st, 1e3 * elapsed / steps)
     pair.close()
     ctx.close()
     return out
@@ -400,7 +465,8 @@ def main():
                                  attach_fixes=lambda ctx: attach_fixes(ctx, args, rank),
                                  apply_options=apply_env_options)
     else:
-        result = run_single(args, pkg, capi, deck, beads, cs, device_index, args.steps, args.warmup, args.integrator)
+        result = run_single(args, pkg, capi, deck, beads, cs, device_index, args.steps, args.warmup, args.integrator,
+                            dropin_steps=args.dropin_steps)
         if args.integrator == "wall" and not args.no_nve_leg and args.style == "table_ucgld" and not cs:
             # the integrator north_star names, on the same beads: a SHORT leg (it is not stationary, see --integrator)
             k = max(50, min(args.steps, 300))
@@ -521,6 +587,8 @@ def main():
                         f"kernel the chip holds {MEASURED_CLOCK_GHZ} GHz (GRBM_GUI_ACTIVE, tools/profile_clock.sh), hence the second figure"}
     if nve_leg:
         out["integrator_nve"] = nve_leg
+    if "dropin" in result:
+        out["dropin"] = result["dropin"]
     if not args.no_cpu_baseline and args.style == "table_ucgld" and world == 1 and not cs:  # rank 0 at N = 1 only
         sdeck = deck
         cb = cpu_baseline(pkg, sdeck, args.cpu_ncell, args.cpu_steps, dt, args.integrator)

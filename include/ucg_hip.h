@@ -196,6 +196,10 @@ int ucg_atoms_counts(const ucg_ctx *ctx, int *nlocal, int *nghost);
  * prior and CV force -- the forward_comm the reference declares but never performs
  * (UCG/pair_table_ucg_bethe_density.cpp:280 vs ...density.h:107-110). */
 int ucg_ghosts_upload(ucg_ctx *ctx, const int *src, int nghost);
+/* ... and, for a single rank, by which box shifts (-1, 0, 1 per dimension: CommBrick's pbc flags).  With ucg_domain_set
+ * this lets the device refresh the host-built ghosts itself (ucg_halo_forward) and take the re-neighbour decision against
+ * the positions held at this call (ucg_decide_local), so a drop-in run moves nothing per step (ucg_host_bind below). */
+int ucg_ghosts_upload_images(ucg_ctx *ctx, const int *src, const int *shift3, int nghost);
 /* AtomVecUCG::force_clear (UCG/atom_vec_ucg.cpp:131-135) + Verlet::force_clear */
 int ucg_force_clear(ucg_ctx *ctx);
 
@@ -280,6 +284,39 @@ int ucg_comm_attach_rccl(ucg_ctx *ctx, const ucg_rccl_id *id, int rank, int worl
 int ucg_comm_detach(ucg_ctx *ctx);
 int ucg_comm_info(const ucg_ctx *ctx, int *rank, int *world, int *is_rccl, long long *nrebuild);
 int ucg_comm_allreduce_f64(ucg_ctx *ctx, double *buf, int n, int op);
+
+/* ------------------------------------------------ host mirrors of a drop-in caller
+ * The reference's styles work on LAMMPS' host arrays, hook by hook (Pair::compute UCG/pair_table_ucgld.h:22-48, the
+ * integrator UCG/fix_nve_ucgld.h:27-36, the thermostat UCG/fix_ucgld_langevin.h:29-47, fix ucgstate
+ * UCG/fix_ucgstate.h:15-23).  Instead of copying every array a hook touches in and out (ucg_atoms_upload_owned /
+ * ucg_atoms_download), a caller can BIND its arrays of the owned atoms once (again after AtomVec::grow_pointers) and
+ * let the library keep the device arrays authoritative between hooks -- upstream's KOKKOS sync / modified protocol:
+ *   ucg_host_modified(mask)  the caller has written these fields: the next device hook that reads them uploads them first
+ *   ucg_host_sync(mask)      the caller is about to read these fields: those a device hook has written since the last
+ *                            synchronisation are downloaded (re-neighbouring, thermo and dump steps; nothing moves on an
+ *                            ordinary step)
+ * Every hook below marks what it reads and writes.  ucg_atoms_upload leaves both sides equal; a device re-neighbouring
+ * (ucg_neigh_rebuild) re-orders the beads, so afterwards every field counts as written by the device.
+ * ucg_host_status reports the two masks and {uploads, downloads} that moved data.  Pinned arrays (hipHostRegister)
+ * make the copies run at PCIe speed; the AoS <-> device-record repacking is done on the device. */
+enum {
+  UCG_F_X = 1, UCG_F_V = 2, UCG_F_F = 4, UCG_F_STATE = 8, UCG_F_NSTATES = 16, UCG_F_UCGL = 32, UCG_F_UCGVL = 64,
+  UCG_F_UCGP = 128, UCG_F_UCGFORCE = 256, UCG_F_SCORES = 512, UCG_F_ALL = 1023
+};
+int ucg_host_bind(ucg_ctx *ctx, double *x, double *v, double *f, int *ucgstate, int *num_ucgstates, double *ucgl,
+                  double *ucgvl, double *ucgp, double *ucgforce, double *ucgsoftmaxscores);
+int ucg_host_modified(ucg_ctx *ctx, int mask);
+int ucg_host_sync(ucg_ctx *ctx, int mask);
+int ucg_host_status(const ucg_ctx *ctx, int *device_newer, int *host_newer, long long *transfers2);
+/* the package's hooks in the order upstream Verlet::run calls them, one C-ABI call per hook (csrc/ucg_host.hip): what a
+ * LAMMPS run makes of these styles, without LAMMPS -- the drop-in leg of bench.py and the C caller of the tests.  The
+ * re-neighbour decision is taken on the device (the glue's integrator forces LAMMPS' re-neighbouring through
+ * Fix::force_reneighbor); bound host mirrors are synchronised before every re-neighbouring when sync_on_reneighbour is set
+ * (x v ucgstate ucgl ucgvl ucgp: what LAMMPS' exchange / borders move; 0 = the package re-neighbours on its own, on the
+ * device) and completely every `sync_every` steps (0 = never).  use_nve as in ucg_md_attach.
+ * stats4: re-neighbourings, host synchronisations, uploads, downloads that moved data. */
+int ucg_verlet_hooks_run(ucg_ctx *ctx, ucg_pair *pair, long long nsteps, int use_nve, int use_langevin, int use_ucgstate,
+                         int groupbit, int sync_on_reneighbour, int sync_every, long long *stats4);
 
 /* ---------------------------------------------------------------- fix nve/ucgld
  * replaces FixNVE_UCGLD::initial_integrate / final_integrate

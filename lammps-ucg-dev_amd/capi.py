@@ -60,6 +60,7 @@ SYMBOLS = [
     "ucg_profile_enable", "ucg_profile_read",
     "ucg_comm_attach", "ucg_comm_rccl_unique_id", "ucg_comm_attach_rccl", "ucg_comm_detach", "ucg_comm_info",
     "ucg_comm_allreduce_f64", "ucg_pair_density_aux_download", "ucg_pair_density_aux_upload",
+    "ucg_ghosts_upload_images", "ucg_host_bind", "ucg_host_modified", "ucg_host_sync", "ucg_host_status", "ucg_verlet_hooks_run",
 ]
 
 # communicator callbacks of a decomposed run (include/ucg_hip.h: ucg_comm_ops)
@@ -217,6 +218,13 @@ def lib():
     L.ucg_comm_allreduce_f64.argtypes = [vp, c_double_p, C.c_int, C.c_int]
     L.ucg_pair_density_aux_download.argtypes = [vp, C.c_int, c_double_p, C.c_int, C.c_int]
     L.ucg_pair_density_aux_upload.argtypes = [vp, C.c_int, c_double_p, C.c_int, C.c_int]
+    L.ucg_ghosts_upload_images.argtypes = [vp, c_int_p, c_int_p, C.c_int]
+    L.ucg_host_bind.argtypes = [vp, c_double_p, c_double_p, c_double_p, c_int_p, c_int_p, c_double_p, c_double_p, c_double_p,
+                                c_double_p, c_double_p]
+    L.ucg_host_modified.argtypes = [vp, C.c_int]
+    L.ucg_host_sync.argtypes = [vp, C.c_int]
+    L.ucg_host_status.argtypes = [vp, c_int_p, c_int_p, c_ll_p]
+    L.ucg_verlet_hooks_run.argtypes = [vp, vp, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_ll_p]
     _LIB = L
     return L
 
@@ -331,6 +339,10 @@ class Context:
     def ghosts_upload(self, src):
         s = _i32(src)
         self.chk(self.L.ucg_ghosts_upload(self.h, _ip(s), len(s)))
+
+    def ghosts_upload_images(self, src, shift3):
+        a, b = _i32(src), _i32(np.ascontiguousarray(shift3).reshape(-1))
+        self.chk(self.L.ucg_ghosts_upload_images(self.h, _ip(a), _ip(b), len(a)))
 
     def force_clear(self):
         self.chk(self.L.ucg_force_clear(self.h))
@@ -646,6 +658,47 @@ class Context:
         a = _f64(values).copy()
         self.chk(self.L.ucg_comm_allreduce_f64(self.h, _dp(a), len(a), 0))
         return a
+
+    # ---- host mirrors of a drop-in caller (lazy synchronisation: ucg_host_bind / _modified / _sync)
+    F_X, F_V, F_F, F_STATE, F_NSTATES, F_UCGL, F_UCGVL, F_UCGP, F_UCGFORCE, F_SCORES, F_ALL = 1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1023
+
+    def host_bind(self, arrays):
+        """arrays: dict with x v f (n,3), ucgstate num_ucgstates (int32), ucgl ucgvl ucgp ucgforce, scores (n,2) of the owned
+        atoms -- C-contiguous numpy arrays the caller keeps alive (LAMMPS' atom arrays); None unbinds"""
+        if arrays is None:
+            self._mirror = None
+            z = None
+            self.chk(self.L.ucg_host_bind(self.h, z, z, z, z, z, z, z, z, z, z))
+            return
+        for k in ("x", "v", "f", "ucgl", "ucgvl", "ucgp", "ucgforce", "scores"):
+            a = arrays[k]
+            assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"], k
+        for k in ("ucgstate", "num_ucgstates"):
+            assert arrays[k].dtype == np.int32 and arrays[k].flags["C_CONTIGUOUS"], k
+        self._mirror = arrays
+        a = arrays
+        self.chk(self.L.ucg_host_bind(self.h, _dp(a["x"]), _dp(a["v"]), _dp(a["f"]), _ip(a["ucgstate"]), _ip(a["num_ucgstates"]),
+                                      _dp(a["ucgl"]), _dp(a["ucgvl"]), _dp(a["ucgp"]), _dp(a["ucgforce"]), _dp(a["scores"])))
+
+    def host_modified(self, mask):
+        self.chk(self.L.ucg_host_modified(self.h, int(mask)))
+
+    def host_sync(self, mask=1023):
+        self.chk(self.L.ucg_host_sync(self.h, int(mask)))
+
+    def host_status(self):
+        d, h = C.c_int(0), C.c_int(0)
+        t = np.zeros(2, np.int64)
+        self.chk(self.L.ucg_host_status(self.h, C.byref(d), C.byref(h), t.ctypes.data_as(c_ll_p)))
+        return dict(device_newer=d.value, host_newer=h.value, uploads=int(t[0]), downloads=int(t[1]))
+
+    def verlet_hooks_run(self, pair, nsteps, nve=True, langevin=False, ucgstate=False, sync_every=0, groupbit=1, sync_on_reneighbour=True):
+        """the hooks in upstream Verlet's order, one C-ABI call each (drop-in emulation); returns the statistics"""
+        kind = 2 if nve == "wall" else (1 if nve else 0)
+        st = np.zeros(4, np.int64)
+        self.chk(self.L.ucg_verlet_hooks_run(self.h, pair.h, int(nsteps), kind, int(bool(langevin)), int(bool(ucgstate)),
+                                             int(groupbit), int(bool(sync_on_reneighbour)), int(sync_every), st.ctypes.data_as(c_ll_p)))
+        return dict(rebuilds=int(st[0]), syncs=int(st[1]), uploads=int(st[2]), downloads=int(st[3]))
 
     # ---- measurement
     def profile_enable(self, on=True):

@@ -625,6 +625,7 @@ static int pair_compute_impl(ucg_pair *p, int eflag, int vflag, double *eng_vdwl
     if (!p->uploaded) return fail(ctx, UCG_ERR_INVALID, "ucg_pair_compute before ucg_pair_init");
     if (ctx->list_inum != ctx->nlocal) return fail(ctx, UCG_ERR_INVALID, "neighbour list does not match the resident atoms");
     const bool ev = (eflag || vflag);
+    mirror_need(ctx, UCG_F_X | UCG_F_STATE | UCG_F_UCGL | UCG_F_UCGP);
     if (ctx->list_from_builder)
       for (int i = 1; i < 4; i++)
         if (ctx->special_lj[i] != 1.0)
@@ -705,6 +706,7 @@ static int pair_compute_impl(ucg_pair *p, int eflag, int vflag, double *eng_vdwl
         UCG_HIP(launch_pair_gather(p->dev, ctx->atoms_dev(), L, ev, p->d_evpart.get(), p->d_evout.get(), p->d_err.get(),
                                    ctx->stream));
     }
+    mirror_wrote(ctx, UCG_F_F | UCG_F_UCGFORCE | UCG_F_SCORES | UCG_F_NSTATES | (p->model.style == STYLE_BETHE_DENSITY ? UCG_F_UCGP : 0));
     if (ctx->prof_on) {
       UCG_HIP(hipEventRecord(e1, ctx->stream));
       ctx->prof_ev.push_back(e0);
@@ -740,6 +742,8 @@ int ucg_pair_density_phase(ucg_pair *p, int phase, int eflag, int vflag, double 
       p->d_evpart.reserve((size_t) density_evpart_doubles(ctx->nlocal));
     }
     if (!p->host_tab.empty()) choose_hot_block(ctx, p, ctx->stage_own ? (size_t) 1024 * 36 : 0);
+    mirror_need(ctx, UCG_F_X | UCG_F_STATE | UCG_F_UCGL | UCG_F_UCGP);
+    mirror_wrote(ctx, UCG_F_F | UCG_F_UCGFORCE | UCG_F_SCORES | UCG_F_NSTATES | UCG_F_UCGP);
     UCG_HIP(launch_density_phase(p->dev, ctx->atoms_dev(), ctx->list_dev(), phase, ev, p->d_prior.get(), p->d_partial.get(),
                                  p->d_cv.get(), p->d_evpart.get(), p->d_evout.get(), p->d_err.get(), ctx->stream));
     if (phase == 3 && ev) {
@@ -864,6 +868,7 @@ int ucg_atoms_upload(ucg_ctx *ctx, int nlocal, int nghost, int ntypes, const dou
     ctx->ntypes = ntypes;
     ctx->list_inum = 0;
     ctx->ghost_src_valid = (nghost == 0);
+    ctx->mirror.dev_newer = ctx->mirror.host_newer = 0;  // the caller's arrays and the device hold the same values
     return UCG_OK;
   });
 }
@@ -1093,7 +1098,9 @@ int ucg_fix_nve_initial(ucg_ctx *ctx, int groupbit)
   if (!ctx) return UCG_ERR_INVALID;
   return guarded(ctx, [&]() -> int {
     // dtv = dt, dtf = 0.5*dt*ftm2v  (UCG/fix_nve_ucgld.cpp:36-38)
+    mirror_need(ctx, UCG_F_X | UCG_F_V | UCG_F_F | UCG_F_UCGL | UCG_F_UCGVL | UCG_F_UCGFORCE);
     UCG_HIP(launch_nve_initial(ctx->atoms_dev(), ctx->dt, 0.5 * ctx->dt * ctx->ftm2v, groupbit, 0, ctx->stream));
+    mirror_wrote(ctx, UCG_F_X | UCG_F_V | UCG_F_UCGL | UCG_F_UCGVL);
     return UCG_OK;
   });
 }
@@ -1102,7 +1109,9 @@ int ucg_fix_nve_final(ucg_ctx *ctx, int groupbit)
 {
   if (!ctx) return UCG_ERR_INVALID;
   return guarded(ctx, [&]() -> int {
+    mirror_need(ctx, UCG_F_V | UCG_F_F | UCG_F_UCGL | UCG_F_UCGVL | UCG_F_UCGFORCE);
     UCG_HIP(launch_nve_final(ctx->atoms_dev(), 0.5 * ctx->dt * ctx->ftm2v, groupbit, 0, ctx->stream));
+    mirror_wrote(ctx, UCG_F_V | UCG_F_UCGVL);
     return UCG_OK;
   });
 }
@@ -1121,7 +1130,9 @@ int ucg_fix_nve_wall_hard_initial(ucg_ctx *ctx, int groupbit)
 {
   if (!ctx) return UCG_ERR_INVALID;
   return guarded(ctx, [&]() -> int {
+    mirror_need(ctx, UCG_F_X | UCG_F_V | UCG_F_F | UCG_F_UCGL | UCG_F_UCGVL | UCG_F_UCGFORCE | UCG_F_STATE);
     UCG_HIP(launch_nve_initial(ctx->atoms_dev(), ctx->dt, 0.5 * ctx->dt * ctx->ftm2v, groupbit, 2, ctx->stream));
+    mirror_wrote(ctx, UCG_F_X | UCG_F_V | UCG_F_UCGL | UCG_F_UCGVL | UCG_F_STATE);
     return UCG_OK;
   });
 }
@@ -1130,7 +1141,9 @@ int ucg_fix_nve_wall_hard_final(ucg_ctx *ctx, int groupbit)
 {
   if (!ctx) return UCG_ERR_INVALID;
   return guarded(ctx, [&]() -> int {
+    mirror_need(ctx, UCG_F_V | UCG_F_F | UCG_F_UCGL | UCG_F_UCGVL | UCG_F_UCGFORCE);
     UCG_HIP(launch_nve_final(ctx->atoms_dev(), 0.5 * ctx->dt * ctx->ftm2v, groupbit, 2, ctx->stream));
+    mirror_wrote(ctx, UCG_F_V | UCG_F_UCGVL | UCG_F_UCGL);
     return UCG_OK;
   });
 }
@@ -1140,7 +1153,11 @@ int ucg_fix_nve_wall_hard_post_force(ucg_ctx *ctx, int groupbit)
   if (!ctx) return UCG_ERR_INVALID;
   return guarded(ctx, [&]() -> int {
     // setmask() adds POST_FORCE only with bias_potential (:41-52)
-    if (ctx->wall_bias) UCG_HIP(launch_wall_bias(ctx->atoms_dev(), ctx->wall_barrier, groupbit, ctx->stream));
+    if (ctx->wall_bias) {
+      mirror_need(ctx, UCG_F_UCGL | UCG_F_UCGFORCE | UCG_F_F);
+      UCG_HIP(launch_wall_bias(ctx->atoms_dev(), ctx->wall_barrier, groupbit, ctx->stream));
+      mirror_wrote(ctx, UCG_F_UCGFORCE);
+    }
     return UCG_OK;
   });
 }
@@ -1275,7 +1292,9 @@ int ucg_fix_langevin_post_force(ucg_ctx *ctx, int groupbit, long long ntimestep,
     Lg.gfactor2 = L.gf2.get();
     Lg.tsqrt = L.tsqrt;
     Lg.draws = rng_next(ctx, L.rng, L.draws, L.batch, ctx->nlocal);
+    mirror_need(ctx, UCG_F_UCGVL | UCG_F_UCGFORCE | UCG_F_F);
     UCG_HIP(launch_langevin(ctx->atoms_dev(), Lg, groupbit, ctx->stream));
+    mirror_wrote(ctx, UCG_F_UCGFORCE);
     return UCG_OK;
   });
 }
@@ -1332,7 +1351,9 @@ int ucg_fix_ucgstate_post_force(ucg_ctx *ctx)
       // one uniform() per 2-state owned bead in index order (:117); every bead is 2-state here
       draws = rng_next(ctx, S.rng, S.draws, S.batch, ctx->nlocal);
     }
+    mirror_need(ctx, UCG_F_SCORES | UCG_F_NSTATES | UCG_F_STATE | UCG_F_X | UCG_F_UCGL);
     UCG_HIP(launch_ucgstate(ctx->atoms_dev(), S.ld_flag, S.mc_flag, S.mc_rate, draws, ctx->stream));
+    mirror_wrote(ctx, UCG_F_UCGP | UCG_F_STATE | UCG_F_UCGL);
     return UCG_OK;
   });
 }
@@ -1366,6 +1387,7 @@ int ucg_md_post_fused(ucg_ctx *ctx, int use_langevin, int use_ucgstate, int use_
     UCG_HIP(launch_post_fused(ctx->atoms_dev(), use_langevin != 0, Lg, use_ucgstate != 0, S.ld_flag, S.mc_flag, S.mc_rate,
                               mc_draws, use_nve != 0, fuse_next_initial != 0, ctx->dt, 0.5 * ctx->dt * ctx->ftm2v,
                               groupbit, use_nve >= 2 ? (ctx->wall_bias ? 3 : 2) : 0, ctx->wall_barrier, ctx->stream));
+    mirror_wrote(ctx, UCG_F_ALL);
     return UCG_OK;
   });
 }
@@ -1428,6 +1450,7 @@ int ucg_md_pair_post(ucg_ctx *ctx, ucg_pair *p, int use_langevin, int use_ucgsta
   ctx->pos4.swap(ctx->pos4_alt);
   ctx->meta.swap(ctx->meta_alt);
   if (Q.ucgst) ctx->ucgp.swap(ctx->ucgp_alt);
+  mirror_wrote(ctx, UCG_F_ALL);
   return UCG_OK;
 }
 

@@ -107,6 +107,20 @@ struct FixUcgState {
   RngBatch batch;
 };
 
+// host mirrors of a drop-in caller (ucg_host.hip): LAMMPS' arrays of the OWNED atoms and which side is ahead, per field
+struct HostMirror {
+  bool bound = false;
+  double *x = nullptr, *v = nullptr, *f = nullptr, *ucgl = nullptr, *ucgvl = nullptr, *ucgp = nullptr, *ucgforce = nullptr,
+         *scores = nullptr;
+  int *state = nullptr, *nstates = nullptr;
+  unsigned dev_newer = 0, host_newer = 0;  // UCG_F_* masks
+  long long uploads = 0, downloads = 0;    // synchronisations that moved data
+  DevBuf<double> stage;
+  DevBuf<int> istage;
+};
+void mirror_need(ucg_ctx *ctx, unsigned reads);
+void mirror_wrote(ucg_ctx *ctx, unsigned writes);
+
 }  // namespace ucg
 
 struct ucg_pair;
@@ -183,6 +197,7 @@ struct ucg_ctx {
   int groupbit = 1;
   long long nrebuild = 0, pair_error_steps = 0;
   double thermo[9] = {0};
+  ucg::HostMirror mirror;
   // profiling
   bool prof_on = false;
   std::vector<hipEvent_t> prof_ev;  // pairs (start, stop) not yet read

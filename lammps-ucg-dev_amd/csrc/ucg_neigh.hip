@@ -1420,7 +1420,9 @@ int ucg_neigh_rebuild(ucg_ctx *ctx)
   if (!ctx) return UCG_ERR_INVALID;
   if (int rc = need_domain(ctx)) return rc;
   return guarded(ctx, [&]() -> int {
+    mirror_need(ctx, UCG_F_ALL);  // whatever the caller changed takes part in the re-ordering
     rebuild(ctx);
+    mirror_wrote(ctx, UCG_F_ALL);  // the beads have a new order: every host mirror is behind
     return UCG_OK;
   });
 }
@@ -1464,6 +1466,46 @@ int ucg_ghosts_download(ucg_ctx *ctx, int *src, int *shift3, int cap)
   });
 }
 
+/* host-built ghosts of a single rank as periodic images (the drop-in path): source owned atom + box shifts per ghost.
+ * From here on the device can refresh the ghosts (ucg_halo_forward: x + shift * prd like CommBrick's pbc flags) and take
+ * the re-neighbour decision (ucg_decide_local) against the positions held now, as after a device build. */
+int ucg_ghosts_upload_images(ucg_ctx *ctx, const int *src, const int *shift3, int nghost)
+{
+  if (!ctx || nghost < 0 || (nghost > 0 && (!src || !shift3))) return UCG_ERR_INVALID;
+  if (int rc = need_domain(ctx)) return rc;
+  return guarded(ctx, [&]() -> int {
+    Domain &D = *ctx->dom;
+    if (D.world != 1) throw InputError{"ucg_ghosts_upload_images: single-rank runs (ghosts of a decomposed run belong to other ranks)"};
+    if (nghost != ctx->nghost) throw InputError{"ghost map length differs from the resident ghost count"};
+    std::vector<int> code((size_t) nghost + 1, 13);
+    for (int g = 0; g < nghost; g++) {
+      if (src[g] < 0 || src[g] >= ctx->nlocal) throw InputError{"ghost source index out of range"};
+      int c = 0, mul = 1;
+      for (int d = 0; d < 3; d++) {
+        const int sh = shift3[3 * g + d];
+        if (sh < -1 || sh > 1) throw InputError{"ghost image shift outside -1 .. 1"};
+        c += (sh + 1) * mul;
+        mul *= 3;
+      }
+      code[(size_t) g] = c;
+    }
+    ctx->ghost_src.reserve((size_t) nghost + 1);
+    D.ghost_code.reserve((size_t) nghost + 1);
+    if (nghost) {
+      UCG_HIP(hipMemcpyAsync(ctx->ghost_src.get(), src, (size_t) nghost * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+      UCG_HIP(hipMemcpyAsync(D.ghost_code.get(), code.data(), (size_t) nghost * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    }
+    D.xhold.reserve((size_t) ctx->nlocal + 1);
+    if (ctx->nlocal)
+      hipLaunchKernelGGL(k_store_xhold, dim3(nblk(ctx->nlocal)), dim3(NB), 0, ctx->stream, ctx->nlocal, ctx->pos4.get(), D.xhold.get());
+    UCG_HIP(hipGetLastError());
+    UCG_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->ghost_src_valid = true;
+    D.ago = 0;
+    return UCG_OK;
+  });
+}
+
 int ucg_md_attach(ucg_ctx *ctx, ucg_pair *pair, int use_nve, int use_langevin, int use_ucgstate)
 {
   if (!ctx || !pair || pair->ctx != ctx) return UCG_ERR_INVALID;
@@ -1491,6 +1533,8 @@ int ucg_md_setup(ucg_ctx *ctx, long long nsteps_planned)
   // FixUCGState::setup both call post_force (UCG/fix_ucgld_langevin.cpp:187-197, UCG/fix_ucgstate.cpp:142-171)
   ctx->beginstep = ctx->ntimestep;
   ctx->endstep = ctx->ntimestep + nsteps_planned;
+  // resident driver: bound host mirrors are read once and fall behind as a whole
+  if (int rc = guarded(ctx, [&]() -> int { mirror_need(ctx, UCG_F_ALL); mirror_wrote(ctx, UCG_F_ALL); return UCG_OK; })) return rc;
   if (ctx->comm) return md_setup_multi(ctx);  // decomposed run: csrc/ucg_comm.hip
   int rc = guarded(ctx, [&]() -> int {
     if (ctx->md_lang && !ctx->lang.inited) {
@@ -1513,6 +1557,7 @@ int ucg_md_run(ucg_ctx *ctx, long long nsteps, int thermo_every)
 {
   if (!ctx || !ctx->md_pair) return UCG_ERR_INVALID;
   if (int rc = need_domain(ctx)) return rc;
+  if (int rc = guarded(ctx, [&]() -> int { mirror_need(ctx, UCG_F_ALL); mirror_wrote(ctx, UCG_F_ALL); return UCG_OK; })) return rc;
   if (ctx->comm) return md_run_multi(ctx, nsteps, thermo_every);  // decomposed run: csrc/ucg_comm.hip
   // Per step (upstream Verlet::run):
   //   initial_integrate | decide -> rebuild or halo refresh | pair | post_force fixes | final_integrate | end_of_step

@@ -10,6 +10,8 @@
 #include "error.h"
 #include "force.h"
 #include "modify.h"
+#include "neighbor.h"
+#include "output.h"
 #include "pair.h"
 #include "respa.h"
 #include "update.h"
@@ -39,6 +41,8 @@ void FixUCGGPUBase::init()
   ctx = force->pair ? (ucg_ctx *) force->pair->extract("ucg_ctx", dim) : nullptr;
   if (!ctx) error->all(FLERR, "USER-UCG/GPU fixes need one of the pair styles table_ucgld / table_ucg_bethe / table_ucg_bethe_density");
   check(ucg_ctx_set_units(ctx, force->boltz, force->ftm2v, force->mvv2e, update->dt, force->special_lj));
+  const int *r = (const int *) force->pair->extract("ucg_resident", dim);
+  resident = r ? *r : 0;
 }
 
 void FixUCGGPUBase::check(int rc)
@@ -48,6 +52,7 @@ void FixUCGGPUBase::check(int rc)
 
 void FixUCGGPUBase::to_device(int fields)
 {
+  if (resident) return;    // the device copy is the authoritative one (host edits are announced with ucg_host_modified)
   auto avec = AtomVecUCG::get(lmp);
   check(ucg_atoms_upload_owned(ctx, (fields & X) ? &atom->x[0][0] : nullptr, (fields & V) ? &atom->v[0][0] : nullptr,
                                (fields & F) ? &atom->f[0][0] : nullptr, (fields & STATE) ? avec->ucgstate : nullptr,
@@ -59,6 +64,7 @@ void FixUCGGPUBase::to_device(int fields)
 
 void FixUCGGPUBase::from_device(int fields)
 {
+  if (resident) return;    // LAMMPS' arrays catch up in pre_exchange() / on output steps
   auto avec = AtomVecUCG::get(lmp);
   check(ucg_atoms_download(ctx, 0, (fields & X) ? &atom->x[0][0] : nullptr, (fields & V) ? &atom->v[0][0] : nullptr,
                            nullptr, nullptr, nullptr, (fields & STATE) ? avec->ucgstate : nullptr, nullptr,
@@ -78,7 +84,8 @@ FixNVEUCGLDGPU::FixNVEUCGLDGPU(LAMMPS *lmp, int narg, char **arg) : FixUCGGPUBas
 
 int FixNVEUCGLDGPU::setmask()
 {
-  return INITIAL_INTEGRATE | FINAL_INTEGRATE | INITIAL_INTEGRATE_RESPA | FINAL_INTEGRATE_RESPA;    // UCG/fix_nve_ucgld.cpp:27-34
+  // UCG/fix_nve_ucgld.cpp:27-34, plus the two hooks of the resident mode (no-ops otherwise)
+  return INITIAL_INTEGRATE | FINAL_INTEGRATE | INITIAL_INTEGRATE_RESPA | FINAL_INTEGRATE_RESPA | PRE_EXCHANGE | END_OF_STEP;
 }
 
 void FixNVEUCGLDGPU::init()
@@ -88,6 +95,27 @@ void FixNVEUCGLDGPU::init()
   // atom style ucg has per-type masses (mass_type = PER_TYPE, UCG/atom_vec_ucg.cpp:36), so the reference's rmass branch
   // (UCG/fix_nve_ucgld.cpp:64-78, 124-138) is reachable only through atom_style hybrid with a per-atom-mass style
   if (atom->rmass) error->all(FLERR, "USER-UCG/GPU integrators use the per-type masses of atom style ucg");
+  if (resident) {
+    // Neighbor::decide() would read x on the host every `every` steps: the distance check runs on the device instead
+    // (ucg_decide_local, with the neigh_modify settings the pair style saved) and a positive outcome is handed to LAMMPS
+    // through force_reneighbor / next_reneighbor; LAMMPS' own criterion is switched off by an unreachable delay
+    force_reneighbor = 1;
+    next_reneighbor = -1;
+    neighbor->delay = 2000000000;
+    neighbor->every = 1;
+  }
+}
+
+void FixNVEUCGLDGPU::pre_exchange()
+{
+  // a re-neighbouring step: pbc / exchange / borders work on LAMMPS' arrays
+  if (resident) check(ucg_host_sync(ctx, UCG_F_X | UCG_F_V | UCG_F_STATE | UCG_F_UCGL | UCG_F_UCGVL | UCG_F_UCGP));
+}
+
+void FixNVEUCGLDGPU::end_of_step()
+{
+  // thermo / dump / restart output of this step reads LAMMPS' arrays
+  if (resident && update->ntimestep == output->next) check(ucg_host_sync(ctx, UCG_F_ALL));
 }
 
 void FixNVEUCGLDGPU::set_step(double dt)
@@ -121,6 +149,12 @@ void FixNVEUCGLDGPU::initial_integrate(int)
   to_device(X | V | F | L | VL | LF | (wall ? STATE : 0));
   check(wall ? ucg_fix_nve_wall_hard_initial(ctx, groupbit) : ucg_fix_nve_initial(ctx, groupbit));
   from_device(X | V | L | VL | (wall ? STATE : 0));
+  if (resident) {
+    int due = 0, flag = 0;
+    check(ucg_md_set_timestep(ctx, update->ntimestep));
+    check(ucg_decide_local(ctx, &due, &flag));
+    if (due && flag) next_reneighbor = update->ntimestep;    // Neighbor::decide() returns 1 for this step
+  }
 }
 
 void FixNVEUCGLDGPU::final_integrate()

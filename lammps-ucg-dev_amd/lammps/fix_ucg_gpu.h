@@ -9,11 +9,13 @@
      fix ID group cluster_switch molSeed molOffset cutoff seed rateFreq N rateFile F contactFile F
                                                              (UCG/fix_cluster_switch.cpp:37-60)
 
-   Drop-in mode: LAMMPS owns the host arrays, so every hook refreshes what it reads
-   (ucg_atoms_upload_owned), launches the kernel and copies back what it wrote
-   (ucg_atoms_download).  The device context is the pair style's (Pair::extract("ucg_ctx")).
-   For production runs the whole loop stays resident instead: see `run_style`-level entry
-   ucg_md_run in INTEGRATION.md.
+   The device context is the pair style's (Pair::extract("ucg_ctx")).  Two modes, chosen by the pair style in init_style():
+   * resident (one rank, every fix of the deck is one of these): the device arrays are authoritative between the hooks and
+     LAMMPS' arrays are mirrors bound with ucg_host_bind; a hook launches its kernel and moves nothing.  The integrator
+     takes Neighbor::decide() over (distance check on the device, re-neighbouring forced through force_reneighbor /
+     next_reneighbor), synchronises what exchange / borders read in pre_exchange() and everything on output steps;
+   * copy mode (anything else): every hook refreshes what it reads (ucg_atoms_upload_owned), launches the kernel and
+     copies back what it wrote (ucg_atoms_download).
 
    Compiles only inside a LAMMPS source tree (needs fix.h); see INTEGRATION.md.
 ------------------------------------------------------------------------- */
@@ -45,6 +47,7 @@ class FixUCGGPUBase : public Fix {
 
  protected:
   ucg_ctx *ctx = nullptr;
+  int resident = 0;    // the pair style's extract("ucg_resident")
   void check(int rc);
   enum { X = 1, V = 2, F = 4, STATE = 8, NSTATES = 16, L = 32, VL = 64, P = 128, LF = 256, SCORES = 512 };
   void to_device(int fields);
@@ -58,6 +61,8 @@ class FixNVEUCGLDGPU : public FixUCGGPUBase {
   void init() override;
   void initial_integrate(int) override;
   void final_integrate() override;
+  void pre_exchange() override;
+  void end_of_step() override;
   void initial_integrate_respa(int, int, int) override;
   void final_integrate_respa(int, int) override;
   void reset_dt() override;

@@ -6,6 +6,10 @@
 //   every step        : ucg_atoms_upload_comm(x, ucgstate, ucgl, ucgp of owned + ghost atoms)
 //                       ucg_pair_compute  ->  ucg_atoms_download(f, ucgforce, scores [, ucgp])
 //                       results are ADDED to LAMMPS' arrays (force_clear has zeroed them)
+// Resident mode (one rank, every per-step fix of the deck is a USER-UCG/GPU fix): nothing of this moves on an ordinary
+// step -- LAMMPS' arrays are bound as host mirrors (ucg_host_bind), the ghosts are refreshed on the device
+// (ucg_halo_forward with the image shifts given at the re-neighbour step) and results stay on the device until a fix
+// of this package synchronises them (re-neighbour, thermo and dump steps: fix_ucg_gpu.cpp).
 // The device kernels gather over a FULL list and leave nothing on ghosts, so newton_pair may
 // stay on (the reverse communication then adds zeros) and no fdotr virial is computed.
 #include "pair_table_ucg_gpu.h"
@@ -13,6 +17,7 @@
 #include "atom.h"
 #include "atom_vec_ucg_gpu.h"
 #include "comm.h"
+#include "domain.h"
 #include "error.h"
 #include "fix.h"
 #include "force.h"
@@ -102,6 +107,24 @@ void PairTableUCGGPU::init_style()
   if (!pT) error->all(FLERR, "USER-UCG/GPU pair styles need a fix that exports t_target (e.g. fix ucgld/langevin)");
   check(ucg_ctx_set_units(ctx, force->boltz, force->ftm2v, force->mvv2e, update->dt, force->special_lj), true);
   check(ucg_pair_init(gpair, atom->ntypes, T), true);
+  // resident mode: one rank, orthogonal box, and no fix that is not of this package (any other fix may read or write
+  // LAMMPS' arrays at a hook this package does not see)
+  user_every = neighbor->every;
+  user_delay = neighbor->delay;
+  user_check = neighbor->dist_check;
+  resident = (comm->nprocs == 1 && !domain->triclinic) ? 1 : 0;
+  for (int ifix = 0; ifix < modify->nfix && resident; ifix++) {
+    const char *st = modify->fix[ifix]->style;
+    if (strcmp(st, "nve/ucgld") && strcmp(st, "nve/ucgld/wall/hard") && strcmp(st, "ucgld/langevin") && strcmp(st, "ucgstate")) resident = 0;
+  }
+  last_ncalls = last_lastcall = -1;    // whatever `run` this is, the first compute() uploads
+}
+
+void PairTableUCGGPU::bind_mirrors()
+{
+  auto avec = AtomVecUCG::get(lmp);
+  check(ucg_host_bind(ctx, &atom->x[0][0], &atom->v[0][0], &atom->f[0][0], avec->ucgstate, avec->num_ucgstates, avec->ucgl,
+                      avec->ucgvl, avec->ucgp, avec->ucgforce, &avec->ucgsoftmaxscores[0][0]), false);
 }
 
 double PairTableUCGGPU::init_one(int i, int j)
@@ -154,9 +177,29 @@ void PairTableUCGGPU::upload_list()
     }
     check(ucg_ghosts_upload(ctx, src.data(), nghost), false);
   }
-  // a list is stale when Neighbor has built since (ncalls counts every build, also the one setup() of a second
-  // `run` makes on an unchanged timestep) or when the atom counts changed
-  last_list_build = neighbor->ncalls;
+  if (resident) {
+    // every ghost of a single rank is a periodic image: its owner and the box shifts CommBrick applied
+    std::vector<int> src((size_t) nghost), sh((size_t) nghost * 3);
+    if (nghost > 0 && atom->map_style == Atom::MAP_NONE) error->all(FLERR, "USER-UCG/GPU resident mode needs an atom map (atom_modify map yes)");
+    for (int g = 0; g < nghost; g++) {
+      const int o = atom->map(tag[nlocal + g]);
+      if (o < 0 || o >= nlocal) error->one(FLERR, "USER-UCG/GPU: ghost atom without an owned image");
+      src[(size_t) g] = o;
+      for (int d = 0; d < 3; d++) {
+        const double k = (atom->x[nlocal + g][d] - atom->x[o][d]) / domain->prd[d];
+        sh[3 * (size_t) g + d] = k > 0.5 ? 1 : (k < -0.5 ? -1 : 0);
+      }
+    }
+    check(ucg_domain_set(ctx, domain->boxlo, domain->boxhi, ucg_pair_cutforce(gpair), neighbor->skin, user_every, user_delay,
+                         user_check), false);
+    check(ucg_ghosts_upload_images(ctx, src.data(), sh.data(), nghost), false);
+    bind_mirrors();    // (again after every re-neighbouring: grow_pointers may have moved LAMMPS' arrays)
+  }
+  // a list is stale when Neighbor has built since -- ncalls counts the builds of this run (it restarts at every `run`),
+  // lastcall is the timestep of the last one: both are kept, so a second `run` whose setup() build leaves ncalls where
+  // the previous run ended is still seen -- or when the atom counts changed
+  last_ncalls = neighbor->ncalls;
+  last_lastcall = neighbor->lastcall;
   last_nlocal = nlocal;
   last_nghost = nghost;
 }
@@ -186,7 +229,9 @@ void PairTableUCGGPU::compute(int eflag, int vflag)
   ev_init(eflag, vflag);
   auto avec = AtomVecUCG::get(lmp);
   const int nlocal = atom->nlocal;
-  if (neighbor->ncalls != last_list_build || nlocal != last_nlocal || atom->nghost != last_nghost) upload_list();
+  if (neighbor->ncalls != last_ncalls || neighbor->lastcall != last_lastcall || nlocal != last_nlocal || atom->nghost != last_nghost)
+    upload_list();
+  else if (resident) check(ucg_halo_forward(ctx), false);    // owner -> periodic images on the device; nothing is uploaded
   else check(ucg_atoms_upload_comm(ctx, &atom->x[0][0], avec->ucgstate, avec->ucgl, avec->ucgp), false);
 
   double eng = 0.0, vir[6] = {0, 0, 0, 0, 0, 0};
@@ -208,6 +253,15 @@ void PairTableUCGGPU::compute(int eflag, int vflag)
     check(ucg_pair_compute(gpair, eflag_global, vflag_global, &eng, vir), false);
   }
   check(ucg_pair_check_errors(gpair), false);    // "Pair distance < table inner cutoff" etc.
+  if (resident) {
+    // f, ucgforce, scores, num_ucgstates (and ucgp) stay on the device: the package's fixes read them there, and the host
+    // mirrors catch up at the next ucg_host_sync (LAMMPS' force_clear has zeroed the host arrays: the device values are
+    // the whole force in a deck that qualifies for this mode)
+    if (eflag_global) eng_vdwl += eng;
+    if (vflag_global)
+      for (int k = 0; k < 6; k++) virial[k] += vir[k];
+    return;
+  }
 
   std::vector<double> f((size_t) nlocal * 3), uf((size_t) nlocal), sc((size_t) nlocal * 2), up;
   std::vector<int> ns((size_t) nlocal);
@@ -288,5 +342,6 @@ void *PairTableUCGGPU::extract(const char *str, int &dim)
   // the USER-UCG/GPU fixes share this style's device context (fix_ucg_gpu.cpp)
   dim = 0;
   if (strcmp(str, "ucg_ctx") == 0) return (void *) ctx;
+  if (strcmp(str, "ucg_resident") == 0) return (void *) &resident;
   return nullptr;
 }

@@ -49,8 +49,14 @@ class PairTableUCGGPU : public Pair {
   int ucg_style;
   ucg_ctx *ctx = nullptr;
   ucg_pair *gpair = nullptr;
-  bigint last_list_build = -1;
+  bigint last_ncalls = -1, last_lastcall = -1;    // Neighbor's two build counters at the last upload (ncalls restarts per run)
   int last_nlocal = -1, last_nghost = -1;
+  // resident mode (one rank, every per-step style of the deck from this package): the device arrays are authoritative
+  // between the hooks, LAMMPS' arrays are bound as lazily synchronised mirrors (ucg_host_bind), ghosts are refreshed and
+  // the re-neighbour decision is taken on the device.  The USER-UCG/GPU fixes ask for it through extract("ucg_resident").
+  int resident = 0;
+  int user_every = 1, user_delay = 0, user_check = 1;    // neigh_modify as the input gave it (the integrator takes decide() over)
+  void bind_mirrors();
   std::vector<double> aux;    // [nall][2]: priors, then CV forces, of owned + ghost atoms (density style under MPI)
   double T = 0.0;
   int tabstyle = 0, tablength = 0;    // as given to pair_style: what the reference keeps in restart files

