@@ -226,16 +226,49 @@ long long sum(const std::vector<long long> &v)
   return s;
 }
 
+// A rank-local failure between two collectives must not leave the peers blocked in the next ncclRecv: the failing rank
+// keeps taking part -- with empty messages -- until the next point where the ranks agree on a status (an all-reduce of
+// the worst local code), and then every rank returns an error together.  `bad` holds the first local failure.
+struct LocalStatus {
+  int bad = UCG_OK;
+  std::string msg;
+  template <typename F>
+  void run(ucg_ctx *ctx, F &&fn)
+  {
+    if (bad != UCG_OK) return;
+    const int rc = fn();
+    if (rc != UCG_OK) {
+      bad = rc;
+      msg = ctx->err;
+    }
+  }
+  // all ranks: the worst code; a rank that was fine itself reports UCG_ERR_COMM-style text
+  int agree(ucg_ctx *ctx, const char *where)
+  {
+    long long worst = bad;
+    allreduce_ll(ctx, &worst, 1, 1);
+    if (worst == UCG_OK) return UCG_OK;
+    if (bad != UCG_OK) ctx->err = msg;
+    else ctx->err = std::string("another rank failed ") + where + " (every rank stops; the job must be aborted)";
+    return (int) worst;
+  }
+};
+
 // CommBrick::exchange + borders: every bead to the rank that owns its wrapped position, then the images every
-// rank's extended brick needs; afterwards bins and rows are rebuilt (ucg_border_unpack)
+// rank's extended brick needs; afterwards bins and rows are rebuilt (ucg_border_unpack).  Ends with a status agreement.
 int multi_rebuild(ucg_ctx *ctx)
 {
   CommState &C = *ctx->comm;
   const size_t w = (size_t) C.world;
   int arec = 0, hrec = 0;
   ucg_record_bytes(&arec, &hrec);
-  std::vector<long long> sc(w), rc(w), sb(w), rb(w);
-  UCG_RC(ucg_exchange_count(ctx, sc.data()));
+  std::vector<long long> sc(w, 0), rc(w, 0), sb(w, 0), rb(w, 0);
+  LocalStatus st;
+  auto zero = [&]() {
+    if (st.bad != UCG_OK) std::fill(sc.begin(), sc.end(), 0LL);
+  };
+  st.run(ctx, [&] { return ucg_exchange_count(ctx, sc.data()); });
+  zero();
   alltoall_counts(ctx, sc.data(), rc.data());
   for (size_t r = 0; r < w; r++) {
     sb[r] = sc[r] * arec;
@@ -243,10 +276,11 @@ int multi_rebuild(ucg_ctx *ctx)
   }
   C.send.reserve((size_t) sum(sb) + 16);
   C.recv.reserve((size_t) sum(rb) + 16);
-  UCG_RC(ucg_exchange_pack(ctx, C.send.get()));
+  st.run(ctx, [&] { return ucg_exchange_pack(ctx, C.send.get()); });
   alltoallv(ctx, C.send.get(), sb.data(), C.recv.get(), rb.data());
-  UCG_RC(ucg_exchange_unpack(ctx, C.recv.get(), sum(rc)));
-  UCG_RC(ucg_border_count(ctx, sc.data()));
+  st.run(ctx, [&] { return ucg_exchange_unpack(ctx, C.recv.get(), sum(rc)); });
+  st.run(ctx, [&] { return ucg_border_count(ctx, sc.data()); });
+  zero();
   alltoall_counts(ctx, sc.data(), rc.data());
   for (size_t r = 0; r < w; r++) {
     sb[r] = sc[r] * hrec;
@@ -254,9 +288,9 @@ int multi_rebuild(ucg_ctx *ctx)
   }
   C.send.reserve((size_t) sum(sb) + 16);
   C.recv.reserve((size_t) sum(rb) + 16);
-  UCG_RC(ucg_border_pack(ctx, C.send.get()));
+  st.run(ctx, [&] { return ucg_border_pack(ctx, C.send.get()); });
   alltoallv(ctx, C.send.get(), sb.data(), C.recv.get(), rb.data());
-  UCG_RC(ucg_border_unpack(ctx, C.recv.get(), sum(rc)));
+  st.run(ctx, [&] { return ucg_border_unpack(ctx, C.recv.get(), sum(rc)); });
   C.halo_send = sc;
   C.halo_recv = rc;
   C.nsend = sum(sc);
@@ -268,12 +302,12 @@ int multi_rebuild(ucg_ctx *ctx)
     }
     C.auxsend.reserve((size_t) C.nsend * 8 + 16);
     C.auxrecv.reserve((size_t) C.nrecv * 8 + 16);
-    UCG_RC(ucg_halo_molmask_pack(ctx, C.auxsend.get()));
+    st.run(ctx, [&] { return ucg_halo_molmask_pack(ctx, C.auxsend.get()); });
     alltoallv(ctx, C.auxsend.get(), sb.data(), C.auxrecv.get(), rb.data());
-    UCG_RC(ucg_halo_molmask_unpack(ctx, C.auxrecv.get()));
+    st.run(ctx, [&] { return ucg_halo_molmask_unpack(ctx, C.auxrecv.get()); });
   }
   C.nrebuild++;
-  return UCG_OK;
+  return st.agree(ctx, "during the re-neighbouring");
 }
 
 // forward_comm: x (+ shift), lambda, ucgp, state of every ghost from its owner, with the send lists of the last
@@ -460,10 +494,15 @@ int md_run_multi(ucg_ctx *ctx, long long nsteps, int thermo_every)
       UCG_RC(ucg_decide_local(ctx, &due, &flag));
       const bool fuse_next = ctx->md_nve && !ev && (s + 1 < nsteps) && !ctx->md_no_fuse;
       bool rebuilt = false;
-      if (due) {  // Neighbor::decide(): MPI_Allreduce of the flag
-        long long f = flag;
-        allreduce_ll(ctx, &f, 1, 1);
-        rebuilt = f != 0;
+      if (due) {  // Neighbor::decide(): MPI_Allreduce of the flag -- and of the ranks' status since the last agreement
+        long long f[2] = {flag, pending};
+        allreduce_ll(ctx, f, 2, 1);
+        if (f[1] != UCG_OK) {
+          if (pending == UCG_OK) ctx->err = "another rank failed in the step loop (every rank stops; the job must be aborted)";
+          else ctx->err = pending_msg;
+          return (int) f[1];
+        }
+        rebuilt = f[0] != 0;
       }
       if (rebuilt) {
         UCG_RC(poll_pair_errors(ctx));  // the stream is drained here anyway: check the steps since the last rebuild

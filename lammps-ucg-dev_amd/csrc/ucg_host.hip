@@ -245,6 +245,10 @@ int ucg_verlet_hooks_run(ucg_ctx *ctx, ucg_pair *p, long long nsteps, int use_nv
 {
   if (!ctx || !p || p->ctx != ctx || nsteps < 0) return UCG_ERR_INVALID;
   long long nre = 0, nsync = 0;
+  if (ctx->endstep <= ctx->ntimestep) {  // no Verlet::setup() (ucg_md_setup) framed this run: it is a run of its own
+    ctx->beginstep = ctx->ntimestep;
+    ctx->endstep = ctx->ntimestep + nsteps;
+  }
   const long long up0 = ctx->mirror.uploads, dn0 = ctx->mirror.downloads;
 #define UCG_STEP(call)              \
   do {                              \

@@ -160,6 +160,22 @@ def lib():
         getattr(L, fn).restype = c_int_p
     L.orc_sim_mass.argtypes = [C.c_void_p]
     L.orc_sim_mass.restype = c_double_p
+    L.orc_world_create.argtypes = [c_int_p, C.c_int, c_double_p, c_double_p, C.c_double, C.c_double, C.c_int]
+    L.orc_world_create.restype = C.c_void_p
+    L.orc_world_destroy.argtypes = [C.c_void_p]
+    L.orc_world_nranks.argtypes = [C.c_void_p]
+    L.orc_world_rank.argtypes = [C.c_void_p, C.c_int]
+    L.orc_world_rank.restype = C.c_void_p
+    L.orc_world_input.argtypes = [C.c_void_p]
+    L.orc_world_input.restype = C.POINTER(Atoms)
+    L.orc_world_input_molecule.argtypes = [C.c_void_p]
+    L.orc_world_input_molecule.restype = c_int_p
+    L.orc_world_set_run_params.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_int]
+    L.orc_world_attach.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_double,
+                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_double]
+    L.orc_world_setup.argtypes = [C.c_void_p, C.c_longlong]
+    L.orc_world_run.argtypes = [C.c_void_p, C.c_longlong, C.c_int]
+    L.orc_world_get_ev.argtypes = [C.c_void_p, c_double_p]
     L.orc_sim_compute_forces.argtypes = [C.c_void_p, C.c_int, C.c_int]
     _LIB = L
     return L
@@ -450,3 +466,86 @@ class Sim:
 
     def half_list(self):
         return list_to_csr(self.L.orc_sim_half_list(self.h))
+
+
+class World:
+    """A decomposed run in the oracle (orc_md.h: orc_world): px x py x pz bricks, one rank simulation each, per-rank
+    RanMars streams (seed + me) in local bead order -- what the GPU library's decomposed loop must reproduce bit for bit."""
+
+    def __init__(self, beads, grid, cutforce=2.5, skin=0.3):
+        self.L = L = lib()
+        n = beads.n
+        g = (C.c_int * 3)(*[int(v) for v in grid])
+        lo = np.ascontiguousarray(beads.boxlo, dtype=np.float64)
+        hi = np.ascontiguousarray(beads.boxhi, dtype=np.float64)
+        self.h = L.orc_world_create(g, n, _dp(lo), _dp(hi), cutforce, skin, beads.ntypes)
+        self.nranks = L.orc_world_nranks(self.h)
+        a = L.orc_world_input(self.h).contents
+        np.ctypeslib.as_array(a.x, shape=(n, 3))[:] = beads.x
+        np.ctypeslib.as_array(a.v, shape=(n, 3))[:] = beads.v
+        for name in ("type", "tag", "mask", "ucgstate"):
+            np.ctypeslib.as_array(getattr(a, name), shape=(n,))[:] = getattr(beads, name)
+        for name in ("ucgl", "ucgvl", "ucgml", "ucgp"):
+            np.ctypeslib.as_array(getattr(a, name), shape=(n,))[:] = getattr(beads, name)
+        np.ctypeslib.as_array(a.mass, shape=(beads.ntypes + 1,))[:] = beads.mass
+        mol = getattr(beads, "molecule", None)
+        np.ctypeslib.as_array(L.orc_world_input_molecule(self.h), shape=(n,))[:] = beads.tag if mol is None else mol
+        self.pair = None
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.orc_world_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def set_run_params(self, dt=0.002, every=1, delay=0, check=1):
+        self.L.orc_world_set_run_params(self.h, dt, every, delay, check)
+
+    def attach(self, pair: "Pair", langevin=None, nve=True, ucgstate=None):
+        """arguments as Sim.attach; the fixes are created on every rank with seed + rank"""
+        self.pair = pair
+        kind, barrier = (1 if nve is True else 0), 0.1
+        if nve == "wall":
+            kind = 2
+        elif isinstance(nve, tuple):
+            kind, barrier = 3, float(nve[1])
+        lg = langevin or (0.0, 0.0, 1.0, 1)
+        have_ucg, ld, mc, seed, rate = 0, 0, 0, 0, 0.01
+        if ucgstate is not None:
+            have_ucg = 1
+            if ucgstate == "ld":
+                ld = 1
+            elif ucgstate != "plain":
+                mc, seed, rate = 1, int(ucgstate[1]), float(ucgstate[2])
+        self.L.orc_world_attach(self.h, pair.h, 1 if langevin else 0, lg[0], lg[1], lg[2], int(lg[3]), kind, barrier, have_ucg, ld,
+                                mc, seed, rate)
+
+    def setup(self, nsteps):
+        return self.L.orc_world_setup(self.h, nsteps)
+
+    def run(self, nsteps, thermo_every=0):
+        return self.L.orc_world_run(self.h, nsteps, thermo_every)
+
+    def ev(self):
+        out = np.zeros(7)
+        self.L.orc_world_get_ev(self.h, _dp(out))
+        return dict(eng_vdwl=out[0], virial=out[1:7].copy())
+
+    def rank_arrays(self, r, ghosts=False):
+        """the per-atom arrays of rank r, as Sim.arrays"""
+        s = Sim.__new__(Sim)
+        s.L, s.h, s.lang, s.pair = self.L, self.L.orc_world_rank(self.h, r), None, None
+        try:
+            return s.arrays(ghosts=ghosts)
+        finally:
+            s.h = None  # borrowed: the world owns the rank simulations
+
+    def rank_info(self, r):
+        s = Sim.__new__(Sim)
+        s.L, s.h, s.lang, s.pair = self.L, self.L.orc_world_rank(self.h, r), None, None
+        try:
+            return s.info()
+        finally:
+            s.h = None

@@ -44,6 +44,8 @@ orc_sim *orc_sim_create(int natoms, const double *boxlo, const double *boxhi, do
     s->boxlo[d] = boxlo[d];
     s->boxhi[d] = boxhi[d];
     s->prd[d] = boxhi[d] - boxlo[d];
+    s->sublo[d] = boxlo[d];
+    s->subhi[d] = boxhi[d];
   }
   s->cutforce = cutforce;
   s->skin = skin;
@@ -85,6 +87,7 @@ void orc_sim_grow(orc_sim *s, int nmax)
   a->scores = (double *) xrealloc(a->scores, 2 * n * sizeof(double));
   s->xhold = (double *) xrealloc(s->xhold, 3 * n * sizeof(double));
   s->ghost_src = (int *) xrealloc(s->ghost_src, n * sizeof(int));
+  s->ghost_rank = (int *) xrealloc(s->ghost_rank, n * sizeof(int));
   s->ghost_shift = (int *) xrealloc(s->ghost_shift, 3 * n * sizeof(int));
   s->bin_of = (int *) xrealloc(s->bin_of, n * sizeof(int));
   s->molecule = (int *) xrealloc(s->molecule, n * sizeof(int));
@@ -104,7 +107,7 @@ void orc_sim_destroy(orc_sim *s)
   free(a->x); free(a->v); free(a->f); free(a->type); free(a->tag); free(a->mask);
   free(a->ucgstate); free(a->num_ucgstates); free(a->ucgl); free(a->ucgvl); free(a->ucgml);
   free(a->ucgp); free(a->ucgforce); free(a->scores); free(a->mass);
-  free(s->xhold); free(s->ghost_src); free(s->ghost_shift); free(s->bin_of); free(s->molecule);
+  free(s->xhold); free(s->ghost_src); free(s->ghost_rank); free(s->ghost_shift); free(s->bin_of); free(s->molecule);
   orc_cs_destroy(s->cs);
   free(s->binstart_owned); free(s->binstart_ghost);
   free(s->full.ilist); free(s->full.numneigh); free(s->full.first); free(s->full.neigh);
@@ -138,8 +141,8 @@ void orc_sim_setup_bins(orc_sim *s)
   const double target = 0.5 * s->cutneigh;
   s->nbins = 1;
   for (int d = 0; d < 3; d++) {
-    s->bboxlo[d] = s->boxlo[d] - s->cutneigh;
-    const double ext = (s->boxhi[d] + s->cutneigh) - s->bboxlo[d];
+    s->bboxlo[d] = s->sublo[d] - s->cutneigh;
+    const double ext = (s->subhi[d] + s->cutneigh) - s->bboxlo[d];
     int nb = (int) (ext / target);
     if (nb < 1) nb = 1;
     s->nbin[d] = nb;
@@ -180,7 +183,7 @@ static long long morton_of_bin(const orc_sim *s, int b)
   return m;
 }
 
-typedef struct { long long key; int idx; int code; int bin; } sortrec;
+typedef struct { long long key; int idx; int code; int bin; int rank; } sortrec;
 
 static int cmp_sortrec(const void *pa, const void *pb)
 {
@@ -241,8 +244,8 @@ static void build_ghosts(orc_sim *s)
   const int n = a->nlocal;
   double lo[3], hi[3];
   for (int d = 0; d < 3; d++) {
-    lo[d] = s->boxlo[d] - s->cutneigh;
-    hi[d] = s->boxhi[d] + s->cutneigh;
+    lo[d] = s->sublo[d] - s->cutneigh;
+    hi[d] = s->subhi[d] + s->cutneigh;
   }
   int cap = 1024, ng = 0;
   sortrec *r = (sortrec *) malloc(sizeof(sortrec) * (size_t) cap);
@@ -650,3 +653,307 @@ const int *orc_sim_ghost_shift(const orc_sim *s) { return s->ghost_shift; }
 const int *orc_sim_bin_of(const orc_sim *s) { return s->bin_of; }
 double *orc_sim_mass(orc_sim *s) { return s->a.mass; }
 int orc_sim_compute_forces(orc_sim *s, int eflag, int vflag) { return compute_forces(s, eflag, vflag); }
+
+
+/* ------------------------------------------------------------------ decomposed runs (orc_md.h: orc_world) */
+
+struct orc_world {
+  int nranks, grid[3];
+  orc_sim **r;
+  orc_fix_langevin **lang; /* per rank, or NULL */
+  orc_atoms input;         /* the beads handed in (rank 0's arrays until the first re-neighbouring) */
+  double ev[7];
+};
+
+static double proc_bound(const orc_sim *s, const int *grid, int d, int i)
+{
+  /* LAMMPS' uniform bricks: boxlo + prd * i / procgrid, the last one ends at boxhi (same expression as the library) */
+  return (i >= grid[d]) ? s->boxhi[d] : s->boxlo[d] + s->prd[d] * i / grid[d];
+}
+
+static int owner_of(const orc_sim *s, const int *grid, const double *x)
+{
+  int loc[3];
+  for (int d = 0; d < 3; d++) {
+    loc[d] = 0;
+    for (int i = 1; i < grid[d]; i++)
+      if (x[d] >= proc_bound(s, grid, d, i)) loc[d] = i;
+  }
+  return loc[0] + grid[0] * (loc[1] + grid[1] * loc[2]);
+}
+
+orc_world *orc_world_create(const int *grid3, int natoms, const double *boxlo, const double *boxhi, double cutforce,
+                            double skin, int ntypes)
+{
+  orc_world *w = (orc_world *) calloc(1, sizeof(orc_world));
+  w->nranks = grid3[0] * grid3[1] * grid3[2];
+  for (int d = 0; d < 3; d++) w->grid[d] = grid3[d];
+  w->r = (orc_sim **) calloc((size_t) w->nranks, sizeof(orc_sim *));
+  w->lang = (orc_fix_langevin **) calloc((size_t) w->nranks, sizeof(orc_fix_langevin *));
+  for (int me = 0; me < w->nranks; me++) {
+    orc_sim *s = orc_sim_create(me == 0 ? natoms : 0, boxlo, boxhi, cutforce, skin, ntypes);
+    const int loc[3] = {me % grid3[0], (me / grid3[0]) % grid3[1], me / (grid3[0] * grid3[1])};
+    for (int d = 0; d < 3; d++) {
+      s->sublo[d] = proc_bound(s, grid3, d, loc[d]);
+      s->subhi[d] = proc_bound(s, grid3, d, loc[d] + 1);
+    }
+    w->r[me] = s;
+  }
+  return w;
+}
+
+void orc_world_destroy(orc_world *w)
+{
+  if (!w) return;
+  for (int me = 0; me < w->nranks; me++) {
+    orc_sim_destroy(w->r[me]);
+    if (w->lang[me]) orc_fix_langevin_destroy(w->lang[me]);
+  }
+  free(w->r);
+  free(w->lang);
+  free(w);
+}
+
+int orc_world_nranks(const orc_world *w) { return w->nranks; }
+orc_sim *orc_world_rank(orc_world *w, int r) { return w->r[r]; }
+orc_atoms *orc_world_input(orc_world *w) { return &w->r[0]->a; }
+int *orc_world_input_molecule(orc_world *w) { return w->r[0]->molecule; }
+
+void orc_world_set_run_params(orc_world *w, double dt, int every, int delay, int check)
+{
+  for (int me = 0; me < w->nranks; me++) orc_sim_set_run_params(w->r[me], dt, every, delay, check, 1);
+}
+
+void orc_world_attach(orc_world *w, orc_pair *pair, int have_langevin, double t_start, double t_stop, double t_period,
+                      int lang_seed, int have_nve, double wall_barrier, int have_ucgstate, int ld_flag, int mc_flag,
+                      int mc_seed, double mc_rate)
+{
+  for (int me = 0; me < w->nranks; me++) {
+    orc_sim *s = w->r[me];
+    if (w->lang[me]) orc_fix_langevin_destroy(w->lang[me]);
+    /* RanMars(seed + comm->me): UCG/fix_ucgld_langevin.cpp:85, UCG/fix_ucgstate.cpp:62 */
+    w->lang[me] = have_langevin ? orc_fix_langevin_create(s->ntypes, t_start, t_stop, t_period, lang_seed, me) : NULL;
+    s->pair = pair;
+    s->lang = w->lang[me];
+    s->have_nve = have_nve;
+    s->wall_barrier = wall_barrier;
+    s->have_ucgstate = have_ucgstate;
+    if (have_ucgstate) orc_fix_ucgstate_init(&s->ucgst, ld_flag, mc_flag, mc_seed, mc_rate, me);
+    for (int t = 0; t <= s->ntypes; t++) s->a.mass[t] = w->r[0]->a.mass[t];
+  }
+}
+
+/* forward halo: every ghost takes x + shift * prd, state, lambda, ucgp from its owner (fields_comm, UCG/atom_vec_ucg.cpp:71) */
+static void world_forward(orc_world *w)
+{
+  for (int me = 0; me < w->nranks; me++) {
+    orc_sim *s = w->r[me];
+    orc_atoms *a = &s->a;
+    const int n = a->nlocal;
+    for (int g = 0; g < a->nghost; g++) {
+      const orc_atoms *o = &w->r[s->ghost_rank[g]]->a;
+      const int src = s->ghost_src[g];
+      for (int d = 0; d < 3; d++) a->x[3 * (n + g) + d] = o->x[3 * src + d] + s->ghost_shift[3 * g + d] * s->prd[d];
+      a->ucgstate[n + g] = o->ucgstate[src];
+      a->ucgl[n + g] = o->ucgl[src];
+      a->ucgp[n + g] = o->ucgp[src];
+    }
+  }
+}
+
+typedef struct {
+  double x[3], v[3], ucgl, ucgvl, ucgml, ucgp;
+  int type, tag, mask, state, nstates, mol;
+} beadrec;
+
+static void world_rebuild(orc_world *w)
+{
+  /* (1) wrap, (2) every bead to the rank whose brick holds it */
+  int total = 0;
+  for (int me = 0; me < w->nranks; me++) {
+    pbc_wrap(w->r[me]);
+    total += w->r[me]->a.nlocal;
+  }
+  beadrec *all = (beadrec *) malloc(sizeof(beadrec) * (size_t) (total ? total : 1));
+  int *owner = (int *) malloc(sizeof(int) * (size_t) (total ? total : 1));
+  int *count = (int *) calloc((size_t) (w->nranks > 0 ? w->nranks : 1), sizeof(int));
+  int k = 0;
+  for (int me = 0; me < w->nranks; me++) {
+    const orc_sim *s = w->r[me];
+    const orc_atoms *a = &s->a;
+    for (int i = 0; i < a->nlocal; i++, k++) {
+      beadrec *b = &all[k];
+      for (int d = 0; d < 3; d++) {
+        b->x[d] = a->x[3 * i + d];
+        b->v[d] = a->v[3 * i + d];
+      }
+      b->ucgl = a->ucgl[i]; b->ucgvl = a->ucgvl[i]; b->ucgml = a->ucgml[i]; b->ucgp = a->ucgp[i];
+      b->type = a->type[i]; b->tag = a->tag[i]; b->mask = a->mask[i]; b->state = a->ucgstate[i];
+      b->nstates = a->num_ucgstates[i]; b->mol = s->molecule[i];
+      owner[k] = owner_of(s, w->grid, b->x);
+      count[owner[k]]++;
+    }
+  }
+  for (int me = 0; me < w->nranks; me++) {
+    orc_sim *s = w->r[me];
+    orc_sim_grow(s, count[me] + count[me] / 2 + 1024);
+    s->a.nlocal = 0;
+    s->a.nghost = 0;
+  }
+  for (k = 0; k < total; k++) {
+    orc_sim *s = w->r[owner[k]];
+    orc_atoms *a = &s->a;
+    const int i = a->nlocal++;
+    const beadrec *b = &all[k];
+    for (int d = 0; d < 3; d++) {
+      a->x[3 * i + d] = b->x[d];
+      a->v[3 * i + d] = b->v[d];
+    }
+    a->ucgl[i] = b->ucgl; a->ucgvl[i] = b->ucgvl; a->ucgml[i] = b->ucgml; a->ucgp[i] = b->ucgp;
+    a->type[i] = b->type; a->tag[i] = b->tag; a->mask[i] = b->mask; a->ucgstate[i] = b->state;
+    a->num_ucgstates[i] = b->nstates; s->molecule[i] = b->mol;
+  }
+  free(all);
+  free(owner);
+  free(count);
+  /* (3) each rank: bins of its brick, owned beads by (Morton bin, tag) */
+  for (int me = 0; me < w->nranks; me++) {
+    orc_sim_setup_bins(w->r[me]);
+    sort_owned(w->r[me]);
+  }
+  /* (4) ghosts of rank me: every image (bead of rank q, shift) inside me's extended brick, its own unshifted beads
+     excepted; sorted by (Morton bin, tag, shift code) */
+  for (int me = 0; me < w->nranks; me++) {
+    orc_sim *s = w->r[me];
+    double lo[3], hi[3];
+    for (int d = 0; d < 3; d++) {
+      lo[d] = s->sublo[d] - s->cutneigh;
+      hi[d] = s->subhi[d] + s->cutneigh;
+    }
+    int cap = 4096, ng = 0;
+    sortrec *rec = (sortrec *) malloc(sizeof(sortrec) * (size_t) cap);
+    for (int q = 0; q < w->nranks; q++) {
+      const orc_atoms *o = &w->r[q]->a;
+      for (int code = 0; code < 27; code++) {
+        if (q == me && code == 13) continue;
+        const int sx = code % 3 - 1, sy = (code / 3) % 3 - 1, sz = code / 9 - 1;
+        for (int i = 0; i < o->nlocal; i++) {
+          double xs[3];
+          xs[0] = o->x[3 * i + 0] + sx * s->prd[0];
+          xs[1] = o->x[3 * i + 1] + sy * s->prd[1];
+          xs[2] = o->x[3 * i + 2] + sz * s->prd[2];
+          if (xs[0] < lo[0] || xs[0] >= hi[0] || xs[1] < lo[1] || xs[1] >= hi[1] || xs[2] < lo[2] || xs[2] >= hi[2]) continue;
+          if (ng == cap) {
+            cap *= 2;
+            rec = (sortrec *) xrealloc(rec, sizeof(sortrec) * (size_t) cap);
+          }
+          rec[ng].bin = coord2bin(s, xs);
+          rec[ng].key = (morton_of_bin(s, rec[ng].bin) << 32) | (unsigned int) o->tag[i];
+          rec[ng].idx = i;
+          rec[ng].code = code;
+          rec[ng].rank = q;
+          ng++;
+        }
+      }
+    }
+    qsort(rec, (size_t) ng, sizeof(sortrec), cmp_sortrec);
+    const int n = s->a.nlocal;
+    orc_sim_grow(s, n + ng);
+    orc_atoms *a = &s->a;
+    a->nghost = ng;
+    for (int g = 0; g < ng; g++) {
+      const int code = rec[g].code;
+      const orc_sim *os = w->r[rec[g].rank];
+      s->ghost_rank[g] = rec[g].rank;
+      s->ghost_src[g] = rec[g].idx;
+      s->ghost_shift[3 * g + 0] = code % 3 - 1;
+      s->ghost_shift[3 * g + 1] = (code / 3) % 3 - 1;
+      s->ghost_shift[3 * g + 2] = code / 9 - 1;
+      s->bin_of[n + g] = rec[g].bin;
+      a->tag[n + g] = os->a.tag[rec[g].idx];
+      a->type[n + g] = os->a.type[rec[g].idx];
+      a->mask[n + g] = os->a.mask[rec[g].idx];
+      s->molecule[n + g] = os->molecule[rec[g].idx];
+    }
+    free(rec);
+  }
+  world_forward(w);
+  /* (5) rows */
+  for (int me = 0; me < w->nranks; me++) {
+    orc_sim *s = w->r[me];
+    build_bins(s);
+    build_lists(s);
+    memcpy(s->xhold, s->a.x, sizeof(double) * 3 * (size_t) s->a.nlocal);
+    s->ago = 0;
+    s->nrebuild++;
+  }
+}
+
+static int world_forces(orc_world *w, int ev)
+{
+  int rc_any = 0;
+  for (int c = 0; c < 7; c++) w->ev[c] = 0.0;
+  for (int me = 0; me < w->nranks; me++) {
+    orc_sim *s = w->r[me];
+    if (s->pair->style == ORC_STYLE_BETHE_DENSITY) return 99; /* its mid-compute halos cross ranks: not stated here */
+    s->mode = 1;
+    const int rc = compute_forces(s, ev, ev);
+    if (rc) rc_any = rc;
+    w->ev[0] += s->ev.eng_vdwl;
+    for (int c = 0; c < 6; c++) w->ev[1 + c] += s->ev.virial[c];
+  }
+  return rc_any;
+}
+
+int orc_world_setup(orc_world *w, long long nsteps_planned)
+{
+  for (int me = 0; me < w->nranks; me++) {
+    orc_sim *s = w->r[me];
+    s->beginstep = s->ntimestep;
+    s->endstep = s->ntimestep + nsteps_planned;
+  }
+  world_rebuild(w);
+  /* Fix_UCGLD_Langevin::init() reads atom->ucgml[type index] of the LOCAL bead order (App. B #5) */
+  for (int me = 0; me < w->nranks; me++) {
+    orc_sim *s = w->r[me];
+    if (s->lang) orc_fix_langevin_init(s->lang, &s->a, s->dt, s->boltz, s->ftm2v, s->mvv2e);
+  }
+  const int rc = world_forces(w, 1);
+  for (int me = 0; me < w->nranks; me++) post_force(w->r[me]);
+  return rc;
+}
+
+int orc_world_run(orc_world *w, long long nsteps, int thermo_every)
+{
+  int rc_any = 0;
+  for (long long n = 0; n < nsteps; n++) {
+    int flag = 0;
+    int ev = 0;
+    for (int me = 0; me < w->nranks; me++) {
+      orc_sim *s = w->r[me];
+      s->ntimestep++;
+      ev = (thermo_every > 0 && (s->ntimestep % thermo_every == 0)) ? 1 : 0;
+      if (s->have_nve == 1) orc_fix_nve_initial(&s->a, s->dt, s->ftm2v, s->groupbit);
+      else if (s->have_nve >= 2) orc_fix_nve_wall_initial(&s->a, s->dt, s->ftm2v, s->groupbit);
+      if (decide(s)) flag = 1; /* Neighbor::decide(): MPI_Allreduce of the ranks' flags */
+    }
+    if (flag) world_rebuild(w);
+    else world_forward(w);
+    const int rc = world_forces(w, ev);
+    if (rc) rc_any = rc;
+    for (int me = 0; me < w->nranks; me++) {
+      orc_sim *s = w->r[me];
+      integrator_post_force(s);
+      post_force(s);
+      if (s->have_nve == 1) orc_fix_nve_final(&s->a, s->dt, s->ftm2v, s->groupbit);
+      else if (s->have_nve >= 2) orc_fix_nve_wall_final(&s->a, s->dt, s->ftm2v, s->groupbit);
+      if (s->lang) orc_fix_langevin_end_of_step(s->lang, &s->a, s->groupbit, s->boltz, s->mvv2e);
+    }
+  }
+  return rc_any;
+}
+
+void orc_world_get_ev(const orc_world *w, double *out7)
+{
+  for (int c = 0; c < 7; c++) out7[c] = w->ev[c];
+}

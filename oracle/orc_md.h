@@ -11,6 +11,7 @@ extern "C" {
 
 typedef struct {
   double boxlo[3], boxhi[3], prd[3];
+  double sublo[3], subhi[3]; /* this rank's brick (= the box for a single-rank run) */
   double cutforce, skin, cutneigh;
   int every, delay, check; /* neigh_modify */
   int ntypes;
@@ -21,7 +22,8 @@ typedef struct {
   orc_atoms a;
   int nmax;
   double *xhold;
-  int *ghost_src;   /* [nghost] owned index this ghost is an image of */
+  int *ghost_src;   /* [nghost] owned index this ghost is an image of (on rank ghost_rank[g] in a decomposed run) */
+  int *ghost_rank;  /* [nghost] decomposed runs (orc_world): the rank that owns the source bead, else unused */
   int *ghost_shift; /* [nghost*3] periodic shift in box lengths       */
   int *bin_of;      /* [nall] bin id at the last rebuild               */
 
@@ -74,6 +76,37 @@ const int *orc_sim_ghost_shift(const orc_sim *s);
 const int *orc_sim_bin_of(const orc_sim *s);
 double *orc_sim_mass(orc_sim *s);
 int orc_sim_compute_forces(orc_sim *s, int eflag, int vflag);
+
+/* ---- decomposed runs: px x py x pz bricks, one orc_sim per rank (the per-rank semantics of a LAMMPS run with these
+ * styles, as the GPU library's decomposed loop implements them -- csrc/ucg_comm.hip, "ucg-rebuild-v1" per brick):
+ *   rank me = ix + px (iy + py iz) owns the beads whose wrapped position lies in its brick [boxlo + prd i / p, ...);
+ *   a re-neighbouring wraps, migrates every bead to its owner, sorts each rank's beads by (Morton bin of the brick's
+ *   own bin grid, tag), makes rank r's ghosts from every (bead of any rank, box shift) image inside r's brick extended
+ *   by the list cutoff -- its own unshifted beads excepted -- sorted by (Morton bin, tag, shift code), and builds r's rows;
+ *   every step the ghosts take x + shift, lambda, ucgp, state from their owners (forward halo; no reverse halo in the
+ *   canonical gather order); Neighbor::decide is the MAX of the ranks' flags (upstream MPI_Allreduce);
+ *   the random streams are per rank: RanMars(seed + me) drawn in the rank's local bead order
+ *   (UCG/fix_ucgld_langevin.cpp:85, 280; UCG/fix_ucgstate.cpp:62, 117).
+ * Gather styles (table_ucgld, table_ucg_bethe) in canonical order; fix cluster_switch and the density style's
+ * mid-compute halos are not covered here. */
+typedef struct orc_world orc_world;
+orc_world *orc_world_create(const int *grid3, int natoms, const double *boxlo, const double *boxhi, double cutforce,
+                            double skin, int ntypes);
+void orc_world_destroy(orc_world *w);
+int orc_world_nranks(const orc_world *w);
+orc_sim *orc_world_rank(orc_world *w, int r);
+/* natoms beads handed to rank 0 as a start (the first re-neighbouring sends every bead to its owner) */
+orc_atoms *orc_world_input(orc_world *w);
+int *orc_world_input_molecule(orc_world *w);
+void orc_world_set_run_params(orc_world *w, double dt, int every, int delay, int check);
+/* fixes on every rank: langevin (NULL-able by have_langevin = 0) with seed + me, ucgstate with mc_seed + me */
+void orc_world_attach(orc_world *w, orc_pair *pair, int have_langevin, double t_start, double t_stop, double t_period,
+                      int lang_seed, int have_nve, double wall_barrier, int have_ucgstate, int ld_flag, int mc_flag,
+                      int mc_seed, double mc_rate);
+int orc_world_setup(orc_world *w, long long nsteps_planned);
+int orc_world_run(orc_world *w, long long nsteps, int thermo_every);
+/* totals over the ranks of the last energy evaluation: eng_vdwl, virial[6] */
+void orc_world_get_ev(const orc_world *w, double *out7);
 
 #ifdef __cplusplus
 }

@@ -253,6 +253,62 @@ def test_world2_thermostatted_run_is_reproducible(pkg, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_world2_thermostatted_run_equals_the_decomposed_oracle_bit_for_bit(pkg, orc):
+    """fix ucgld/langevin + fix ucgstate mc + fix nve/ucgld/wall/hard on two ranks against the oracle's statement of the
+    same decomposed run (oracle/orc_md.c: orc_world -- bricks, per-rank bead order, RanMars(seed + me) streams drawn in
+    local order, migration): every rank's beads in its local order, positions, velocities, lambda and states after 360
+    steps with migration, bit for bit; and the bead counts of the ranks along the run"""
+    res = _launch("gpu_lang", world=2)
+    deck = util.make_deck("spline", 1024)
+    beads = pkg.synth.make_beads(10, seed=5)
+    op = util.oracle_pair("table_ucgld", deck)
+    w = orc.World(beads, [2, 1, 1])
+    w.set_run_params(dt=0.004, every=2, delay=0, check=1)
+    w.attach(op, langevin=(1.0, 1.0, 1.0, 48279), nve="wall", ucgstate=("mc", 9127, 0.3))
+    assert w.setup(360) == 0
+    counts = [[w.rank_arrays(r)["nlocal"]] for r in range(2)]
+    for _ in range(6):
+        assert w.run(60) == 0
+        for r in range(2):
+            counts[r].append(w.rank_arrays(r)["nlocal"])
+    assert any(len(set(c)) > 1 for c in counts)
+    for r in range(2):
+        O = w.rank_arrays(r)
+        G = res[r]
+        assert G["counts"] == counts[r]
+        assert np.array_equal(G["tag"], O["tag"]) and np.array_equal(G["st"], O["ucgstate"])
+        assert util.bits_equal(G["x"], O["x"]) and util.bits_equal(G["l"], O["ucgl"]) and util.bits_equal(G["v"], O["v"])
+        assert G["nrebuild"] == w.rank_info(r)["nrebuild"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_decomposed_forces_and_trajectory_equal_the_decomposed_oracle_bit_for_bit(pkg, orc, world):
+    """2 x 1 x 1 and 2 x 2 x 1 bricks: forces, ucgforce and scores of every rank at setup and positions / lambda after 40
+    steps with re-neighbouring, in each rank's local order, against orc_world -- the canonical order of a decomposed run
+    is a function of the decomposition, and the oracle states it"""
+    res = _launch("gpu", world=world)
+    deck = util.make_deck("spline", 1024)
+    beads = pkg.synth.make_beads(10, seed=5)
+    op = util.oracle_pair("table_ucgld", deck)
+    w = orc.World(beads, pkg.multi.choose_procgrid(world))
+    w.set_run_params(dt=0.004, every=2, delay=0, check=1)
+    w.attach(op, langevin=None, nve=True, ucgstate=None)
+    assert w.setup(40) == 0
+    for r in range(world):
+        O, G = w.rank_arrays(r), res[r]
+        assert np.array_equal(G["tag0"], O["tag"])
+        assert util.bits_equal(G["f0"], O["f"]) and util.bits_equal(G["uf0"], O["ucgforce"]) and util.bits_equal(G["s0"], O["scores"])
+    assert abs(res[0]["e0"] - w.ev()["eng_vdwl"]) <= 1e-12 * abs(res[0]["e0"])
+    assert w.run(40, 40) == 0
+    for r in range(world):
+        O, G = w.rank_arrays(r), res[r]
+        assert np.array_equal(G["tag1"], O["tag"])
+        assert util.bits_equal(G["x1"], O["x"]) and util.bits_equal(G["l1"], O["ucgl"])
+        assert G["nrebuild"] == w.rank_info(r)["nrebuild"] and G["nghost"] == O["nghost"]
+
+
+@pytest.mark.gpu
 def test_world2_config5_density_with_cluster_switch_vs_oracle(pkg, orc):
     """BASELINE.json config 5 in small (table_ucg_bethe_density + fix ucgstate mc + fix cluster_switch on two actual atom
     types), two ranks, against the ORACLE's single-rank run of the same beads: forces, posteriors and states at setup by
