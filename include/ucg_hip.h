@@ -266,7 +266,13 @@ int ucg_decide_local(ucg_ctx *ctx, int *due, int *flag);
  *                    work queued on `stream` (a hipStream_t) and complete, or be ordered on it, on return
  *     alltoall_ll    host arrays, one long long per rank each way, blocking
  *     allreduce_ll / allreduce_f64   host arrays of n elements, in place, blocking; op 0 = sum, 1 = max, 2 = min
- * Callbacks return 0 on success.  fix cluster_switch on a decomposed run: create it on every rank after the beads
+ * Callbacks return 0 on success.  Errors: a rank-local failure (a HIP error, an overflowing neighbour row, a pair-table
+ * range violation) is held by that rank, which keeps taking part in the collectives with empty or stale messages until the
+ * next status agreement (the all-reduce of the re-neighbour decision, an error poll, the end of the re-neighbouring), where
+ * EVERY rank returns an error code from ucg_md_setup / ucg_md_run together -- no rank is left blocked in a receive.  The
+ * simulation state is undefined afterwards: the caller must abort the job (MPI_Abort).  A failure of the communicator
+ * itself (UCG_ERR_COMM from RCCL or a callback) cannot be agreed on and is returned at once.
+ * fix cluster_switch on a decomposed run: create it on every rank after the beads
  * and molecule ids are uploaded; the library performs its reductions at the next ucg_md_setup. */
 typedef struct ucg_comm_ops {
   void *user;

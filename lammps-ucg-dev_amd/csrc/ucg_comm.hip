@@ -17,6 +17,7 @@
 // per-molecule arrays of fix cluster_switch) go through the same communicator.
 #include <dlfcn.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -313,7 +314,7 @@ int multi_rebuild(ucg_ctx *ctx)
 // forward_comm: x (+ shift), lambda, ucgp, state of every ghost from its owner, with the send lists of the last
 // border exchange; the unpack of a step is ordered before the next step's transfer on the stream, so one pair of
 // buffers serves
-int multi_halo_forward(ucg_ctx *ctx)
+int multi_halo_forward(ucg_ctx *ctx, LocalStatus *ls = nullptr)
 {
   CommState &C = *ctx->comm;
   const size_t w = (size_t) C.world;
@@ -324,14 +325,21 @@ int multi_halo_forward(ucg_ctx *ctx)
     sb[r] = C.halo_send[r] * hrec;
     rb[r] = C.halo_recv[r] * hrec;
   }
-  UCG_RC(ucg_halo_pack(ctx, C.send.get()));
+  // a rank with a pending local failure (ls->bad) still moves its (stale) buffers: the peers' receives complete
+  LocalStatus own;
+  LocalStatus &st = ls ? *ls : own;
+  st.run(ctx, [&] { return ucg_halo_pack(ctx, C.send.get()); });
   alltoallv(ctx, C.send.get(), sb.data(), C.recv.get(), rb.data());
-  UCG_RC(ucg_halo_unpack(ctx, C.recv.get()));
+  st.run(ctx, [&] { return ucg_halo_unpack(ctx, C.recv.get()); });
+  if (!ls && own.bad != UCG_OK) {
+    ctx->err = own.msg;
+    return own.bad;
+  }
   return UCG_OK;
 }
 
 // one double2 per ghost from its owner: the density style's priors (which = 0) and CV forces (which = 1)
-int multi_aux_halo(ucg_ctx *ctx, ucg_pair *p, int which)
+int multi_aux_halo(ucg_ctx *ctx, ucg_pair *p, int which, LocalStatus &st)
 {
   CommState &C = *ctx->comm;
   const size_t w = (size_t) C.world;
@@ -343,30 +351,36 @@ int multi_aux_halo(ucg_ctx *ctx, ucg_pair *p, int which)
   C.auxsend.reserve((size_t) C.nsend * 16 + 16);
   C.auxrecv.reserve((size_t) C.nrecv * 16 + 16);
   void *field = ucg_pair_density_buffer(p, which);
-  UCG_RC(ucg_halo_aux_pack(ctx, field, C.auxsend.get()));
+  st.run(ctx, [&] { return field ? ucg_halo_aux_pack(ctx, field, C.auxsend.get()) : (int) UCG_ERR_INVALID; });
   alltoallv(ctx, C.auxsend.get(), sb.data(), C.auxrecv.get(), rb.data());
-  UCG_RC(ucg_halo_aux_unpack(ctx, field, C.auxrecv.get()));
+  st.run(ctx, [&] { return ucg_halo_aux_unpack(ctx, field, C.auxrecv.get()); });
   return UCG_OK;
 }
 
-int multi_pair_compute(ucg_ctx *ctx, int ev)
+int multi_pair_compute(ucg_ctx *ctx, int ev, LocalStatus *ls = nullptr)
 {
   ucg_pair *p = ctx->md_pair;
   double e = 0.0, vir[6] = {0, 0, 0, 0, 0, 0};
+  LocalStatus own;
+  LocalStatus &st = ls ? *ls : own;
   if (p->model.style != STYLE_BETHE_DENSITY) {
-    UCG_RC(ucg_pair_compute(p, ev, ev, ev ? &e : nullptr, ev ? vir : nullptr));
+    st.run(ctx, [&] { return ucg_pair_compute(p, ev, ev, ev ? &e : nullptr, ev ? vir : nullptr); });
   } else {
     // table_ucg_bethe_density: its two mid-compute halos cross ranks
-    UCG_RC(ucg_pair_density_phase(p, 1, ev, ev, nullptr, nullptr));
-    UCG_RC(multi_aux_halo(ctx, p, 0));
-    UCG_RC(ucg_pair_density_phase(p, 2, ev, ev, nullptr, nullptr));
-    UCG_RC(multi_aux_halo(ctx, p, 1));
-    UCG_RC(ucg_pair_density_phase(p, 3, ev, ev, ev ? &e : nullptr, ev ? vir : nullptr));
+    st.run(ctx, [&] { return ucg_pair_density_phase(p, 1, ev, ev, nullptr, nullptr); });
+    multi_aux_halo(ctx, p, 0, st);
+    st.run(ctx, [&] { return ucg_pair_density_phase(p, 2, ev, ev, nullptr, nullptr); });
+    multi_aux_halo(ctx, p, 1, st);
+    st.run(ctx, [&] { return ucg_pair_density_phase(p, 3, ev, ev, ev ? &e : nullptr, ev ? vir : nullptr); });
   }
   if (ev) {  // thermo output: one all-reduce of {E_pair, virial[6]}; each rank keeps the totals
     double t[7] = {e, vir[0], vir[1], vir[2], vir[3], vir[4], vir[5]};
     allreduce_f64(ctx, t, 7, 0);
     for (int c = 0; c < 7; c++) ctx->thermo[c] = t[c];
+  }
+  if (!ls && own.bad != UCG_OK) {
+    ctx->err = own.msg;
+    return own.bad;
   }
   return UCG_OK;
 }
@@ -436,14 +450,15 @@ int guarded_comm(ucg_ctx *ctx, F &&fn)
   }
 }
 
-int poll_pair_errors(ucg_ctx *ctx)
+int poll_pair_errors(ucg_ctx *ctx, LocalStatus *ls = nullptr)
 {
-  // the sticky table-range flag of the pair kernels; every rank must take the same decision
-  int rc = ucg_pair_check_errors(ctx->md_pair);
+  // the sticky table-range flag of the pair kernels and any pending rank-local failure; every rank takes the same decision
+  int rc = (ls && ls->bad != UCG_OK) ? ls->bad : ucg_pair_check_errors(ctx->md_pair);
+  if (ls && ls->bad != UCG_OK) ctx->err = ls->msg;
   long long worst = rc;
   allreduce_ll(ctx, &worst, 1, 1);
   if (rc == UCG_OK && worst != 0) {
-    ctx->err = "another rank reported a pair-table range error";
+    ctx->err = "another rank reported an error (a pair-table range error or a failed call; every rank stops, the job must be aborted)";
     return (int) worst;
   }
   return rc;
@@ -485,27 +500,40 @@ int md_run_multi(ucg_ctx *ctx, long long nsteps, int thermo_every)
     ucg_pair *p = ctx->md_pair;
     const bool density = p->model.style == STYLE_BETHE_DENSITY;
     bool initial_done = false;
+    // a rank-local failure inside a step is held (`ls`) and this rank goes on taking part in the collectives until the
+    // next status agreement -- the re-neighbour decision's all-reduce, an error poll, the re-neighbouring itself -- where
+    // every rank returns together; nothing local runs on this rank after the failure
+    LocalStatus ls;
+    // test aid (tests/test_multi_rank.py): UCG_FAULT_INJECT="<rank> <timestep>" makes that rank fail locally at that step
+    int fault_rank = -1;
+    long long fault_step = -1;
+    if (const char *fi = getenv("UCG_FAULT_INJECT")) {
+      if (sscanf(fi, "%d %lld", &fault_rank, &fault_step) != 2) fault_rank = -1;
+    }
     for (long long s = 0; s < nsteps; s++) {
       ctx->ntimestep++;
+      if (fault_rank == ctx->comm->rank && fault_step == ctx->ntimestep && ls.bad == UCG_OK) {
+        ls.bad = UCG_ERR_INVALID;
+        ls.msg = "injected rank-local failure (UCG_FAULT_INJECT)";
+      }
       const int ev = (thermo_every > 0 && (ctx->ntimestep % thermo_every == 0)) ? 1 : 0;
       if (ctx->md_nve && !initial_done)
-        UCG_RC(ctx->md_nve == 2 ? ucg_fix_nve_wall_hard_initial(ctx, ctx->groupbit) : ucg_fix_nve_initial(ctx, ctx->groupbit));
+        ls.run(ctx, [&] { return ctx->md_nve == 2 ? ucg_fix_nve_wall_hard_initial(ctx, ctx->groupbit) : ucg_fix_nve_initial(ctx, ctx->groupbit); });
       int due = 0, flag = 0;
-      UCG_RC(ucg_decide_local(ctx, &due, &flag));
+      UCG_RC(ucg_decide_local(ctx, &due, &flag));  // (the schedule must stay in step on every rank: a failure here is fatal)
       const bool fuse_next = ctx->md_nve && !ev && (s + 1 < nsteps) && !ctx->md_no_fuse;
       bool rebuilt = false;
       if (due) {  // Neighbor::decide(): MPI_Allreduce of the flag -- and of the ranks' status since the last agreement
-        long long f[2] = {flag, pending};
+        long long f[2] = {flag, ls.bad};
         allreduce_ll(ctx, f, 2, 1);
         if (f[1] != UCG_OK) {
-          if (pending == UCG_OK) ctx->err = "another rank failed in the step loop (every rank stops; the job must be aborted)";
-          else ctx->err = pending_msg;
+          ctx->err = ls.bad != UCG_OK ? ls.msg : std::string("another rank failed in the step loop (every rank stops; the job must be aborted)");
           return (int) f[1];
         }
         rebuilt = f[0] != 0;
       }
       if (rebuilt) {
-        UCG_RC(poll_pair_errors(ctx));  // the stream is drained here anyway: check the steps since the last rebuild
+        UCG_RC(poll_pair_errors(ctx, &ls));  // the stream is drained here anyway: check the steps since the last rebuild
         UCG_RC(multi_rebuild(ctx));
         if (ctx->cs) {
           int forced = 0, switching = 0;
@@ -513,24 +541,29 @@ int md_run_multi(ucg_ctx *ctx, long long nsteps, int thermo_every)
           if (switching) UCG_RC(multi_cluster_step(ctx));
         }
       } else {
-        UCG_RC(multi_halo_forward(ctx));
+        multi_halo_forward(ctx, &ls);
       }
       // pair force, then langevin -> ucgstate -> final_integrate (-> next initial_integrate): one launch (the gather
       // kernel's epilogue) where that applies, else two
-      int rc = (fuse_next && !density) ? ucg_md_pair_post(ctx, p, ctx->md_lang, ctx->md_ucgst, ctx->md_nve, ctx->groupbit,
-                                                          ctx->ntimestep, ctx->beginstep, ctx->endstep)
-                                       : UCG_ERR_UNSUPPORTED;
-      if (rc == UCG_ERR_UNSUPPORTED) {
-        UCG_RC(multi_pair_compute(ctx, ev));
-        rc = ucg_md_post_fused(ctx, ctx->md_lang, ctx->md_ucgst, ctx->md_nve, fuse_next, ctx->groupbit, ctx->ntimestep,
-                               ctx->beginstep, ctx->endstep);
+      int rc = UCG_ERR_UNSUPPORTED;
+      if (fuse_next && !density && ls.bad == UCG_OK) {
+        rc = ucg_md_pair_post(ctx, p, ctx->md_lang, ctx->md_ucgst, ctx->md_nve, ctx->groupbit, ctx->ntimestep, ctx->beginstep,
+                              ctx->endstep);
+        if (rc != UCG_OK && rc != UCG_ERR_UNSUPPORTED) {
+          ls.bad = rc;
+          ls.msg = ctx->err;
+        }
       }
-      if (rc) return rc;
+      if (rc == UCG_ERR_UNSUPPORTED) {
+        multi_pair_compute(ctx, ev, &ls);
+        ls.run(ctx, [&] { return ucg_md_post_fused(ctx, ctx->md_lang, ctx->md_ucgst, ctx->md_nve, fuse_next, ctx->groupbit, ctx->ntimestep,
+                                                   ctx->beginstep, ctx->endstep); });
+      }
       initial_done = fuse_next;
-      if (ev && ctx->md_lang) UCG_RC(ucg_fix_langevin_end_of_step(ctx, ctx->groupbit, nullptr));
-      if (ev) UCG_RC(poll_pair_errors(ctx));
+      if (ev && ctx->md_lang) ls.run(ctx, [&] { return ucg_fix_langevin_end_of_step(ctx, ctx->groupbit, nullptr); });
+      if (ev) UCG_RC(poll_pair_errors(ctx, &ls));
     }
-    return poll_pair_errors(ctx);
+    return poll_pair_errors(ctx, &ls);
   });
 }
 

@@ -78,6 +78,31 @@ def main():
                       nrebuild=sim.nrebuild)
         pair.close()
         ctx.close()
+    elif mode == "gpu_fault":
+        # a rank-local failure in the step loop (injected on rank 1 at step 7): BOTH ranks must come back from ucg_md_run
+        # with an error -- the failing one with its own message, the other told that a peer failed -- instead of one of
+        # them blocking in a receive
+        capi = pkg.capi
+        deck = util.make_deck("spline", 1024)
+        ctx = capi.Context(0, dt=0.004)
+        sl = slice(rank * beads.n // world, (rank + 1) * beads.n // world)
+        n = sl.stop - sl.start
+        ctx.atoms_upload(n, 0, beads.ntypes, beads.x[sl], beads.v[sl], beads.type[sl], beads.tag[sl], beads.mask[sl],
+                         beads.ucgstate[sl], beads.ucgl[sl], beads.ucgvl[sl], beads.ucgml[sl], beads.ucgp[sl], beads.mass)
+        ctx.domain_set(beads.boxlo, beads.boxhi, 2.5, 0.3, every=2, delay=0, check=1)
+        pair = util.gpu_pair(ctx, "table_ucgld", deck)
+        tr = multi.Transport(dist, torch.device("cuda", 0), staged=True)
+        sim = multi.RankSim(ctx, pair, tr, grid, use_langevin=False, use_ucgstate=False)
+        sim.setup(40)
+        os.environ["UCG_FAULT_INJECT"] = "1 7"
+        code, msg = 0, ""
+        try:
+            sim.run(40)
+        except capi.UcgError as e:
+            code, msg = e.code, e.msg
+        result = dict(code=code, msg=msg, ntimestep=ctx.md_info()["ntimestep"])
+        pair.close()
+        ctx.close()
     elif mode == "gpu_cluster":
         # fix cluster_switch on a decomposed run: labels must equal the single-rank ones; then a short run
         capi = pkg.capi

@@ -253,6 +253,17 @@ def test_world2_thermostatted_run_is_reproducible(pkg, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_a_rank_local_failure_stops_every_rank_together(pkg):
+    """a failure on one rank between two collectives must not leave its peer blocked in a receive.  The
+    failing rank keeps taking part in the halo until the next status agreement (the re-neighbour decision's all-reduce,
+    here at the next even step), where both ranks return an error from ucg_md_run"""
+    res = _launch("gpu_fault", world=2, timeout=240)
+    assert res[1]["code"] == 1 and "injected" in res[1]["msg"]
+    assert res[0]["code"] != 0 and "another rank failed" in res[0]["msg"]
+    assert res[0]["ntimestep"] == res[1]["ntimestep"] == 8  # injected at step 7, agreed at the decision of step 8
+
+
+@pytest.mark.gpu
 def test_world2_thermostatted_run_equals_the_decomposed_oracle_bit_for_bit(pkg, orc):
     """fix ucgld/langevin + fix ucgstate mc + fix nve/ucgld/wall/hard on two ranks against the oracle's statement of the
     same decomposed run (oracle/orc_md.c: orc_world -- bricks, per-rank bead order, RanMars(seed + me) streams drawn in
