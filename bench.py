@@ -631,17 +631,19 @@ def main():
 
 
 def load_pmc_stamp(args, world, cs):
-    """profiles/r02_pmc_<style>.json: {"commit", "kernel", "workload", "traffic_bytes_per_launch", "valu_insts_per_launch", "note"}"""
+    """profiles/rNN_pmc_<style>.json (the newest round): {"commit", "kernel", "workload", "traffic_bytes_per_launch", "valu_insts_per_launch", "note"}"""
     if world != 1 or cs or args.tabstyle != "spline" or args.tablength != 1024 or args.lattice != "sc" or args.ncell != 100:
         return None
-    path = os.path.join(ROOT, "profiles", f"r02_pmc_{args.style}.json")
-    if not os.path.exists(path):
+    import glob
+    stamps = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_pmc_{args.style}.json")))  # named per round: the newest
+    if not stamps:
         return None
+    path = stamps[-1]
     with open(path) as fh:
         d = json.load(fh)
     if d.get("workload") != f"{args.style} {args.tabstyle} {args.tablength} sc {args.ncell}":
         return None
-    d["note"] = (f"rocprofv3 PMC of kernel {d.get('kernel')} at commit {d.get('commit')} (profiles/r02_pmc_{args.style}.json): "
+    d["note"] = (f"rocprofv3 PMC of kernel {d.get('kernel')} at commit {d.get('commit')} (profiles/{os.path.basename(path)}): "
                  "FETCH_SIZE x2 per the gfx950 calibration + WRITE_SIZE; SQ_INSTS_VALU")
     return d
 
