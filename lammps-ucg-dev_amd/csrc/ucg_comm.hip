@@ -138,13 +138,34 @@ void alltoallv(ucg_ctx *ctx, const void *send, const long long *sendbytes, void 
     cb_check(C.ops.alltoallv(C.ops.user, send, sendbytes, recv, recvbytes, (void *) ctx->stream), "alltoallv");
     return;
   }
-  nccl_check(g_rccl.GroupStart(), "ncclGroupStart");
+  // the block a rank sends to itself (its own periodic images: every grid with a dimension of one rank) never leaves the
+  // device: a plain copy on the stream instead of an ncclSend / ncclRecv pair to self
+  // (UCG_RCCL_SELF_SEND=1 keeps the self block on RCCL: the one-rank tests run the grouped send / receive path that way)
+  const char *selfenv = getenv("UCG_RCCL_SELF_SEND");
+  const bool self_copy = !(selfenv && selfenv[0] == '1');
   long long so = 0, ro = 0;
+  bool peers = false;
   for (int r = 0; r < C.world; r++) {
-    if (sendbytes[r] > 0)
-      nccl_check(g_rccl.Send((const char *) send + so, (size_t) sendbytes[r], NCCL_CHAR, r, C.nccl, ctx->stream), "ncclSend");
-    if (recvbytes[r] > 0)
-      nccl_check(g_rccl.Recv((char *) recv + ro, (size_t) recvbytes[r], NCCL_CHAR, r, C.nccl, ctx->stream), "ncclRecv");
+    if (r == C.rank && self_copy) {
+      if (sendbytes[r] != recvbytes[r]) throw CommFailure{"alltoallv: a rank's block to itself has two sizes"};
+      if (sendbytes[r] > 0)
+        UCG_HIP(hipMemcpyAsync((char *) recv + ro, (const char *) send + so, (size_t) sendbytes[r], hipMemcpyDeviceToDevice, ctx->stream));
+    } else if (sendbytes[r] > 0 || recvbytes[r] > 0) {
+      peers = true;
+    }
+    so += sendbytes[r];
+    ro += recvbytes[r];
+  }
+  if (!peers) return;
+  nccl_check(g_rccl.GroupStart(), "ncclGroupStart");
+  so = ro = 0;
+  for (int r = 0; r < C.world; r++) {
+    if (r != C.rank || !self_copy) {
+      if (sendbytes[r] > 0)
+        nccl_check(g_rccl.Send((const char *) send + so, (size_t) sendbytes[r], NCCL_CHAR, r, C.nccl, ctx->stream), "ncclSend");
+      if (recvbytes[r] > 0)
+        nccl_check(g_rccl.Recv((char *) recv + ro, (size_t) recvbytes[r], NCCL_CHAR, r, C.nccl, ctx->stream), "ncclRecv");
+    }
     so += sendbytes[r];
     ro += recvbytes[r];
   }

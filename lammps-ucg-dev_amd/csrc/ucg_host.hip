@@ -168,6 +168,12 @@ int ucg_host_bind(ucg_ctx *ctx, double *x, double *v, double *f, int *ucgstate, 
     ctx->err = "ucg_host_bind: give all ten arrays, or none to unbind";
     return UCG_ERR_INVALID;
   }
+  if (any && (ctx->comm || ctx->dom_world > 1)) {
+    // a decomposed run of the library migrates beads between ranks on the device: the bead count behind the caller's
+    // arrays would change under them.  (Under MPI the LAMMPS glue stays in copy mode.)
+    ctx->err = "ucg_host_bind: host mirrors are for single-rank contexts";
+    return UCG_ERR_UNSUPPORTED;
+  }
   const bool was = M.bound;
   M.bound = any;
   M.x = x; M.v = v; M.f = f; M.state = ucgstate; M.nstates = num_ucgstates;

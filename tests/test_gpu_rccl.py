@@ -108,8 +108,12 @@ def _same_bits(a, b, keys=("x", "v", "f", "ucgl", "ucgvl", "ucgforce", "scores",
         assert util.bits_equal(a[k], b[k]), k
 
 
+@pytest.mark.parametrize("self_send", ["1", "0"])
 @pytest.mark.parametrize("case", ["ucgld", "density", "cluster"])
-def test_one_rank_on_rccl_equals_the_callback_transport_and_the_oracle(pkg, orc, case):
+def test_one_rank_on_rccl_equals_the_callback_transport_and_the_oracle(pkg, orc, case, self_send, monkeypatch):
+    # "1": the block a rank sends to itself goes through ncclSend / ncclRecv like a peer's (the grouped path every
+    # multi-rank run takes); "0", the default: it is a device copy and only counts and reductions use RCCL
+    monkeypatch.setenv("UCG_RCCL_SELF_SEND", self_send)
     steps, every = 40, 2
     if case == "ucgld":
         dt = 0.004
