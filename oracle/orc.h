@@ -188,6 +188,20 @@ int orc_pair_compute_gather(orc_pair *p, orc_atoms *a, const orc_list *l, int ef
 
 /* table_ucg_bethe_density (orc_density.c): mode 0 = sequential sweep with scatter (the
  * reference's loop shape), 1 = canonical gather; ghost_src[g] = owned index ghost g images */
+/* the same in three calls on shared work arrays [nall][2] (fpart [nall][3]): a decomposed run moves the ghosts' entries of
+ * prior / partial (after pass 1) and cv (after pass 2) between ranks itself */
+typedef struct {
+  int nall;
+  double *prior, *partial, *G, *S, *cv, *fpart;
+} orc_density_work;
+orc_density_work *orc_density_work_create(int nall);
+void orc_density_work_destroy(orc_density_work *w);
+int orc_pair_density_check(orc_pair *p, const orc_atoms *a);
+void orc_pair_density_pass1(orc_pair *p, orc_atoms *a, const orc_list *l, orc_density_work *w);
+void orc_pair_density_pass2(orc_pair *p, orc_atoms *a, const orc_list *l, int mode, int eflag, int vflag, orc_density_work *w,
+                            orc_ev *ev);
+void orc_pair_density_pass3(orc_pair *p, orc_atoms *a, const orc_list *l, int mode, int vflag, const int *ghost_src,
+                            orc_density_work *w, orc_ev *ev);
 int orc_pair_density_compute(orc_pair *p, orc_atoms *a, const orc_list *l, int mode, int eflag,
                              int vflag, const int *ghost_src, orc_ev *ev);
 

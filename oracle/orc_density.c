@@ -184,15 +184,34 @@ static void dclosure(const orc_pair *p, const dquad *q, double pi1, double pj1, 
   *p01 = pj1 - *p11;
 }
 
-int orc_pair_density_compute(orc_pair *p, orc_atoms *a, const orc_list *l, int mode, int eflag, int vflag,
-                             const int *ghost_src, orc_ev *ev)
+/* The three passes as separate calls on shared work arrays, so that a decomposed run (orc_md.c: orc_world) can move the
+ * ghosts' priors (after pass 1) and CV forces (after pass 2) between ranks -- the forward_comm the reference declares and
+ * never performs (UCG/pair_table_ucg_bethe_density.cpp:280, App. B #7).  orc_pair_density_compute below is the single-rank
+ * composition: pass 1, ghosts <- owners, pass 2, ghosts <- owners, pass 3. */
+orc_density_work *orc_density_work_create(int nall)
 {
-  const int nt = p->n_formal + 1, ms = p->max_states;
-  const int nlocal = a->nlocal, nall = a->nlocal + a->nghost;
-  const double kT = p->kT;
-  const double *x = a->x;
-  double *f = a->f;
-  memset(ev, 0, sizeof(*ev));
+  orc_density_work *w = (orc_density_work *) calloc(1, sizeof(orc_density_work));
+  const size_t n = (size_t) (nall > 0 ? nall : 1);
+  w->nall = nall;
+  w->prior = (double *) calloc(n * 2, sizeof(double));
+  w->partial = (double *) calloc(n * 2, sizeof(double));
+  w->G = (double *) calloc(n * 2, sizeof(double));
+  w->S = (double *) calloc(n * 2, sizeof(double));
+  w->cv = (double *) calloc(n * 2, sizeof(double));
+  w->fpart = (double *) calloc(n * 3, sizeof(double)); /* mode 0 scatter target incl. ghosts */
+  return w;
+}
+
+void orc_density_work_destroy(orc_density_work *w)
+{
+  if (!w) return;
+  free(w->prior); free(w->partial); free(w->G); free(w->S); free(w->cv); free(w->fpart);
+  free(w);
+}
+
+int orc_pair_density_check(orc_pair *p, const orc_atoms *a)
+{
+  const int nall = a->nlocal + a->nghost;
   if (p->style != ORC_STYLE_BETHE_DENSITY) {
     strcpy(p->errmsg, "orc_pair_density_compute needs style table_ucg_bethe_density");
     return 1;
@@ -204,12 +223,19 @@ int orc_pair_density_compute(orc_pair *p, orc_atoms *a, const orc_list *l, int m
       return 1;
     }
   }
-  double *prior = (double *) calloc((size_t) nall * 2, sizeof(double));
-  double *partial = (double *) calloc((size_t) nall * 2, sizeof(double));
-  double *G = (double *) calloc((size_t) nall * 2, sizeof(double));
-  double *S = (double *) calloc((size_t) nall * 2, sizeof(double));
-  double *cv = (double *) calloc((size_t) nall * 2, sizeof(double));
+  return 0;
+}
 
+void orc_pair_density_pass1(orc_pair *p, orc_atoms *a, const orc_list *l, orc_density_work *w)
+{
+  const int nt = p->n_formal + 1, ms = p->max_states;
+  const int nlocal = a->nlocal, nall = a->nlocal + a->nghost;
+  const double kT = p->kT;
+  const double *x = a->x;
+  double *f = a->f;
+  double *prior = w->prior, *partial = w->partial, *G = w->G, *S = w->S, *cv = w->cv, *fpart = w->fpart;
+  (void) nt; (void) ms; (void) nlocal; (void) nall; (void) kT; (void) x; (void) f;
+  (void) prior; (void) partial; (void) G; (void) S; (void) cv; (void) fpart;
   /* ---- pass 1 */
   for (int ii = 0; ii < l->inum; ii++) {
     const int i = l->ilist[ii];
@@ -239,17 +265,20 @@ int orc_pair_density_compute(orc_pair *p, orc_atoms *a, const orc_list *l, int m
       for (int si = 0; si < 2; si++) prior[2 * i + si] /= den;
     }
   }
-  /* forward communication of the priors (fix of App. B #7) */
-  for (int g = 0; g < a->nghost; g++) {
-    const int src = ghost_src[g];
-    prior[2 * (nlocal + g)] = prior[2 * src];
-    prior[2 * (nlocal + g) + 1] = prior[2 * src + 1];
-    partial[2 * (nlocal + g)] = partial[2 * src];
-    partial[2 * (nlocal + g) + 1] = partial[2 * src + 1];
-  }
+}
 
+void orc_pair_density_pass2(orc_pair *p, orc_atoms *a, const orc_list *l, int mode, int eflag, int vflag, orc_density_work *w,
+                            orc_ev *ev)
+{
+  const int nt = p->n_formal + 1, ms = p->max_states;
+  const int nlocal = a->nlocal, nall = a->nlocal + a->nghost;
+  const double kT = p->kT;
+  const double *x = a->x;
+  double *f = a->f;
+  double *prior = w->prior, *partial = w->partial, *G = w->G, *S = w->S, *cv = w->cv, *fpart = w->fpart;
+  (void) nt; (void) ms; (void) nlocal; (void) nall; (void) kT; (void) x; (void) f;
+  (void) prior; (void) partial; (void) G; (void) S; (void) cv; (void) fpart;
   /* ---- pass 2 */
-  double *fpart = (double *) calloc((size_t) nall * 3, sizeof(double)); /* mode 0 scatter target incl. ghosts */
   for (int ii = 0; ii < l->inum; ii++) {
     const int i = l->ilist[ii];
     const int itype = a->type[i];
@@ -341,11 +370,19 @@ int orc_pair_density_compute(orc_pair *p, orc_atoms *a, const orc_list *l, int m
       cv[2 * i + 1] = G[2 * i + 1] * partial[2 * i + 1];
     }
   }
-  for (int g = 0; g < a->nghost; g++) {
-    cv[2 * (nlocal + g)] = cv[2 * ghost_src[g]];
-    cv[2 * (nlocal + g) + 1] = cv[2 * ghost_src[g] + 1];
-  }
+}
 
+void orc_pair_density_pass3(orc_pair *p, orc_atoms *a, const orc_list *l, int mode, int vflag, const int *ghost_src,
+                            orc_density_work *w, orc_ev *ev)
+{
+  const int nt = p->n_formal + 1, ms = p->max_states;
+  const int nlocal = a->nlocal, nall = a->nlocal + a->nghost;
+  const double kT = p->kT;
+  const double *x = a->x;
+  double *f = a->f;
+  double *prior = w->prior, *partial = w->partial, *G = w->G, *S = w->S, *cv = w->cv, *fpart = w->fpart;
+  (void) nt; (void) ms; (void) nlocal; (void) nall; (void) kT; (void) x; (void) f;
+  (void) prior; (void) partial; (void) G; (void) S; (void) cv; (void) fpart;
   /* ---- pass 3: back-force of the density CV (:698-733) */
   memset(fpart, 0, sizeof(double) * 3 * (size_t) nall);
   for (int ii = 0; ii < l->inum; ii++) {
@@ -418,6 +455,33 @@ int orc_pair_density_compute(orc_pair *p, orc_atoms *a, const orc_list *l, int m
       for (int d = 0; d < 3; d++) f[3 * src + d] += fpart[3 * (nlocal + g) + d];
     }
   }
-  free(prior); free(partial); free(G); free(S); free(cv); free(fpart);
+}
+
+int orc_pair_density_compute(orc_pair *p, orc_atoms *a, const orc_list *l, int mode, int eflag, int vflag,
+                             const int *ghost_src, orc_ev *ev)
+{
+  const int nlocal = a->nlocal, nall = a->nlocal + a->nghost;
+  memset(ev, 0, sizeof(*ev));
+  if (orc_pair_density_check(p, a)) return 1;
+  orc_density_work *w = orc_density_work_create(nall);
+  double *prior = w->prior, *partial = w->partial, *cv = w->cv;
+  orc_pair_density_pass1(p, a, l, w);
+  /* forward communication of the priors (fix of App. B #7) */
+  for (int g = 0; g < a->nghost; g++) {
+    const int src = ghost_src[g];
+    prior[2 * (nlocal + g)] = prior[2 * src];
+    prior[2 * (nlocal + g) + 1] = prior[2 * src + 1];
+    partial[2 * (nlocal + g)] = partial[2 * src];
+    partial[2 * (nlocal + g) + 1] = partial[2 * src + 1];
+  }
+
+  orc_pair_density_pass2(p, a, l, mode, eflag, vflag, w, ev);
+  for (int g = 0; g < a->nghost; g++) {
+    cv[2 * (nlocal + g)] = cv[2 * ghost_src[g]];
+    cv[2 * (nlocal + g) + 1] = cv[2 * ghost_src[g] + 1];
+  }
+
+  orc_pair_density_pass3(p, a, l, mode, vflag, ghost_src, w, ev);
+  orc_density_work_destroy(w);
   return ev->err ? 2 : 0;
 }

@@ -889,13 +889,66 @@ static void world_rebuild(orc_world *w)
   }
 }
 
+/* ghosts take two doubles per bead from their owners (the density style's priors + their derivatives, then its CV forces) */
+static void world_forward2(orc_world *w, double **field)
+{
+  for (int me = 0; me < w->nranks; me++) {
+    const orc_sim *s = w->r[me];
+    const int n = s->a.nlocal;
+    for (int g = 0; g < s->a.nghost; g++) {
+      const double *o = field[s->ghost_rank[g]];
+      const int src = s->ghost_src[g];
+      field[me][2 * (n + g)] = o[2 * src];
+      field[me][2 * (n + g) + 1] = o[2 * src + 1];
+    }
+  }
+}
+
 static int world_forces(orc_world *w, int ev)
 {
   int rc_any = 0;
   for (int c = 0; c < 7; c++) w->ev[c] = 0.0;
+  if (w->r[0]->pair->style == ORC_STYLE_BETHE_DENSITY) {
+    /* table_ucg_bethe_density: the three passes in lockstep; between them the ghosts' priors (and their derivatives) and
+       CV forces come from the owner RANKS -- the forward_comm of UCG/pair_table_ucg_bethe_density.cpp:280 (App. B #7) */
+    orc_density_work **wk = (orc_density_work **) calloc((size_t) w->nranks, sizeof(orc_density_work *));
+    double **fld = (double **) calloc((size_t) w->nranks, sizeof(double *));
+    for (int me = 0; me < w->nranks; me++) {
+      orc_sim *s = w->r[me];
+      if (orc_pair_density_check(s->pair, &s->a)) rc_any = 1;
+      orc_force_clear(&s->a, 0);
+      memset(&s->ev, 0, sizeof(s->ev));
+      wk[me] = orc_density_work_create(s->a.nlocal + s->a.nghost);
+    }
+    if (!rc_any) {
+      for (int me = 0; me < w->nranks; me++) orc_pair_density_pass1(w->r[me]->pair, &w->r[me]->a, &w->r[me]->full, wk[me]);
+      for (int me = 0; me < w->nranks; me++) fld[me] = wk[me]->prior;
+      world_forward2(w, fld);
+      for (int me = 0; me < w->nranks; me++) fld[me] = wk[me]->partial;
+      world_forward2(w, fld);
+      for (int me = 0; me < w->nranks; me++)
+        orc_pair_density_pass2(w->r[me]->pair, &w->r[me]->a, &w->r[me]->full, 1, ev, ev, wk[me], &w->r[me]->ev);
+      for (int me = 0; me < w->nranks; me++) fld[me] = wk[me]->cv;
+      world_forward2(w, fld);
+      for (int me = 0; me < w->nranks; me++)
+        orc_pair_density_pass3(w->r[me]->pair, &w->r[me]->a, &w->r[me]->full, 1, ev, NULL, wk[me], &w->r[me]->ev);
+    }
+    for (int me = 0; me < w->nranks; me++) {
+      orc_sim *s = w->r[me];
+      if (s->ev.err) {
+        rc_any = 2;
+        s->pair_errors++;
+      }
+      w->ev[0] += s->ev.eng_vdwl;
+      for (int c = 0; c < 6; c++) w->ev[1 + c] += s->ev.virial[c];
+      orc_density_work_destroy(wk[me]);
+    }
+    free(wk);
+    free(fld);
+    return rc_any;
+  }
   for (int me = 0; me < w->nranks; me++) {
     orc_sim *s = w->r[me];
-    if (s->pair->style == ORC_STYLE_BETHE_DENSITY) return 99; /* its mid-compute halos cross ranks: not stated here */
     s->mode = 1;
     const int rc = compute_forces(s, ev, ev);
     if (rc) rc_any = rc;

@@ -87,8 +87,8 @@ int orc_sim_compute_forces(orc_sim *s, int eflag, int vflag);
  *   canonical gather order); Neighbor::decide is the MAX of the ranks' flags (upstream MPI_Allreduce);
  *   the random streams are per rank: RanMars(seed + me) drawn in the rank's local bead order
  *   (UCG/fix_ucgld_langevin.cpp:85, 280; UCG/fix_ucgstate.cpp:62, 117).
- * Gather styles (table_ucgld, table_ucg_bethe) in canonical order; fix cluster_switch and the density style's
- * mid-compute halos are not covered here. */
+ * All three pair styles in canonical order (the density style's passes run in lockstep over the ranks, its ghosts' priors
+ * and CV forces coming from their owner ranks); fix cluster_switch's reductions are not covered here. */
 typedef struct orc_world orc_world;
 orc_world *orc_world_create(const int *grid3, int natoms, const double *boxlo, const double *boxhi, double cutforce,
                             double skin, int ntypes);

@@ -320,6 +320,30 @@ def test_decomposed_forces_and_trajectory_equal_the_decomposed_oracle_bit_for_bi
 
 
 @pytest.mark.gpu
+def test_world2_density_style_equals_the_decomposed_oracle_bit_for_bit(pkg, orc):
+    """table_ucg_bethe_density on two ranks -- its two mid-compute halos carry the ghosts' priors and CV forces between the
+    ranks -- against orc_world's lockstep passes: forces and posteriors of every rank at setup, positions after 40 steps"""
+    res = _launch("gpu_density")
+    deck = util.make_deck("spline", 1024, density=(11.3, 1.5), extra11=0.05)
+    beads = pkg.synth.make_beads(10, seed=5)
+    op = util.oracle_pair("table_ucg_bethe_density", deck)
+    w = orc.World(beads, [2, 1, 1])
+    w.set_run_params(dt=0.002, every=2, delay=0, check=1)
+    w.attach(op, langevin=None, nve=True, ucgstate=None)
+    assert w.setup(40) == 0
+    for r in range(2):
+        O, G = w.rank_arrays(r), res[r]
+        assert np.array_equal(G["tag0"], O["tag"])
+        assert util.bits_equal(G["f0"], O["f"]) and util.bits_equal(G["p0"], O["ucgp"])
+    assert abs(res[0]["e0"] - w.ev()["eng_vdwl"]) <= 1e-12 * abs(res[0]["e0"])
+    assert w.run(40, 40) == 0
+    for r in range(2):
+        O, G = w.rank_arrays(r), res[r]
+        assert np.array_equal(G["tag1"], O["tag"]) and util.bits_equal(G["x1"], O["x"])
+        assert G["nrebuild"] == w.rank_info(r)["nrebuild"]
+
+
+@pytest.mark.gpu
 def test_world2_config5_density_with_cluster_switch_vs_oracle(pkg, orc):
     """BASELINE.json config 5 in small (table_ucg_bethe_density + fix ucgstate mc + fix cluster_switch on two actual atom
     types), two ranks, against the ORACLE's single-rank run of the same beads: forces, posteriors and states at setup by

@@ -22,11 +22,14 @@ def _world(orc, beads, deck, grid, style="table_ucgld", dt=0.004, every=2, lang=
     return w, op
 
 
-def test_one_brick_is_the_single_rank_oracle_bit_for_bit(orc, pkg):
-    deck = util.make_deck("spline", 1024)
+@pytest.mark.parametrize("style", ["table_ucgld", "table_ucg_bethe", "table_ucg_bethe_density"])
+def test_one_brick_is_the_single_rank_oracle_bit_for_bit(orc, pkg, style):
+    dens = dict(density=(11.3, 1.5), extra11=0.05) if style.endswith("density") else {}
+    deck = util.make_deck("spline", 1024, **dens)
     beads = pkg.synth.make_beads(7, seed=5)
-    w, op = _world(orc, beads, deck, [1, 1, 1])
-    sim = util.oracle_sim(beads, op, mode=1, dt=0.004, langevin=(1.0, 1.0, 1.0, 48279), nve="wall", ucgstate=("mc", 9127, 0.3), every=2)
+    lang = (1.0, 1.0, 1.0, 48279) if style == "table_ucgld" else None
+    w, op = _world(orc, beads, deck, [1, 1, 1], style=style, lang=lang)
+    sim = util.oracle_sim(beads, op, mode=1, dt=0.004, langevin=lang, nve="wall", ucgstate=("mc", 9127, 0.3), every=2)
     assert w.setup(60) == 0 and sim.setup(60) == 0
     assert w.run(60, 30) == 0 and sim.run(60, 30) == 0
     A, B = w.rank_arrays(0, ghosts=True), sim.arrays(ghosts=True)
@@ -69,6 +72,32 @@ def test_bricks_partition_the_beads_and_reproduce_the_single_rank_physics(orc, p
     d -= np.round(d / beads.boxhi) * beads.boxhi
     assert np.abs(d).max() < 1e-9
     assert all(w.rank_info(r)["nrebuild"] == sim.info()["nrebuild"] for r in range(w.nranks))
+
+
+def test_density_style_on_bricks_takes_its_ghosts_priors_from_the_owner_ranks(orc, pkg):
+    """table_ucg_bethe_density decomposed: the priors (after pass 1) and CV forces (after pass 2) of ghosts come from the ranks
+    that own them; forces and posteriors agree with the single-rank oracle to rounding, momentum is conserved"""
+    deck = util.make_deck("spline", 1024, density=(11.3, 1.5), extra11=0.05)
+    beads = pkg.synth.make_beads(10, seed=5)
+    n = beads.n
+    w, op = _world(orc, beads, deck, [2, 2, 1], style="table_ucg_bethe_density", dt=0.002, lang=None, ust=None, nve=True)
+    sim = util.oracle_sim(beads, op, mode=1, dt=0.002, nve=True, every=2)
+    assert w.setup(20) == 0 and sim.setup(20) == 0
+    R = [w.rank_arrays(r) for r in range(4)]
+    tags = np.concatenate([a["tag"] for a in R])
+    S = sim.arrays()
+    for k, tol in (("f", 1e-10), ("ucgp", 1e-12)):
+        multi, ref = _by_tag(n, tags, np.concatenate([a[k] for a in R])), _by_tag(n, S["tag"], S[k])
+        assert np.abs(multi - ref).max() <= tol * np.abs(ref).max(), k
+    f = np.concatenate([a["f"] for a in R])
+    assert np.abs(f.sum(axis=0)).max() < 1e-9 * np.abs(f).max() * n
+    assert abs(w.ev()["eng_vdwl"] - sim.ev()["eng_vdwl"]) <= 1e-11 * abs(sim.ev()["eng_vdwl"])
+    assert w.run(20, 20) == 0 and sim.run(20, 20) == 0
+    R = [w.rank_arrays(r) for r in range(4)]
+    tags = np.concatenate([a["tag"] for a in R])
+    d = _by_tag(n, tags, np.concatenate([a["x"] for a in R])) - _by_tag(n, sim.arrays()["tag"], sim.arrays()["x"])
+    d -= np.round(d / beads.boxhi) * beads.boxhi
+    assert np.abs(d).max() < 1e-9
 
 
 def test_thermostatted_decomposed_run_migrates_beads_and_is_reproducible(orc, pkg):
