@@ -290,7 +290,7 @@ def apply_env_options(ctx):
     ctx.set_option("gather_slots", int(os.environ.get("UCG_GATHER_SLOTS", "0")))
     if os.environ.get("UCG_FMA_CONTRACT"):  # NOT the bit-exact path: see DESIGN.md 4.1; never the default
         ctx.set_option("fma_contract", int(os.environ["UCG_FMA_CONTRACT"]))
-    for env, opt in (("UCG_POST_IN_PAIR", "post_in_pair"), ("UCG_STAGE_OWN", "stage_own"), ("UCG_PAIR_ONCE", "pair_once"),
+    for env, opt in (("UCG_POST_IN_PAIR", "post_in_pair"), ("UCG_STAGE_OWN", "stage_own"), ("UCG_PAIR_VROW", "pair_vrow"),
                      ("UCG_HOT_BLOCK", "hot_block"), ("UCG_GENERIC_KERNELS", "generic_kernels")):
         if os.environ.get(env):
             ctx.set_option(opt, int(os.environ[env]))
@@ -389,7 +389,7 @@ def run_single(args, pkg, capi, deck, beads, cs, local_rank, steps, warmup, inte
     info = ctx.md_info()
     out = dict(elapsed=elapsed, n=beads.n, pair_launches=launches, pair_ms=pair_ms, list_entries=info["list_entries"],
                nghost=info["nghost"], rebuilds=info["nrebuild"] - info0["nrebuild"], maxrow=info["maxrow"],
-               once_beads=info.get("once_beads", 0), lanes_per_bead=pair.gather_slots)
+               virtual_rows=bool(pair.sum_fixed), lanes_per_bead=pair.gather_slots)
     if cs:
         out["cluster_switch_vector"] = [float(v) for v in ctx.fix_cluster_switch_vector()]
     if dropin_steps > 0 and not cs:
@@ -539,7 +539,8 @@ def main():
         "roofline": {
             "bound": "hbm",
             "kernel": ("k_density_pass1+2+3" if args.style == "table_ucg_bethe_density"
-                       else f"k_pair_gather<{args.style}> (with the fused per-bead epilogue)"),
+                       else (f"k_pair_vrow<{args.style}>" if result.get("virtual_rows") else f"k_pair_gather<{args.style}>")
+                       + " (with the fused per-bead epilogue)"),
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -559,11 +560,11 @@ def main():
         out["roofline"]["with_fused_hooks"] = {
             "algorithmic_bytes_per_launch": b172, "frac": b172 / pair_avg_s / 1e9 / HBM_PEAK_GBS if pair_avg_s > 0 else 0.0,
             "note": "44 E + 172 N: the pair loop's bytes minus the 48 B kept in registers plus the 124 B of the fused hooks"}
-    if "once_beads" in result:
-        out["config"]["pair_kernel"] = {"lanes_per_bead": int(result["lanes_per_bead"]),
-                                        "own_block_pairs_once": int(result["once_beads"]),
-                                        "note": "own_block_pairs_once = beads per workgroup whose mutual pairs are evaluated by one "
-                                                "lane only (option pair_once, DESIGN.md 4.1); 0 = every pair from both rows"}
+    if "virtual_rows" in result:
+        out["config"]["pair_kernel"] = {"virtual_rows": bool(result["virtual_rows"]), "lanes_per_bead": int(result["lanes_per_bead"]),
+                                        "note": "virtual_rows: the pairs of two beads of one 512-bead workgroup block are evaluated once, "
+                                                "on balanced virtual rows with order-free fixed sums (ucg_pair_vrow.hip, DESIGN.md 4.1); "
+                                                "false: full-row gather kernel, lanes_per_bead lanes per bead (option pair_vrow 0)"}
     if cs and "cluster_switch_vector" in result:
         out["config"]["cluster_switch_vector"] = result["cluster_switch_vector"]
     if "small_messages" in result:

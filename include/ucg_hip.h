@@ -89,6 +89,10 @@ int ucg_ctx_set_units(ucg_ctx *ctx, double boltz, double ftm2v, double mvv2e, do
  *                   adds them as 2^-40 fixed-point integers (order-independent, so still bit-reproducible: its own
  *                   canonical order).  A term >= 2048 in magnitude sets error bit 4 and
  *                   ucg_pair_check_errors returns UCG_ERR_UNSUPPORTED: rerun without the option.  Off by default.
+ *   "pair_vrow"     (default 1; set before ucg_pair_init) table_ucgld / table_ucg_bethe whose tables fit the LDS (one shared
+ *                   r^2 grid, no BITMAP tables) run on balanced virtual rows: the pairs of two beads of one 512-bead
+ *                   workgroup block are evaluated once, and a bead's terms are summed as fixed sums (ucg_pair_sum_fixed);
+ *                   0 = the full-row gather kernels with ordered double sums for every style
  *   "fma_contract"  = 1 runs the gather kernels compiled with FMA contraction: NOT the bit-exact path (results within
  *                   1e-12), never the default */
 int ucg_ctx_set_option(ucg_ctx *ctx, const char *name, int value);
@@ -133,6 +137,16 @@ int ucg_pair_single(const ucg_pair *p, int itype, int jtype, double rsq, double 
  * default 1).  It is part of the canonical summation order: entry e of a row is added into partial
  * sum e % slots, and the partial sums are combined by the tree s[l] += s[l + slots/2], ..., s[l] += s[l+1]. */
 int ucg_pair_gather_slots(const ucg_pair *p);
+/* How this pair sums a bead's terms (decided at ucg_pair_init; anyone comparing bits needs it):
+ *   0 = ordered double sums: the canonical order above (row order, gather_slots);
+ *   1 = fixed sums (option "pair_vrow" applies): every term of a bead's force components, ucgforce and scores is rounded
+ *       to nearest-even at 2^-38 of a per-field power-of-two unit and the images are added as 64-bit integers, so the
+ *       sum depends on no order -- not on the rows, the lanes, which lane evaluates a pair, or the decomposition.
+ *       Units: 2^-(4 - ilogb(R)) with R = max |f(k)| sqrt(rsq_k) (forces), max |e(k)| (ucgforce), max |e(k)| / kT
+ *       (scores) over the reachable tables' knots in the upper three quarters of the r^2 grid.  bead total = prologue
+ *       value + (double) integer sum * unit * 2^-38.  A term of 2^24 units or more sets an error
+ *       (ucg_pair_check_errors: UCG_ERR_UNSUPPORTED).  The oracle states the same (oracle/orc.h, sum_fixed). */
+int ucg_pair_sum_fixed(const ucg_pair *p);
 /* host copies of the built tables, for inspection: which in
  * {"rsq","e","f","de","df","e2","f2"}; returns the length or <0 */
 int ucg_pair_table_count(const ucg_pair *p);

@@ -33,7 +33,7 @@ SYMBOLS = [
     "ucg_abi_version", "ucg_ctx_create", "ucg_ctx_destroy", "ucg_last_error", "ucg_ctx_set_stream",
     "ucg_ctx_synchronize", "ucg_ctx_set_units", "ucg_ctx_set_option", "ucg_selftest_div", "ucg_selftest_stream",
     "ucg_pair_create", "ucg_pair_create_host", "ucg_pair_last_error", "ucg_pair_destroy", "ucg_pair_settings", "ucg_pair_coeff", "ucg_pair_init",
-    "ucg_pair_cut", "ucg_pair_cutforce", "ucg_pair_gather_slots", "ucg_pair_single", "ucg_pair_table_count",
+    "ucg_pair_cut", "ucg_pair_cutforce", "ucg_pair_gather_slots", "ucg_pair_sum_fixed", "ucg_pair_single", "ucg_pair_table_count",
     "ucg_pair_table_params", "ucg_pair_table_array", "ucg_pair_tabindex", "ucg_pair_compute",
     "ucg_pair_check_errors",
     "ucg_atoms_upload", "ucg_atoms_upload_comm", "ucg_atoms_upload_owned", "ucg_atoms_download", "ucg_atoms_counts", "ucg_ghosts_upload", "ucg_force_clear",
@@ -122,6 +122,7 @@ def lib():
     L.ucg_pair_cut.argtypes = [vp, C.c_int, C.c_int]
     L.ucg_pair_cut.restype = C.c_double
     L.ucg_pair_gather_slots.argtypes = [vp]
+    L.ucg_pair_sum_fixed.argtypes = [vp]
     L.ucg_pair_cutforce.argtypes = [vp]
     L.ucg_pair_cutforce.restype = C.c_double
     L.ucg_pair_single.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_double, c_double_p, c_double_p]
@@ -770,6 +771,11 @@ class Pair:
     @property
     def gather_slots(self):
         return self.ctx.L.ucg_pair_gather_slots(self.h)
+
+    @property
+    def sum_fixed(self):
+        """True: this pair sums a bead's terms as order-free integer images (include/ucg_hip.h, ucg_pair_sum_fixed)"""
+        return bool(self.ctx.L.ucg_pair_sum_fixed(self.h))
 
     @property
     def cutforce(self):

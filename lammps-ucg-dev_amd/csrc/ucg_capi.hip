@@ -425,6 +425,67 @@ int ucg_pair_init(ucg_pair *p, int ntypes, double T)
       } else if (ctx->pair_once) {
         ctx->once_beads_wanted = 0;
       }
+      // option pair_vrow (default): both gather styles on virtual rows (ucg_pair_vrow.hip) when the tables, 512 own beads
+      // and their fixed-point accumulators fit the LDS next to the static model arrays.  Decided here, once: it fixes how
+      // a bead's terms are summed (fixed sums, ucg_pair_sum_fixed), which callers comparing bits need to know.
+      p->vrow = false;
+      p->vr_gen = -1;
+      for (int c = 0; c < 3; c++) {
+        D.sum_sc[c] = 1.0;
+        D.sum_dec[c] = std::ldexp(1.0, -38);
+      }
+      D.sum_rsq_safe = 1.0e300;
+      if (ctx->pair_vrow && !p->once && (M.style == STYLE_UCGLD || M.style == STYLE_BETHE) && fast && D.tab_in_lds && !bitmap &&
+          !ctx->fma_contract) {
+        PairDev probe = D;
+        probe.fast = 1;
+        p->vrow = vrow_lds_bytes(probe) + 4608 <= 160 * 1024;
+      }
+      if (p->vrow) {
+        // the power-of-two units of the three fields -- the rule of the oracle's orc_pair_sum_scales, on the same table
+        // values -- and the r^2 beyond which the magic-constant image is valid
+        const int nent = (M.tabstyle == LOOKUP) ? M.tablength - 1 : M.tablength;
+        double fref = 0.0, uref = 0.0;
+        for (int d = 0; d < ntab; d++) {
+          const Table &tb = M.tables[(size_t) order[(size_t) d]];
+          // the knots of the upper three quarters of the table's r^2 range
+          const double from = tb.innersq + 0.25 * ((nent - 1) * tb.delta);
+          for (int k = 0; k < nent; k++) {
+            const double rs = tb.innersq + k * tb.delta;
+            if (!(rs >= from)) continue;
+            const double fv = std::fabs(tb.f[(size_t) k]) * std::sqrt(rs > 0.0 ? rs : 0.0), ue = std::fabs(tb.e[(size_t) k]);
+            if (fv > fref) fref = fv;
+            if (ue > uref) uref = ue;
+          }
+        }
+        const double sref = uref / M.kT;
+        const int ex[3] = {(fref > 0.0 && std::isfinite(fref)) ? 4 - std::ilogb(fref) : 0,
+                           (uref > 0.0 && std::isfinite(uref)) ? 4 - std::ilogb(uref) : 0,
+                           (sref > 0.0 && std::isfinite(sref)) ? 4 - std::ilogb(sref) : 0};
+        for (int c = 0; c < 3; c++) {
+          D.sum_sc[c] = std::ldexp(1.0, ex[c]);
+          D.sum_dec[c] = std::ldexp(1.0, -38 - ex[c]);
+        }
+        // terms: weight (<= 2.8^2 for |lambda - 0.5| <= 2.3; Bethe: probabilities) x {F = (f/r) r, an energy difference
+        // (<= 2 max|e|), an energy / kT}; walk the grid down from the cutoff while all of them stay below 8192 units
+        const double wmax = 8.0;
+        int ksafe = nent;
+        for (int k = nent - 1; k >= 0; k--) {
+          double mag = 0.0;
+          for (int d = 0; d < ntab; d++) {
+            const Table &tb = M.tables[(size_t) order[(size_t) d]];
+            const double rs = tb.innersq + k * tb.delta;
+            mag = std::fmax(mag, std::fabs(tb.f[(size_t) k]) * std::sqrt(rs > 0.0 ? rs : 0.0) * D.sum_sc[0]);
+            mag = std::fmax(mag, 2.0 * std::fabs(tb.e[(size_t) k]) * D.sum_sc[1]);
+            mag = std::fmax(mag, 2.0 * std::fabs(tb.e[(size_t) k]) / M.kT * D.sum_sc[2]);
+          }
+          if (!(wmax * mag < 8192.0)) break;
+          ksafe = k;
+        }
+        const Table &t0 = M.tables[(size_t) order[0]];
+        const int kk = ksafe + 2;  // two knots of margin for the interpolant between knots
+        if (kk < nent) D.sum_rsq_safe = t0.innersq + kk * t0.delta;
+      }
       D.hot_type = 0;
       D.hot_ent = 0;
       D.hot_k0 = -1;
@@ -489,6 +550,7 @@ int ucg_pair_single(const ucg_pair *p, int itype, int jtype, double rsq, double 
 }
 
 int ucg_pair_gather_slots(const ucg_pair *p) { return (p && p->uploaded) ? p->dev.gather_slots : 1; }
+int ucg_pair_sum_fixed(const ucg_pair *p) { return (p && p->uploaded && p->vrow) ? 1 : 0; }
 
 int ucg_pair_table_count(const ucg_pair *p) { return p ? (int) p->model.tables.size() : -1; }
 
@@ -662,8 +724,28 @@ static int pair_compute_impl(ucg_pair *p, int eflag, int vflag, double *eng_vdwl
       p->tab_lds_bytes = hot;
       p->dev.stage_own = (ctx->stage_own && hot + (size_t) (1024 / p->dev.gather_slots) * 36 + 6 * 1024 <= 160 * 1024) ? 1 : 0;
     }
-    const int nb = pair_gather_blocks(ctx->nlocal, p->dev.gather_slots);
+    const int nb = p->vrow ? vrow_blocks(ctx->nlocal) : pair_gather_blocks(ctx->nlocal, p->dev.gather_slots);
     if (ev) p->d_evpart.reserve((size_t) nb * 8 + 8);
+    if (p->vrow && p->vr_gen != ctx->list_gen && ctx->nlocal > 0) {
+      // the virtual rows of this list (one launch, no host round trip: the buffers are sized from the longest full row)
+      if (ctx->list_maxrow > vrow_maxrow())
+        return fail(ctx, UCG_ERR_UNSUPPORTED, "a neighbour row has more entries than the virtual-row builder takes (128); "
+                                              "set option pair_vrow 0 before ucg_pair_init");
+      int cap = vrow_capacity(ctx->list_maxrow);
+      cap = cap > 32 ? 32 : cap;  // (what the builder's LDS staging takes; a longer list is reported by the builder)
+      const int pitch = nb * 1024;
+      if (cap > p->vr_cap || pitch > p->vr_pitch) {
+        p->vr_cap = cap > p->vr_cap ? cap : p->vr_cap;
+        p->vr_pitch = pitch > p->vr_pitch ? pitch : p->vr_pitch;
+        p->d_vr_entP.reserve((size_t) p->vr_pitch * (size_t) p->vr_cap);
+        p->d_vr_entQ.reserve((size_t) p->vr_pitch * (size_t) p->vr_cap);
+        p->d_vr_entS.reserve((size_t) p->vr_pitch * (size_t) p->vr_cap);
+        p->d_vr_lanemeta.reserve((size_t) p->vr_pitch * 3);
+      }
+      UCG_HIP(launch_vrow_build(p->dev, ctx->atoms_dev(), ctx->list_dev(), p->d_vr_entP.get(), p->d_vr_entQ.get(),
+                                p->d_vr_entS.get(), p->vr_cap, p->vr_pitch, p->d_vr_lanemeta.get(), p->d_err.get(), ctx->stream));
+      p->vr_gen = ctx->list_gen;
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->prof_on) {
       UCG_HIP(hipEventCreate(&e0));
@@ -688,7 +770,7 @@ static int pair_compute_impl(ucg_pair *p, int eflag, int vflag, double *eng_vdwl
     } else {
       ListDev L = ctx->list_dev();
       if (part != 0) {
-        const int bslots = p->dev.gather_slots;  // beads per workgroup = 1024 / bslots
+        const int bslots = p->vrow ? 1024 / vrow_beads() : p->dev.gather_slots;  // beads per workgroup = 1024 / bslots
         if (p->blockflag_build != ctx->list_gen || p->blockflag_slots != bslots) {
           p->d_blockflag.reserve((size_t) nb + 1);
           UCG_HIP(launch_block_classify(ctx->atoms_dev(), L, bslots, p->d_blockflag.get(), ctx->stream));
@@ -699,7 +781,11 @@ static int pair_compute_impl(ucg_pair *p, int eflag, int vflag, double *eng_vdwl
         L.blockwant = part == 1 ? 0 : 1;
       }
       if (post) L.post = *post;
-      if (ctx->fma_contract)
+      if (p->vrow)
+        UCG_HIP(launch_pair_vrow(p->dev, ctx->atoms_dev(), L, p->d_vr_entP.get(), p->d_vr_entQ.get(), p->d_vr_entS.get(),
+                                 p->d_vr_lanemeta.get(), p->vr_pitch, ev, p->d_evpart.get(), p->d_evout.get(), p->d_err.get(),
+                                 ctx->stream));
+      else if (ctx->fma_contract)
         UCG_HIP(launch_pair_gather_fused(p->dev, ctx->atoms_dev(), L, ev, p->d_evpart.get(), p->d_evout.get(),
                                          p->d_err.get(), ctx->stream));
       else
@@ -805,6 +891,13 @@ int ucg_pair_check_errors(ucg_pair *p)
     UCG_HIP(hipMemsetAsync(p->d_err.get(), 0, sizeof(int), ctx->stream));
     if (flag & 1) return fail(ctx, UCG_ERR_TABLE_INNER, "Pair distance < table inner cutoff");
     if (flag & 2) return fail(ctx, UCG_ERR_TABLE_OUTER, "Pair distance > table outer cutoff");
+    if (flag & 8)
+      return fail(ctx, UCG_ERR_UNSUPPORTED, "the virtual rows of a block of 512 beads do not fit (a row of more than 128 entries, or "
+                                            "more than 32 768 kept entries in one of the block's lists): set option pair_vrow 0 "
+                                            "before ucg_pair_init");
+    if (p->vrow)
+      return fail(ctx, UCG_ERR_UNSUPPORTED, "a pair term left the range of the fixed sums (|term| >= 2^24 units of the tables' "
+                                            "reference force / energy): the tables or lambda are far outside any physical range");
     return fail(ctx, UCG_ERR_UNSUPPORTED, "option pair_once: a pair term left the range of the fixed-point accumulators "
                                           "(|term| >= 2048); run without the option");
   });
@@ -1540,6 +1633,10 @@ int ucg_ctx_set_option(ucg_ctx *ctx, const char *name, int value)
   }
   if (std::strcmp(name, "rows_untiled") == 0) {
     ctx->rows_untiled = value != 0;
+    return UCG_OK;
+  }
+  if (std::strcmp(name, "pair_vrow") == 0) {
+    ctx->pair_vrow = value != 0;
     return UCG_OK;
   }
   if (std::strcmp(name, "pair_once") == 0) {

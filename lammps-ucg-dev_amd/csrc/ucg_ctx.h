@@ -146,6 +146,8 @@ struct ucg_ctx {
   bool rows_untiled = false;           // option "rows_untiled": build rows with the one-lane-per-bead kernels
   bool pair_once = false;              // option "pair_once": own-block pairs evaluated once (see ucg_pair.hip, ONCE variants)
   int once_beads_wanted = 0;           // set by ucg_pair_init when the option applies to that pair: beads per workgroup
+  bool pair_vrow = true;               // option "pair_vrow" (default on): the gather styles run on virtual rows where they can
+                                       // (ucg_pair_vrow.hip: own-block pairs once, fixed sums)
 
   // atoms
   int nlocal = 0, nghost = 0, ntypes = 0;
@@ -230,6 +232,13 @@ struct ucg_pair {
   std::string err;
   size_t tab_lds_bytes = 0;
   bool once = false;  // option pair_once applies: gather_slots 2, rows with own-block pairs once
+  // option pair_vrow applies (decided at ucg_pair_init: it fixes the summation mode, ucg_pair_sum_fixed): the virtual
+  // rows made from the resident full rows (ucg_pair_vrow.hip)
+  bool vrow = false;
+  long long vr_gen = -1;  // ctx->list_gen they were made from
+  int vr_pitch = 0, vr_cap = 0;
+  ucg::DevBuf<int2> d_vr_lanemeta;
+  ucg::DevBuf<int> d_vr_entP, d_vr_entQ, d_vr_entS;
   // tables read through L2 (several actual types): host copy of the device tables and the table ids of every
   // (type, type) pair, from which the LDS block of the most populous type is made (PairDev::hot_type)
   std::vector<double4> host_tab;

@@ -45,6 +45,10 @@ struct PairDev {
   int gather_slots;    // lanes per bead in k_pair_gather (1, 4, 8 or 16): part of the canonical order
   int stage_own;       // 1: k_pair_gather keeps its workgroup's own beads in LDS behind the tables
   int stage_own_allowed;  // the context option "stage_own" (kernels with other block shapes decide the fit themselves)
+  // fixed sums (ucg_pair_dev.h; set when the pair runs on virtual rows): power-of-two units of the force / ucgforce /
+  // score sums, their inverses * 2^-38, and the r^2 beyond which every term of a pair is below 8192 units for
+  // |lambda - 0.5| <= 2.3
+  double sum_sc[3], sum_dec[3], sum_rsq_safe;
   int fast;            // 1: one shared r^2 grid, all special_lj == 1, kT usable for div_by_const
   // FAST tables that do not fit the LDS (several actual types: read through L1 / L2): the three tables of the pairs of
   // ONE actual type with itself -- the most populous one, chosen by the host -- are staged in LDS all the same, and a lane

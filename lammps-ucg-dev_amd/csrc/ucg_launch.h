@@ -20,6 +20,18 @@ hipError_t launch_block_classify(const AtomsDev &A, const ListDev &L, int slots,
 
 hipError_t launch_ev_final(const double *part, int nblocks, double *out, hipStream_t st);
 
+// ---- ucg_pair_vrow.hip: own-block pairs once on balanced virtual rows, fixed sums
+int vrow_blocks(int nlocal);
+int vrow_beads();
+int vrow_maxrow();
+int vrow_capacity(int maxrow);
+size_t vrow_lds_bytes(const PairDev &P);
+hipError_t launch_vrow_build(const PairDev &P, const AtomsDev &A, const ListDev &L, int *entP, int *entQ, int *entS, int cap,
+                             int vpitch, int2 *lanemeta, int *errflag, hipStream_t st);
+hipError_t launch_pair_vrow(const PairDev &P, const AtomsDev &A, const ListDev &L, const int *entP, const int *entQ,
+                            const int *entS, const int2 *lanemeta, int vpitch, bool ev, double *evpart, double *evout,
+                            int *errflag, hipStream_t st);
+
 hipError_t launch_selftest_div(double b, unsigned long long seed, int n, unsigned long long *d_mismatches, hipStream_t st);
 
 // ---- ucg_density.hip

@@ -16,6 +16,54 @@ struct Quad {
   double u00, u01, u10, u11;
   double f00, f01, f10, f11;
 };
+// ---- fixed sums (the kernels of ucg_pair_vrow.hip).  A bead's force components, ucgforce and scores are sums of
+// per-pair terms.  Every term is rounded to nearest-even at 2^-38 of a per-field power-of-two unit (PairDev::sum_sc,
+// fixed by the tables at ucg_pair_init so that it follows the unit system) and the images are added as 64-bit
+// integers: associative and commutative, so the sums do not depend on the order of the additions, on how entries are
+// dealt to lanes, on which lane evaluates a pair, or on the decomposition (the oracle states the same:
+// oracle/orc_compute.c, sum_fixed).
+// Fast path: bits(v * unit + 1.5 * 2^14) - bits(1.5 * 2^14) is that image while |v * unit| < 8192 (the sum's ulp is
+// 2^-38 there); callers take it only where the tables guarantee the bound (PairDev::sum_rsq_safe, moderate lambda),
+// the slow path converts in software (same rounding) up to 2^24 units and reports anything beyond as error bit 4.
+constexpr double SUM_MAGIC = 24576.0;
+constexpr long long SUM_MAGIC_BITS = 0x40D8000000000000ll;
+
+struct SumDev {
+  double sc_f, sc_u, sc_s;     // 2^e of the three fields
+  double dec_f, dec_u, dec_s;  // 2^(-38 - e)
+  double rsq_safe;
+};
+__device__ __forceinline__ SumDev sum_dev(const PairDev &P)
+{
+  return SumDev{P.sum_sc[0], P.sum_sc[1], P.sum_sc[2], P.sum_dec[0], P.sum_dec[1], P.sum_dec[2], P.sum_rsq_safe};
+}
+// RAW images: the image plus bits(1.5 * 2^14).  Accumulators add raw images modulo 2^64 and subtract (number of terms)
+// x bits(1.5 * 2^14) once at the end (sum_finish): one fused multiply-add (v * unit is exact, so the fusion changes nothing)
+// and one 64-bit integer addition per term.
+__device__ __forceinline__ unsigned long long sum_raw_fast(const double v, const double sc)
+{
+  return (unsigned long long) __double_as_longlong(fma(v, sc, SUM_MAGIC));
+}
+__device__ __forceinline__ unsigned long long sum_raw_slow(const double v, const double sc, int &err)
+{
+  const double u = v * sc;
+  long long im = 0;
+  if (!(fabs(u) < 16777216.0)) err |= 4;
+  else im = __double2ll_rn(u * 274877906944.0);  // 2^38: exact product, rounded to nearest even
+  return (unsigned long long) im + (unsigned long long) SUM_MAGIC_BITS;
+}
+__device__ __forceinline__ unsigned long long sum_raw(const double v, const double sc, const bool fast, int &err)
+{
+  return fast ? sum_raw_fast(v, sc) : sum_raw_slow(v, sc, err);
+}
+// the integer sum of `nterms` raw images
+__device__ __forceinline__ long long sum_finish(const unsigned long long raw, const unsigned nterms)
+{
+  // bits(1.5 * 2^14) has a zero low word: n x it is one 32-bit product in the high word (modulo 2^64 like the sum)
+  return (long long) (raw - ((unsigned long long) (nterms * 0x40D80000u) << 32));
+}
+__device__ __forceinline__ double sum_decode(const long long s, const double dec) { return (double) s * dec; }
+
 
 // correctly rounded a / b from y = RN(1/b): q0 = RN(a*y), then two FMA residual steps.
 // Exact when b's significand is not all ones and neither the quotient nor the residuals leave the

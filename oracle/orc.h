@@ -120,21 +120,19 @@ typedef struct {
   int density_proximity_as_shipped;  /* #12 */
   /* canonical gather order: number of interleaved slot accumulators per bead (power of two, <= ORC_MAX_SLOTS) */
   int gather_slots;
-  /* canonical order of the library's option pair_once ("own-block pairs once", csrc/ucg_pair.hip): > 0 = beads per
-     workgroup block B.  A pair of two OWNED beads k, m of one block (k / B == m / B) is swept only from the row of
-     the bead that keeps it -- k iff (k < m) != ((k + m) odd) -- and what the pair adds to the OTHER bead (the same
-     numbers the half-list sweep adds to it) is accumulated there as integers in units of 2^-40; a bead's total is
-     (its slot sums over the kept rows entries, fixed tree) + (that integer sum converted back).  Sets *err bit 4 when
-     a term is not smaller than once_limit. */
-  int once_block;
-  double once_limit;
+  /* "fixed" sums (the library's pair kernels that evaluate a pair of one workgroup once, csrc/ucg_pair_vrow.hip):
+     sum_fixed != 0 -> a bead's terms are rounded to nearest-even at 2^-38 of a per-field power-of-two unit
+     (2^-sum_exp[field]; field 0 force components, 1 ucgforce, 2 scores) and added as 64-bit integers: associative and
+     commutative, so no order is part of the definition.  bead total = prologue value + (double) integer sum * unit.
+     Sets *err bit 4 when a term's image does not fit. */
+  int sum_fixed;
+  int sum_exp[3];
   char errmsg[512];
 } orc_pair;
 
 #define ORC_MAX_SLOTS 64
-#define ORC_ONCE_MAGIC 6144.0                 /* 1.5 * 2^12: ulp 2^-40 */
-#define ORC_ONCE_UNIT 9.094947017729282e-13   /* 2^-40 */
-void orc_pair_set_once(orc_pair *p, int block_beads, double limit);
+void orc_pair_set_sum_fixed(orc_pair *p, int on);
+void orc_pair_sum_scales(orc_pair *p); /* called by orc_pair_init */
 orc_pair *orc_pair_create(int style);
 void orc_pair_destroy(orc_pair *p);
 const char *orc_pair_error(const orc_pair *p);

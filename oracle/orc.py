@@ -98,7 +98,7 @@ def lib():
     L.orc_pair_dbl_array.restype = c_double_p
     L.orc_pair_set_compat.argtypes = [C.c_void_p, C.c_int]
     L.orc_pair_set_gather_slots.argtypes = [C.c_void_p, C.c_int]
-    L.orc_pair_set_once.argtypes = [C.c_void_p, C.c_int, C.c_double]
+    L.orc_pair_set_sum_fixed.argtypes = [C.c_void_p, C.c_int]
     L.orc_pair_density_compute.argtypes = [C.c_void_p, C.POINTER(Atoms), C.POINTER(NList), C.c_int, C.c_int,
                                            C.c_int, c_int_p, C.POINTER(Ev)]
     L.orc_force_clear.argtypes = [C.POINTER(Atoms), C.c_int]
@@ -234,9 +234,9 @@ class Pair:
         """canonical order: interleaved partial sums per bead (must equal the GPU kernel's lanes per bead)"""
         self.L.orc_pair_set_gather_slots(self.h, int(slots))
 
-    def set_once(self, block_beads: int, limit: float = 2048.0):
-        """canonical order of the library's option pair_once (orc.h): own-block pairs swept from one row only"""
-        self.L.orc_pair_set_once(self.h, int(block_beads), float(limit))
+    def set_sum_fixed(self, on: bool):
+        """order-free integer sums (orc.h, sum_fixed): what the library's pair kernels on virtual rows compute"""
+        self.L.orc_pair_set_sum_fixed(self.h, 1 if on else 0)
 
     def set_compat(self, flags: int):
         self.L.orc_pair_set_compat(self.h, flags)

@@ -291,14 +291,68 @@ int orc_pair_compute_half(orc_pair *p, orc_atoms *a, const orc_list *l, int newt
   return ev->err ? 2 : 0;
 }
 
-/* pair_once: image of one term in units of 2^-40 (round to nearest even, as the double addition does) */
-static long long once_image(const orc_pair *p, double v, orc_ev *ev)
+/* ---- "fixed" sums: the integer image of one term: round to nearest even of v * 2^(38 + e); field = 0 force
+   components, 1 ucgforce (energies), 2 scores (energies / kT); |image| < 2^62 or error bit 4 */
+static long long sum_image(const orc_pair *p, int field, double v, orc_ev *ev)
 {
-  union { double d; long long i; } t, m;
-  if (!(fabs(v) < p->once_limit)) ev->err |= 4;
-  t.d = v + ORC_ONCE_MAGIC;
-  m.d = ORC_ONCE_MAGIC;
-  return t.i - m.i;
+  const double scaled = ldexp(v, 38 + p->sum_exp[field]); /* exact: a power of two */
+  if (!(fabs(scaled) < 4.611686018427388e18)) {
+    ev->err |= 4;
+    return 0;
+  }
+  return llrint(scaled);
+}
+
+static double sum_decode(const orc_pair *p, int field, long long s)
+{
+  return ldexp((double) s, -38 - p->sum_exp[field]);
+}
+
+/* The units of the integer sums: powers of two fixed by the tables (so that they follow the unit system): with
+   Fref = max |f(k)| sqrt(rsq_k) and Uref = max |e(k)| over the reachable tables and the knots whose r^2 lies in the
+   upper three quarters of the table's r^2 range (the well-behaved part of the grid), the exponents are
+   4 - ilogb(Fref), 4 - ilogb(Uref), 4 - ilogb(Uref / kT): the reference magnitudes map to [16, 32).  Zero or
+   non-finite references give exponent 0.  (Not defined for BITMAP tables: the library's kernels that sum this way do
+   not take them.) */
+void orc_pair_sum_scales(orc_pair *p)
+{
+  const int nt = p->n_formal + 1, ms = p->max_states;
+  double fref = 0.0, uref = 0.0;
+  p->sum_exp[0] = p->sum_exp[1] = p->sum_exp[2] = 0;
+  if (p->tabstyle == ORC_BITMAP) return;
+  for (int ti = 1; ti <= p->n_actual; ti++)
+    for (int tj = 1; tj <= p->n_actual; tj++)
+      for (int sa = 0; sa < 2; sa++)
+        for (int sb = 0; sb < 2; sb++) {
+          const int fi = p->formal_from_actual[ti * ms + sa], fj = p->formal_from_actual[tj * ms + sb];
+          if (fi < 1 || fj < 1 || fi > p->n_formal || fj > p->n_formal) continue;
+          const orc_table *tb = &p->tables[p->tabindex[fi * nt + fj]];
+          const int n = (p->tabstyle == ORC_LOOKUP) ? p->tablength - 1 : p->tablength;
+          const double from = tb->innersq + 0.25 * ((n - 1) * tb->delta);
+          for (int k = 0; k < n; k++) {
+            const double rsq = tb->innersq + k * tb->delta;
+            if (!(rsq >= from)) continue;
+            const double fv = fabs(tb->f[k]) * sqrt(rsq > 0.0 ? rsq : 0.0), ue = fabs(tb->e[k]);
+            if (fv > fref) fref = fv;
+            if (ue > uref) uref = ue;
+          }
+        }
+  const double sref = uref / p->kT;
+  p->sum_exp[0] = (fref > 0.0 && isfinite(fref)) ? 4 - ilogb(fref) : 0;
+  p->sum_exp[1] = (uref > 0.0 && isfinite(uref)) ? 4 - ilogb(uref) : 0;
+  p->sum_exp[2] = (sref > 0.0 && isfinite(sref)) ? 4 - ilogb(sref) : 0;
+}
+
+void orc_pair_set_sum_fixed(orc_pair *p, int on) { p->sum_fixed = on ? 1 : 0; }
+
+/* one running sum of a bead: ordered mode adds doubles in row order; fixed mode keeps the prologue value in d and
+   adds the terms' integer images to i */
+typedef struct { double d; long long i; } acc_t;
+
+static inline void acc_add(const orc_pair *p, int field, acc_t *a, double v, orc_ev *ev)
+{
+  if (p->sum_fixed) a->i += sum_image(p, field, v, ev);
+  else a->d += v;
 }
 
 int orc_pair_compute_gather(orc_pair *p, orc_atoms *a, const orc_list *l, int eflag, int vflag,
@@ -308,22 +362,17 @@ int orc_pair_compute_gather(orc_pair *p, orc_atoms *a, const orc_list *l, int ef
   const int nall = a->nlocal + a->nghost;
   const double kT = p->kT;
   const double *x = a->x;
-  const int B = p->once_block;
-  long long *acc = NULL; /* pair_once: six integer accumulators per owned bead */
   memset(ev, 0, sizeof(*ev));
-  if (B > 0) {
-    if (p->style != ORC_STYLE_UCGLD) {
-      strcpy(p->errmsg, "pair_once order is defined for table_ucgld");
-      return 1;
-    }
-    acc = (long long *) calloc((size_t) a->nlocal * 6 + 1, sizeof(long long));
-  }
   if (p->style == ORC_STYLE_BETHE_DENSITY) {
     strcpy(p->errmsg, "use orc_pair_density_compute for table_ucg_bethe_density");
     return 1;
   }
   if (p->style == ORC_STYLE_BETHE && p->prior_flag == ORC_PRIOR_CHEMPOT_NOISE) {
     strcpy(p->errmsg, "prior chemical_potential noise draws RNG in list order (App. B #17): half-list mode only");
+    return 1;
+  }
+  if (p->sum_fixed && p->tabstyle == ORC_BITMAP) {
+    strcpy(p->errmsg, "fixed sums are not defined for BITMAP tables");
     return 1;
   }
   if (check_types(p, a, nall)) return 1;
@@ -335,42 +384,32 @@ int orc_pair_compute_gather(orc_pair *p, orc_atoms *a, const orc_list *l, int ef
     const double lk = a->ucgl[k];
     const int *row = l->neigh + l->first[ii];
     const int n = l->numneigh[ii];
-    const double xk = x[3 * k + 0], yk = x[3 * k + 1], zk = x[3 * k + 2];
-    /* slot accumulators: entry e of the row goes to slot e % S; slot 0 starts from the prologue
+    /* ordered mode -- slot accumulators: entry e of the row goes to slot e % S; slot 0 starts from the prologue
        value, the others from 0; at the end slots are combined by the fixed tree
-       s[l] += s[l + S/2], ..., s[l] += s[l + 1] (what a group of S GPU lanes does) */
-    const int S = p->gather_slots > 0 ? p->gather_slots : 1;
-    double sfx[ORC_MAX_SLOTS] = {0}, sfy[ORC_MAX_SLOTS] = {0}, sfz[ORC_MAX_SLOTS] = {0};
-    double suf[ORC_MAX_SLOTS] = {0}, ss0[ORC_MAX_SLOTS] = {0}, ss1[ORC_MAX_SLOTS] = {0};
-    double fx = 0.0, fy = 0.0, fz = 0.0, uf = 0.0, s0 = 0.0, s1 = 0.0;
+       s[l] += s[l + S/2], ..., s[l] += s[l + 1] (what a group of S GPU lanes does).
+       fixed mode -- one slot: the integer sum does not depend on any order */
+    const int S = (!p->sum_fixed && p->gather_slots > 0) ? p->gather_slots : 1;
+    enum { FX, FY, FZ, UF, S0, S1 };
+    static const int field_of[6] = {0, 0, 0, 1, 2, 2};
+    acc_t acc[6][ORC_MAX_SLOTS];
+    memset(acc, 0, sizeof(acc));
     double e_acc = 0.0, v_acc[6] = {0, 0, 0, 0, 0, 0};
 
     a->num_ucgstates[k] = p->n_states_per_type[ktype];
     if (p->style == ORC_STYLE_UCGLD) {
       double mui = p->chem_pot[p->formal_from_actual[ktype * ms + 1]] -
           p->chem_pot[p->formal_from_actual[ktype * ms + 0]];
-      uf -= mui;
-      s1 -= mui / kT;
+      acc[UF][0].d -= mui;
+      acc[S1][0].d -= mui / kT;
     } else {
-      s0 = -p->chem_pot[p->formal_from_actual[ktype * ms + 0]] / kT;
-      s1 = -p->chem_pot[p->formal_from_actual[ktype * ms + 1]] / kT;
+      acc[S0][0].d = -p->chem_pot[p->formal_from_actual[ktype * ms + 0]] / kT;
+      acc[S1][0].d = -p->chem_pot[p->formal_from_actual[ktype * ms + 1]] / kT;
     }
 
-    sfx[0] = fx; sfy[0] = fy; sfz[0] = fz; suf[0] = uf; ss0[0] = s0; ss1[0] = s1;
-    int ekept = 0; /* position in the row as the library stores it (pair_once rows lack the dropped entries) */
     for (int e = 0; e < n; e++) {
-      int own_pair = 0;
-      if (B > 0) {
-        const int mm = row[e] & ORC_NEIGHMASK;
-        if (mm < a->nlocal && k / B == mm / B) {
-          const int k_keeps = (k < mm) != (((k + mm) & 1) != 0);
-          if (!k_keeps) continue; /* swept from the partner's row */
-          own_pair = 1;
-        }
-      }
-      const int slot = ekept % S;
-      ekept++;
-      fx = sfx[slot]; fy = sfy[slot]; fz = sfz[slot]; uf = suf[slot]; s0 = ss0[slot]; s1 = ss1[slot];
+      const int slot = e % S;
+      acc_t *fx = &acc[FX][slot], *fy = &acc[FY][slot], *fz = &acc[FZ][slot];
+      acc_t *uf = &acc[UF][slot], *s0 = &acc[S0][slot], *s1 = &acc[S1][slot];
       int m = row[e];
       const int k_is_i = (m >> ORC_ORIENT_BIT) & 1;
       const double factor_lj = p->special_lj[(m >> ORC_SBBITS) & 3];
@@ -385,7 +424,6 @@ int orc_pair_compute_gather(orc_pair *p, orc_atoms *a, const orc_list *l, int ef
       const double dely = x[3 * i + 1] - x[3 * j + 1];
       const double delz = x[3 * i + 2] - x[3 * j + 2];
       const double rsq = delx * delx + dely * dely + delz * delz;
-      (void) xk; (void) yk; (void) zk;
       if (rsq < p->cutsq[itype * nt + jtype]) {
         quad q;
         int rc = eval4(p, itype, jtype, rsq, factor_lj, &q);
@@ -398,22 +436,23 @@ int orc_pair_compute_gather(orc_pair *p, orc_atoms *a, const orc_list *l, int ef
         const double u00 = q.u[0][0], u01 = q.u[0][1], u10 = q.u[1][0], u11 = q.u[1][1];
         const double fpair00 = q.fp[0][0], fpair01 = q.fp[0][1], fpair10 = q.fp[1][0], fpair11 = q.fp[1][1];
         double evdwl, fpair;
+        /* (x -= y and x += -y are the same double operation) */
         if (p->style == ORC_STYLE_UCGLD || p->pseudo_flag == 0) {
           if (k_is_i) {
-            s0 -= q.u[0][jstate] / kT;
-            s1 -= q.u[1][jstate] / kT;
+            acc_add(p, 2, s0, -(q.u[0][jstate] / kT), ev);
+            acc_add(p, 2, s1, -(q.u[1][jstate] / kT), ev);
           } else {
-            s0 -= q.u[istate][0] / kT;
-            s1 -= q.u[istate][1] / kT;
+            acc_add(p, 2, s0, -(q.u[istate][0] / kT), ev);
+            acc_add(p, 2, s1, -(q.u[istate][1] / kT), ev);
           }
         }
         if (p->style == ORC_STYLE_UCGLD) {
           evdwl = (1. - ldi) * (1. - ldj) * u00 + (1. - ldi) * ldj * u01 + (1. - ldj) * ldi * u10 + ldi * ldj * u11;
           fpair = (1. - ldi) * (1. - ldj) * fpair00 + (1. - ldi) * ldj * fpair01 + (1. - ldj) * ldi * fpair10 + ldi * ldj * fpair11;
           if (k_is_i)
-            uf -= ldj * (u11 - u01) + (1. - ldj) * (u10 - u00);
+            acc_add(p, 1, uf, -(ldj * (u11 - u01) + (1. - ldj) * (u10 - u00)), ev);
           else
-            uf -= ldi * (u11 - u10) + (1. - ldi) * (u01 - u00);
+            acc_add(p, 1, uf, -(ldi * (u11 - u10) + (1. - ldi) * (u01 - u00)), ev);
         } else {
           /* priors: i from ucgl[i], j from ucgp[j] (first call: per prior_flag) */
           double pi0, pi1, pj0, pj1;
@@ -425,24 +464,24 @@ int orc_pair_compute_gather(orc_pair *p, orc_atoms *a, const orc_list *l, int ef
             double pj0i0 = pij00 / pi0, pj0i1 = pij01 / pi0, pj1i0 = pij10 / pi1, pj1i1 = pij11 / pi1;
             double pi0j0 = pij00 / pj0, pi0j1 = pij10 / pj0, pi1j0 = pij01 / pj1, pi1j1 = pij11 / pj1;
             if (k_is_i) {
-              s0 -= (pj0i0 * u00 + pj1i0 * u01) / kT;
-              s1 -= (pj0i1 * u10 + pj1i1 * u11) / kT;
+              acc_add(p, 2, s0, -((pj0i0 * u00 + pj1i0 * u01) / kT), ev);
+              acc_add(p, 2, s1, -((pj0i1 * u10 + pj1i1 * u11) / kT), ev);
             } else {
-              s0 -= (pi0j0 * u00 + pi0j1 * u01) / kT;
-              s1 -= (pi1j0 * u10 + pi1j1 * u11) / kT;
+              acc_add(p, 2, s0, -((pi0j0 * u00 + pi0j1 * u01) / kT), ev);
+              acc_add(p, 2, s1, -((pi1j0 * u10 + pi1j1 * u11) / kT), ev);
             }
           }
           evdwl = pij00 * u00 + pij01 * u01 + pij10 * u10 + pij11 * u11;
           fpair = pij00 * fpair00 + pij01 * fpair01 + pij10 * fpair10 + pij11 * fpair11;
         }
         if (k_is_i) {
-          fx += delx * fpair;
-          fy += dely * fpair;
-          fz += delz * fpair;
+          acc_add(p, 0, fx, delx * fpair, ev);
+          acc_add(p, 0, fy, dely * fpair, ev);
+          acc_add(p, 0, fz, delz * fpair, ev);
         } else {
-          fx -= delx * fpair;
-          fy -= dely * fpair;
-          fz -= delz * fpair;
+          acc_add(p, 0, fx, -(delx * fpair), ev);
+          acc_add(p, 0, fy, -(dely * fpair), ev);
+          acc_add(p, 0, fz, -(delz * fpair), ev);
         }
         /* a pair is seen from both of its owned ends: half of E and W each time */
         if (eflag) e_acc += 0.5 * evdwl;
@@ -454,69 +493,26 @@ int orc_pair_compute_gather(orc_pair *p, orc_atoms *a, const orc_list *l, int ef
           v_acc[4] += 0.5 * (delx * delz * fpair);
           v_acc[5] += 0.5 * (dely * delz * fpair);
         }
-        if (own_pair) {
-          /* pair_once: this row is the only one holding the pair; what the half-list sweep adds to the partner m
-             (UCG/pair_table_ucgld.cpp:500-502 / :492-498, :514-517, :523-530) goes to m's integer accumulators */
-          long long *am = acc + (size_t) m * 6;
-          double ufm, sm0, sm1;
-          if (k_is_i) { /* m is "j" */
-            am[0] += once_image(p, -(delx * fpair), ev);
-            am[1] += once_image(p, -(dely * fpair), ev);
-            am[2] += once_image(p, -(delz * fpair), ev);
-            ufm = ldi * (u11 - u10) + (1. - ldi) * (u01 - u00);
-            sm0 = q.u[istate][0] / kT;
-            sm1 = q.u[istate][1] / kT;
-          } else { /* m is "i" */
-            am[0] += once_image(p, delx * fpair, ev);
-            am[1] += once_image(p, dely * fpair, ev);
-            am[2] += once_image(p, delz * fpair, ev);
-            ufm = ldj * (u11 - u01) + (1. - ldj) * (u10 - u00);
-            sm0 = q.u[0][jstate] / kT;
-            sm1 = q.u[1][jstate] / kT;
-          }
-          am[3] += once_image(p, -ufm, ev);
-          am[4] += once_image(p, -sm0, ev);
-          am[5] += once_image(p, -sm1, ev);
-          if (eflag) e_acc += 0.5 * evdwl;
-          if (vflag) {
-            v_acc[0] += 0.5 * (delx * delx * fpair);
-            v_acc[1] += 0.5 * (dely * dely * fpair);
-            v_acc[2] += 0.5 * (delz * delz * fpair);
-            v_acc[3] += 0.5 * (delx * dely * fpair);
-            v_acc[4] += 0.5 * (delx * delz * fpair);
-            v_acc[5] += 0.5 * (dely * delz * fpair);
-          }
-        }
       }
-      sfx[slot] = fx; sfy[slot] = fy; sfz[slot] = fz; suf[slot] = uf; ss0[slot] = s0; ss1[slot] = s1;
     }
-    for (int off = S / 2; off > 0; off >>= 1)
-      for (int l = 0; l < off; l++) {
-        sfx[l] += sfx[l + off]; sfy[l] += sfy[l + off]; sfz[l] += sfz[l + off];
-        suf[l] += suf[l + off]; ss0[l] += ss0[l + off]; ss1[l] += ss1[l + off];
+    double tot[6];
+    for (int c = 0; c < 6; c++) {
+      if (p->sum_fixed) {
+        tot[c] = acc[c][0].d + sum_decode(p, field_of[c], acc[c][0].i);
+      } else {
+        for (int off = S / 2; off > 0; off >>= 1)
+          for (int s = 0; s < off; s++) acc[c][s].d += acc[c][s + off].d;
+        tot[c] = acc[c][0].d;
       }
-    fx = sfx[0]; fy = sfy[0]; fz = sfz[0]; uf = suf[0]; s0 = ss0[0]; s1 = ss1[0];
-    a->f[3 * k + 0] = fx;
-    a->f[3 * k + 1] = fy;
-    a->f[3 * k + 2] = fz;
-    if (p->style == ORC_STYLE_UCGLD) a->ucgforce[k] = uf;
-    a->scores[2 * k + 0] = s0;
-    a->scores[2 * k + 1] = s1;
+    }
+    a->f[3 * k + 0] = tot[FX];
+    a->f[3 * k + 1] = tot[FY];
+    a->f[3 * k + 2] = tot[FZ];
+    if (p->style == ORC_STYLE_UCGLD) a->ucgforce[k] = tot[UF];
+    a->scores[2 * k + 0] = tot[S0];
+    a->scores[2 * k + 1] = tot[S1];
     ev->eng_vdwl += e_acc;
     for (int c = 0; c < 6; c++) ev->virial[c] += v_acc[c];
-  }
-  if (acc) {
-    for (int ii = 0; ii < l->inum; ii++) {
-      const int k = l->ilist[ii];
-      const long long *ak = acc + (size_t) k * 6;
-      a->f[3 * k + 0] += (double) ak[0] * ORC_ONCE_UNIT;
-      a->f[3 * k + 1] += (double) ak[1] * ORC_ONCE_UNIT;
-      a->f[3 * k + 2] += (double) ak[2] * ORC_ONCE_UNIT;
-      a->ucgforce[k] += (double) ak[3] * ORC_ONCE_UNIT;
-      a->scores[2 * k + 0] += (double) ak[4] * ORC_ONCE_UNIT;
-      a->scores[2 * k + 1] += (double) ak[5] * ORC_ONCE_UNIT;
-    }
-    free(acc);
   }
   return ev->err ? 2 : 0;
 }

@@ -85,11 +85,6 @@ void orc_pair_set_special_lj(orc_pair *p, const double *s)
 }
 
 void orc_pair_set_gather_slots(orc_pair *p, int slots) { p->gather_slots = slots; }
-void orc_pair_set_once(orc_pair *p, int block_beads, double limit)
-{
-  p->once_block = block_beads;
-  p->once_limit = limit;
-}
 
 void orc_pair_set_compat(orc_pair *p, int flags) { p->density_proximity_as_shipped = flags & 1; }
 

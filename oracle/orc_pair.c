@@ -363,5 +363,6 @@ int orc_pair_init(orc_pair *p, int ntypes, double T, double boltz)
       }
     }
   }
+  orc_pair_sum_scales(p);
   return 0;
 }

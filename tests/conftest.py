@@ -60,3 +60,11 @@ def fresh_ctx(pkg):
     ctx = pkg.capi.Context(-1)
     yield ctx
     ctx.close()
+
+
+@pytest.fixture(autouse=True)
+def _forget_oracle_pairs():
+    """tests/util.py keeps the oracle pairs a test made (to put them into the library pair's summation mode)"""
+    yield
+    import util
+    util.forget_oracle_pairs()

@@ -20,7 +20,7 @@ def _build(outdir):
     exe = os.path.join(outdir, "ucg_c_caller")
     subprocess.check_call(["gcc", "-std=c99", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
                            os.path.join(HERE, "c_abi", "ucg_c_caller.c"), "-o", exe, "-L", PKG, "-lucg_hip",
-                           "-L", "/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib"])
+                           "-L", "/opt/rocm/lib", "-lamdhip64", "-lm", "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib"])
     return exe
 
 

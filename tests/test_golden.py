@@ -49,7 +49,8 @@ def _fixes(case):
     return ((1.0, 1.0, 1.0, 48279) if ucgld else None), ("ld" if ucgld else ("mc", 4242, 0.3))
 
 
-CASES = ["ucgld_spline1024", "ucgld_linear2000", "bethe_pseudo_yes", "bethe_mf", "density"]
+CASES = ["ucgld_spline1024", "ucgld_spline1024_ordered", "ucgld_linear2000", "bethe_pseudo_yes", "bethe_pseudo_yes_ordered",
+         "bethe_mf", "density"]
 
 
 def test_ranmar_known_answers_from_the_fixture(orc):
@@ -72,6 +73,7 @@ def test_oracle_reproduces_golden(pkg, orc, name):
     assert hashlib.sha256(open(deck.table_file, "rb").read()).hexdigest() == case["table_sha256"]
     lang, ucgst = _fixes(case)
     op = util.oracle_pair(case["style"], deck)
+    op.set_sum_fixed(case["sum_fixed"])
     sim = util.oracle_sim(beads, op, mode=1, dt=0.004, nve=True, every=1, langevin=lang, ucgstate=ucgst)
     assert sim.setup(10) == 0
     A = sim.arrays()
@@ -99,7 +101,10 @@ def test_gpu_reproduces_golden(fresh_ctx, pkg, name):
     ctx.set_units(1.0, 1.0, 1.0, 0.004)
     ctx.upload_beads(beads)
     ctx.domain_set(beads.boxlo, beads.boxhi, 2.5, 0.3, every=1, delay=0, check=1)
+    if not case["pair_vrow"]:
+        ctx.set_option("pair_vrow", 0)
     gp = util.gpu_pair(ctx, case["style"], deck)
+    assert gp.sum_fixed == case["sum_fixed"]  # the summation mode the vectors were made in
     if lang:
         ctx.fix_ucgld_langevin(*lang)
     if ucgst == "ld":

@@ -226,11 +226,16 @@ def test_exact_division_by_constant(gpu_ctx, kT):
 @pytest.mark.parametrize("tabstyle,tablength,T", [("spline", 1024, 0.7), ("linear", 2048, 1.3), ("lookup", 3000, 1.0), ("spline", 512, 0.25),
                                                   ("bitmap", 10, 0.7)])
 def test_fast_and_generic_kernels_give_the_same_bits(fresh_ctx, pkg, orc, style, tabstyle, tablength, T):
+    """the full-row gather kernels' fast variants (one shared r^2 grid, exact reciprocal divisions) against their
+    general code path: same bits, both equal to the oracle's ordered sums (option pair_vrow 0: the virtual-row kernels
+    have no general variant, and sum differently)"""
     ctx = fresh_ctx
+    ctx.set_option("pair_vrow", 0)
     deck = util.make_deck(tabstyle, tablength)
     beads = pkg.synth.make_beads(9, seed=55)
     beads.ucgp = np.clip(np.random.default_rng(2).uniform(size=beads.n), 1e-6, 1 - 1e-6)
     op = util.oracle_pair(style, deck, T=T)
+    op.set_sum_fixed(False)
     sim = util.oracle_sim(beads, op, mode=1)
     sim.rebuild()
     assert sim.compute_forces(1, 1) == 0
@@ -240,6 +245,7 @@ def test_fast_and_generic_kernels_give_the_same_bits(fresh_ctx, pkg, orc, style,
         ctx.set_option("generic_kernels", generic)
         util.upload_from_oracle(ctx, sim, beads)
         gp = util.gpu_pair(ctx, style, deck, T=T)
+        assert not gp.sum_fixed
         res[generic] = (gp.compute(1, 1), ctx.atoms_download())
         gp.check_errors()
         gp.close()
@@ -334,8 +340,10 @@ def test_pair_bethe_density_parity(fresh_ctx, pkg, orc, tabstyle, tablength, ent
 @pytest.mark.parametrize("slots", [1, 2, 4, 8, 16])
 @pytest.mark.parametrize("style", ["table_ucgld", "table_ucg_bethe"])
 def test_gather_slots_define_the_canonical_order(fresh_ctx, pkg, orc, slots, style):
-    """lanes per bead of the gather kernel = interleaved partial sums + fixed tree in the oracle"""
+    """lanes per bead of the full-row gather kernel (option pair_vrow 0) = interleaved partial sums + fixed tree in the
+    oracle's ordered sums"""
     ctx = fresh_ctx
+    ctx.set_option("pair_vrow", 0)
     ctx.set_option("gather_slots", slots)
     deck = util.make_deck("spline", 1024)
     beads = pkg.synth.make_beads(9, seed=slots)
@@ -357,15 +365,18 @@ def test_gather_slots_define_the_canonical_order(fresh_ctx, pkg, orc, slots, sty
 
 
 @pytest.mark.parametrize("style", ["table_ucgld", "table_ucg_bethe"])
-@pytest.mark.parametrize("slots", [1, 4, 16])
+@pytest.mark.parametrize("slots", [0, 1, 4, 16])
 def test_interior_and_boundary_launches_add_up(fresh_ctx, pkg, style, slots):
-    """ucg_pair_compute_part 1 (workgroups without ghost neighbours) + 2 (the rest) == ucg_pair_compute"""
+    """ucg_pair_compute_part 1 (workgroups without ghost neighbours) + 2 (the rest) == ucg_pair_compute; slots 0 = the
+    virtual-row kernels (512 beads per workgroup), else the full-row gather kernels with that many lanes per bead"""
     ctx = fresh_ctx
     deck = util.make_deck("spline", 1024)
     beads = pkg.synth.make_beads(30, seed=4)
     beads.ucgp = np.clip(np.random.default_rng(1).uniform(size=beads.n), 1e-6, 1 - 1e-6)
     ctx.set_units(1.0, 1.0, 1.0, 0.002)
-    ctx.set_option("gather_slots", slots)
+    if slots:
+        ctx.set_option("pair_vrow", 0)
+    ctx.set_option("gather_slots", slots if slots else 1)
     ctx.upload_beads(beads)
     ctx.domain_set(beads.boxlo, beads.boxhi, 2.5, 0.3, every=1, delay=0, check=1)
     ctx.neigh_rebuild()
@@ -377,7 +388,8 @@ def test_interior_and_boundary_launches_add_up(fresh_ctx, pkg, style, slots):
     part1 = ctx.atoms_download()
     interior = np.any(part1["f"] != 0.0, axis=1)
     assert interior.sum() < beads.n
-    if slots >= 4:
+    assert gp.sum_fixed == (slots == 0)
+    if slots >= 4 or slots == 0:
         assert interior.sum() > 0  # some workgroups are interior (at 1024 beads per workgroup none is, at this size)
     gp.compute_part(2)
     both = ctx.atoms_download()
@@ -397,6 +409,7 @@ def test_fma_contracted_kernels_within_tolerance(fresh_ctx, pkg, orc, style):
     beads = pkg.synth.make_beads(12, seed=19)
     beads.ucgp = np.clip(np.random.default_rng(5).uniform(size=beads.n), 1e-6, 1 - 1e-6)
     op = util.oracle_pair(style, deck)
+    op.set_sum_fixed(False)  # the contracted kernels are full-row gather kernels: ordered sums
     sim = util.oracle_sim(beads, op, mode=1)
     sim.rebuild()
     assert sim.compute_forces(0, 0) == 0

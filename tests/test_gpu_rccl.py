@@ -22,17 +22,19 @@ class LocalComm:
 
     def __init__(self):
         self.hip = C.CDLL("libamdhip64.so")
-        self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
         self.hip.hipStreamSynchronize.argtypes = [C.c_void_p]
         self.calls = dict(alltoallv=0, alltoall_ll=0, allreduce_ll=0, allreduce_f64=0)
 
     def alltoallv(self, user, send, sendbytes, recv, recvbytes, stream):
         self.calls["alltoallv"] += 1
-        if sendbytes[0] != recvbytes[0] or self.hip.hipStreamSynchronize(stream):
+        if sendbytes[0] != recvbytes[0]:
             return 1
-        if sendbytes[0] and self.hip.hipMemcpy(recv, send, sendbytes[0], 3):  # hipMemcpyDeviceToDevice
+        # ordered on the context's stream (a plain hipMemcpy between device buffers runs on the null stream and does not
+        # wait for, or hold back, a non-blocking stream: the unpack kernel could read the buffer before the copy landed)
+        if sendbytes[0] and self.hip.hipMemcpyAsync(recv, send, sendbytes[0], 3, stream):  # hipMemcpyDeviceToDevice
             return 1
-        return 0
+        return 1 if self.hip.hipStreamSynchronize(stream) else 0
 
     def alltoall_ll(self, user, send, recv):
         self.calls["alltoall_ll"] += 1

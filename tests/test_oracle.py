@@ -435,35 +435,47 @@ def test_cluster_switch_acceptance_rates(orc, pkg):
     assert abs(suc_on / att_on - 0.25) < 0.08 and abs(suc_off / att_off - 0.75) < 0.08
 
 
-def test_pair_once_order_agrees_with_the_reference_loop(orc, pkg):
-    """the canonical order of the library's option pair_once (orc_pair_set_once: own-block pairs swept from one row,
-    the partner's share accumulated as integers in units of 2^-40) against the reference's half-list loop"""
+def test_fixed_sums_do_not_depend_on_the_order_of_the_rows(orc, pkg):
+    """the fixed sums (orc_pair_set_sum_fixed, oracle/orc_compute.c: every term rounded to nearest-even at 2^-38 of a per-field power-of-two unit,
+    images added as 64-bit integers) against the reference's half-list loop, and against themselves with every row of the
+    full list shuffled: integer addition is associative and commutative, so the bits must not change -- the property that
+    frees the GPU kernels to deal entries to lanes as they like (lanes per bead, pairs evaluated once, decompositions)"""
+    import ctypes as C
     deck = util.make_deck("spline", 1024)
-    beads = pkg.synth.make_beads(11, seed=8)  # 1331 beads: blocks of 512 / 512 / 307
-    op = util.oracle_pair("table_ucgld", deck, slots=2)
-    op.set_once(512)
-    sim = util.oracle_sim(beads, op, mode=1)
-    sim.rebuild()
-    assert sim.compute_forces(1, 1) == 0
-    A = sim.arrays()
-    op0 = util.oracle_pair("table_ucgld", deck)
-    sim0 = util.oracle_sim(beads, op0, mode=0)
-    sim0.rebuild()
-    assert sim0.compute_forces(1, 1) == 0
-    B = sim0.arrays()
-    for k in ("f", "ucgforce", "scores"):
-        assert np.max(np.abs(A[k] - B[k])) <= 1e-11 * np.max(np.abs(B[k])), k
-    assert abs(sim.ev()["eng_vdwl"] - sim0.ev()["eng_vdwl"]) <= 1e-12 * abs(sim0.ev()["eng_vdwl"])
-    assert np.max(np.abs(A["f"].sum(axis=0))) < 1e-8
-    # and it is a different order from the plain gather (the integer images round at 2^-40)
-    op1 = util.oracle_pair("table_ucgld", deck, slots=2)
-    sim1 = util.oracle_sim(beads, op1, mode=1)
-    sim1.rebuild()
-    assert sim1.compute_forces(1, 1) == 0
-    assert not util.bits_equal(A["f"], sim1.arrays()["f"])
-    # a term beyond the accumulators' range is reported, not wrapped
-    op.set_once(512, 1e-3)
-    assert sim.compute_forces(1, 1) != 0
+    beads = pkg.synth.make_beads(9, seed=8)
+    for style, extra in (("table_ucgld", ()), ("table_ucg_bethe", ("pseudo", "no"))):
+        d = util.make_deck("spline", 1024, extra_keywords=extra) if extra else deck
+        op = util.oracle_pair(style, d)
+        op.set_sum_fixed(True)
+        sim = util.oracle_sim(beads, op, mode=1)
+        sim.rebuild()
+        assert sim.compute_forces(1, 1) == 0
+        A = sim.arrays()
+        sim0 = util.oracle_sim(beads, op, mode=0)
+        sim0.rebuild()
+        assert sim0.compute_forces(1, 1) == 0
+        B = sim0.arrays()
+        for k in ("f", "ucgforce", "scores"):
+            if np.abs(B[k]).max() > 0:
+                assert np.max(np.abs(A[k] - B[k])) <= 1e-11 * np.max(np.abs(B[k])), k
+        assert abs(sim.ev()["eng_vdwl"] - sim0.ev()["eng_vdwl"]) <= 1e-12 * abs(sim0.ev()["eng_vdwl"])
+        # shuffle every row of the full list in place
+        L = orc.lib()
+        lst = L.orc_sim_full_list(sim.h).contents
+        n = lst.inum
+        first = np.ctypeslib.as_array(lst.first, shape=(n,))
+        nn = np.ctypeslib.as_array(lst.numneigh, shape=(n,))
+        neigh = np.ctypeslib.as_array(lst.neigh, shape=(int(first[n - 1] + nn[n - 1]),))
+        rng = np.random.default_rng(1)
+        for i in range(n):
+            seg = neigh[first[i]:first[i] + nn[i]]
+            seg[:] = seg[rng.permutation(len(seg))]
+        assert sim.compute_forces(1, 1) == 0
+        S = sim.arrays()
+        for k in ("f", "ucgforce", "scores"):
+            assert util.bits_equal(A[k], S[k]), (style, k)
+    # exact antisymmetry: image(-v) = -image(v), so the integer force sums of a periodic system cancel exactly
+    assert np.max(np.abs(A["f"].sum(axis=0))) < 1e-9
 
 
 def test_both_definitions_of_the_math_kernels_agree_bit_for_bit(orc, tmp_path):
