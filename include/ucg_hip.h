@@ -89,10 +89,11 @@ int ucg_ctx_set_units(ucg_ctx *ctx, double boltz, double ftm2v, double mvv2e, do
  *                   adds them as 2^-40 fixed-point integers (order-independent, so still bit-reproducible: its own
  *                   canonical order).  A term >= 2048 in magnitude sets error bit 4 and
  *                   ucg_pair_check_errors returns UCG_ERR_UNSUPPORTED: rerun without the option.  Off by default.
- *   "pair_vrow"     (default 1; set before ucg_pair_init) table_ucgld / table_ucg_bethe whose tables fit the LDS (one shared
+ *   "pair_vrow"     = 1 (set before ucg_pair_init) table_ucgld / table_ucg_bethe whose tables fit the LDS (one shared
  *                   r^2 grid, no BITMAP tables) run on balanced virtual rows: the pairs of two beads of one 512-bead
- *                   workgroup block are evaluated once, and a bead's terms are summed as fixed sums (ucg_pair_sum_fixed);
- *                   0 = the full-row gather kernels with ordered double sums for every style
+ *                   workgroup block are evaluated once, and a bead's terms are summed as fixed sums (ucg_pair_sum_fixed).
+ *                   Off by default: measured 6 % (table_ucgld) / 2 % (table_ucg_bethe) slower than the full-row gather
+ *                   kernels at 1 M beads, whose ordered double sums stay the default for every style
  *   "fma_contract"  = 1 runs the gather kernels compiled with FMA contraction: NOT the bit-exact path (results within
  *                   1e-12), never the default */
 int ucg_ctx_set_option(ucg_ctx *ctx, const char *name, int value);

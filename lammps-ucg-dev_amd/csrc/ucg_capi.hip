@@ -425,7 +425,7 @@ int ucg_pair_init(ucg_pair *p, int ntypes, double T)
       } else if (ctx->pair_once) {
         ctx->once_beads_wanted = 0;
       }
-      // option pair_vrow (default): both gather styles on virtual rows (ucg_pair_vrow.hip) when the tables, 512 own beads
+      // option pair_vrow (off by default): both gather styles on virtual rows (ucg_pair_vrow.hip) when the tables, 512 own beads
       // and their fixed-point accumulators fit the LDS next to the static model arrays.  Decided here, once: it fixes how
       // a bead's terms are summed (fixed sums, ucg_pair_sum_fixed), which callers comparing bits need to know.
       p->vrow = false;
@@ -737,13 +737,12 @@ static int pair_compute_impl(ucg_pair *p, int eflag, int vflag, double *eng_vdwl
       if (cap > p->vr_cap || pitch > p->vr_pitch) {
         p->vr_cap = cap > p->vr_cap ? cap : p->vr_cap;
         p->vr_pitch = pitch > p->vr_pitch ? pitch : p->vr_pitch;
-        p->d_vr_entP.reserve((size_t) p->vr_pitch * (size_t) p->vr_cap);
-        p->d_vr_entQ.reserve((size_t) p->vr_pitch * (size_t) p->vr_cap);
-        p->d_vr_entS.reserve((size_t) p->vr_pitch * (size_t) p->vr_cap);
-        p->d_vr_lanemeta.reserve((size_t) p->vr_pitch * 3);
+        p->d_vr_ent.reserve((size_t) p->vr_pitch * (size_t) p->vr_cap * (size_t) vrow_lists());
+        p->d_vr_lanemeta.reserve((size_t) p->vr_pitch * (size_t) vrow_lists());
       }
-      UCG_HIP(launch_vrow_build(p->dev, ctx->atoms_dev(), ctx->list_dev(), p->d_vr_entP.get(), p->d_vr_entQ.get(),
-                                p->d_vr_entS.get(), p->vr_cap, p->vr_pitch, p->d_vr_lanemeta.get(), p->d_err.get(), ctx->stream));
+      UCG_HIP(launch_vrow_build(p->dev, ctx->atoms_dev(), ctx->list_dev(), ctx->skin, p->d_vr_ent.get(),
+                                (size_t) p->vr_pitch * (size_t) p->vr_cap, p->vr_cap, p->vr_pitch, p->d_vr_lanemeta.get(),
+                                p->d_err.get(), ctx->stream));
       p->vr_gen = ctx->list_gen;
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -782,7 +781,7 @@ static int pair_compute_impl(ucg_pair *p, int eflag, int vflag, double *eng_vdwl
       }
       if (post) L.post = *post;
       if (p->vrow)
-        UCG_HIP(launch_pair_vrow(p->dev, ctx->atoms_dev(), L, p->d_vr_entP.get(), p->d_vr_entQ.get(), p->d_vr_entS.get(),
+        UCG_HIP(launch_pair_vrow(p->dev, ctx->atoms_dev(), L, p->d_vr_ent.get(), (size_t) p->vr_pitch * (size_t) p->vr_cap,
                                  p->d_vr_lanemeta.get(), p->vr_pitch, ev, p->d_evpart.get(), p->d_evout.get(), p->d_err.get(),
                                  ctx->stream));
       else if (ctx->fma_contract)

@@ -146,8 +146,9 @@ struct ucg_ctx {
   bool rows_untiled = false;           // option "rows_untiled": build rows with the one-lane-per-bead kernels
   bool pair_once = false;              // option "pair_once": own-block pairs evaluated once (see ucg_pair.hip, ONCE variants)
   int once_beads_wanted = 0;           // set by ucg_pair_init when the option applies to that pair: beads per workgroup
-  bool pair_vrow = true;               // option "pair_vrow" (default on): the gather styles run on virtual rows where they can
-                                       // (ucg_pair_vrow.hip: own-block pairs once, fixed sums)
+  bool pair_vrow = false;              // option "pair_vrow" (default off: measured slower than the full-row kernels, DESIGN.md
+                                       // 4.1): the gather styles run on virtual rows where they can (ucg_pair_vrow.hip:
+                                       // own-block pairs once, fixed sums)
 
   // atoms
   int nlocal = 0, nghost = 0, ntypes = 0;
@@ -169,6 +170,7 @@ struct ucg_ctx {
   int list_pitch = 0, list_maxrow = 0, list_inum = 0;
   long long list_entries = 0;  // as a FULL list (an own-block pair kept in one row of pair_once rows counts twice)
   long long list_stored = 0;   // entries actually stored in the rows
+  double skin = 0.0;           // Neighbor::skin as given to ucg_domain_set (0 when the caller builds the lists)
   long long list_gen = 0;      // changes whenever the rows change (device build or upload): what derived lists key on
   bool list_from_builder = false;  // rows made by the device builder (which sets no special-bond bits)
   int list_once_beads = 0;   // > 0: the rows hold own-block pairs once (workgroups of this many beads)
@@ -238,7 +240,7 @@ struct ucg_pair {
   long long vr_gen = -1;  // ctx->list_gen they were made from
   int vr_pitch = 0, vr_cap = 0;
   ucg::DevBuf<int2> d_vr_lanemeta;
-  ucg::DevBuf<int> d_vr_entP, d_vr_entQ, d_vr_entS;
+  ucg::DevBuf<int> d_vr_ent;  // the block lists, one after the other (vr_pitch * vr_cap ints each)
   // tables read through L2 (several actual types): host copy of the device tables and the table ids of every
   // (type, type) pair, from which the LDS block of the most populous type is made (PairDev::hot_type)
   std::vector<double4> host_tab;

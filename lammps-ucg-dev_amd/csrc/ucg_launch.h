@@ -24,13 +24,14 @@ hipError_t launch_ev_final(const double *part, int nblocks, double *out, hipStre
 int vrow_blocks(int nlocal);
 int vrow_beads();
 int vrow_maxrow();
+int vrow_lists();
 int vrow_capacity(int maxrow);
 size_t vrow_lds_bytes(const PairDev &P);
-hipError_t launch_vrow_build(const PairDev &P, const AtomsDev &A, const ListDev &L, int *entP, int *entQ, int *entS, int cap,
-                             int vpitch, int2 *lanemeta, int *errflag, hipStream_t st);
-hipError_t launch_pair_vrow(const PairDev &P, const AtomsDev &A, const ListDev &L, const int *entP, const int *entQ,
-                            const int *entS, const int2 *lanemeta, int vpitch, bool ev, double *evpart, double *evout,
-                            int *errflag, hipStream_t st);
+hipError_t launch_vrow_build(const PairDev &P, const AtomsDev &A, const ListDev &L, double skin, int *ent, size_t list_stride,
+                             int cap, int vpitch, int2 *lanemeta, int *errflag, hipStream_t st);
+hipError_t launch_pair_vrow(const PairDev &P, const AtomsDev &A, const ListDev &L, const int *ent, size_t list_stride,
+                            const int2 *lanemeta, int vpitch, bool ev, double *evpart, double *evout, int *errflag,
+                            hipStream_t st);
 
 hipError_t launch_selftest_div(double b, unsigned long long seed, int n, unsigned long long *d_mismatches, hipStream_t st);
 

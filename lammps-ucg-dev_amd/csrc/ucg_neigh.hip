@@ -1406,6 +1406,7 @@ int ucg_domain_set(ucg_ctx *ctx, const double *boxlo, const double *boxhi, doubl
     ctx->dom_world = 1;
     D.cutforce = cutforce;
     D.skin = skin;
+    ctx->skin = skin;
     D.cutneigh = cutforce + skin;
     D.every = every;
     D.delay = delay;

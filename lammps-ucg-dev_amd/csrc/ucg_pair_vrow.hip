@@ -12,9 +12,10 @@
 //   * an entry whose neighbour is a bead of the same block is kept only in the row of the lower-indexed bead: the pair
 //     is then evaluated once, and what the reference's half-list sweep adds to the partner
 //     (UCG/pair_table_ucgld.cpp:500-502, 514-517, 523-530) is formed by the same lane;
-//   * the block's kept entries form three lists -- P: own-block pairs inside the force cutoff at build time, Q: the
-//     other entries inside the cutoff, S: everything in the skin -- so that the lanes of a wavefront run the same code
-//     (P: the partner's terms always, Q: never) and run the heavy body together;
+//   * the block's kept entries form five lists -- P: own-block pairs inside the force cutoff at build time, Q: the
+//     other entries inside the cutoff, S1..S3: the thirds of the skin, nearest first -- so that the lanes of a
+//     wavefront run the same code (P: the partner's terms always, Q: never) and run the heavy body together (a skin
+//     entry that has drifted inside the cutoff is most likely one of S1: the other skin lists stay light);
 //   * in each list a bead's entries are padded to a multiple of VR_ALIGN, the beads' padded lists are concatenated in
 //     bead order and cut into 1024 pieces of equal length: piece l is virtual row l, stored transposed
 //     ([slot][lane], 64 consecutive ints per wavefront and slot).  The first entry of a bead carries VR_FLAG;
@@ -38,7 +39,8 @@ constexpr int VR_LANES = PAIR_BLOCK;
 constexpr int VR_ALIGN = 4;
 constexpr int VR_FLAG = 1 << 30;
 constexpr int VR_DUMMY = (int) 0x80000000u;  // bit 31: a padding slot (its index field holds the block's first bead)
-constexpr int VR_MAXROW = 128;               // entries of a full row the builder can classify (2 bits each in registers)
+constexpr int VR_MAXROW = 128;               // entries of a full row the builder can classify (4 bits each in registers)
+constexpr int VR_NLIST = 5;                  // P, Q, S1, S2, S3
 constexpr int VR_STAGE_WORDS = 36 * 1024;    // LDS staging of one list of one block: 1024 lanes x (T + 1) ints
 
 // ------------------------------------------------------------------------------------------------ building the rows
@@ -53,18 +55,21 @@ __device__ __forceinline__ int roundup_align(int n) { return ((n + VR_ALIGN - 1)
 //  3. list by list: the threads walk their rows again (L2) and put the kept entries at their places in an LDS image of
 //     the transposed list, then the whole workgroup writes that image out with coalesced stores, together with every
 //     lane's first bead and entry count.
+struct VrowLists {
+  int *ent[VR_NLIST];
+};
+
 __global__ __launch_bounds__(VR_BEADS) void k_vrow_build(const int nlocal, const int na1, const double4 *pos4, const int *meta,
-                                                        const double *cutsq, const int *numneigh, const int *neigh,
-                                                        const int pitch, int *entP, int *entQ, int *entS, const int capP,
-                                                        const int capQ, const int capS, const int vpitch, int2 *lanemeta,
-                                                        int *errflag)
+                                                        const double *cutsq, const double skin, const int *numneigh,
+                                                        const int *neigh, const int pitch, const VrowLists lists, const int cap,
+                                                        const int vpitch, int2 *lanemeta, int *errflag)
 {
   extern __shared__ int s_stage[];
-  __shared__ int s_scan[3][VR_BEADS];
+  __shared__ int s_scan[VR_NLIST][VR_BEADS];
   const int blk = blockIdx.x, i = threadIdx.x, k0 = blk * VR_BEADS, k = k0 + i;
   const bool live = k < nlocal;
-  unsigned long long cls[VR_MAXROW / 32];  // 2 bits per entry: 0 dropped, 1 P, 2 Q, 3 S
-  int cnt[3] = {0, 0, 0};
+  unsigned long long cls[VR_MAXROW / 16];  // 4 bits per entry: 0 dropped, 1 + list
+  int cnt[VR_NLIST] = {0, 0, 0, 0, 0};
   int n = 0;
   if (live) {
     n = numneigh[k];
@@ -75,10 +80,10 @@ __global__ __launch_bounds__(VR_BEADS) void k_vrow_build(const int nlocal, const
     const double4 pk = pos4[k];
     const int tk = UCG_META_TYPE(meta[k]);
 #pragma unroll
-    for (int c = 0; c < VR_MAXROW / 32; c++) {
+    for (int c = 0; c < VR_MAXROW / 16; c++) {
       unsigned long long w = 0ull;
-      const int e1 = min(n, 32 * c + 32);
-      for (int e = 32 * c; e < e1; e++) {
+      const int e1 = min(n, 16 * c + 16);
+      for (int e = 16 * c; e < e1; e++) {
         const int m = neigh[(size_t) e * pitch + k] & 0x1FFFFFFF;
         const bool own = m >= k0 && m < k0 + VR_BEADS && m < nlocal;
         if (own && m <= k) continue;  // the pair lives in the lower bead's row
@@ -86,34 +91,41 @@ __global__ __launch_bounds__(VR_BEADS) void k_vrow_build(const int nlocal, const
         const int tm = UCG_META_TYPE(meta[m]);
         const double dx = pk.x - pm.x, dy = pk.y - pm.y, dz = pk.z - pm.z;
         const double rsq = dx * dx + dy * dy + dz * dz;
-        const int c3 = rsq < cutsq[tk * na1 + tm] ? (own ? 0 : 1) : 2;
-        cnt[c3]++;
-        w |= (unsigned long long) (c3 + 1) << (2 * (e - 32 * c));
+        const double csq = cutsq[tk * na1 + tm];
+        int li;
+        if (rsq < csq) {
+          li = own ? 0 : 1;
+        } else {  // thirds of the skin (a heuristic only: any assignment gives the same sums)
+          const double rc = sqrt(csq), r1 = rc + skin * (1.0 / 3.0), r2 = rc + skin * (2.0 / 3.0);
+          li = rsq < r1 * r1 ? 2 : (rsq < r2 * r2 ? 3 : 4);
+        }
+#pragma unroll
+        for (int x = 0; x < VR_NLIST; x++) cnt[x] += li == x;
+        w |= (unsigned long long) (li + 1) << (4 * (e - 16 * c));
       }
       cls[c] = w;
     }
   }
-  // padded counts, inclusive scans (Hillis-Steele in LDS; 512 values, three lists)
-  int pad[3];
+  // padded counts, inclusive scans (Hillis-Steele in LDS; 512 values per list)
+  int pad[VR_NLIST];
 #pragma unroll
-  for (int x = 0; x < 3; x++) {
+  for (int x = 0; x < VR_NLIST; x++) {
     pad[x] = live ? roundup_align(cnt[x] > 0 ? cnt[x] : 1) : 0;  // a bead without entries still announces itself
     s_scan[x][i] = pad[x];
   }
   __syncthreads();
   for (int d = 1; d < VR_BEADS; d <<= 1) {
-    int a[3];
+    int a[VR_NLIST];
 #pragma unroll
-    for (int x = 0; x < 3; x++) a[x] = i >= d ? s_scan[x][i - d] : 0;
+    for (int x = 0; x < VR_NLIST; x++) a[x] = i >= d ? s_scan[x][i - d] : 0;
     __syncthreads();
 #pragma unroll
-    for (int x = 0; x < 3; x++) s_scan[x][i] += a[x];
+    for (int x = 0; x < VR_NLIST; x++) s_scan[x][i] += a[x];
     __syncthreads();
   }
 #pragma unroll
-  for (int x = 0; x < 3; x++) {
-    int *out = x == 0 ? entP : (x == 1 ? entQ : entS);
-    const int cap = x == 0 ? capP : (x == 1 ? capQ : capS);
+  for (int x = 0; x < VR_NLIST; x++) {
+    int *out = lists.ent[x];
     const int total = s_scan[x][VR_BEADS - 1];
     int T = roundup_align((total + VR_LANES - 1) / VR_LANES);
     T = T > 0 ? T : VR_ALIGN;
@@ -128,11 +140,11 @@ __global__ __launch_bounds__(VR_BEADS) void k_vrow_build(const int nlocal, const
       int lane = q / T, slot = q - lane * T;
       int j = 0;
 #pragma unroll
-      for (int c = 0; c < VR_MAXROW / 32; c++) {
+      for (int c = 0; c < VR_MAXROW / 16; c++) {
         const unsigned long long w = cls[c];
-        const int e1 = min(n, 32 * c + 32);
-        for (int e = 32 * c; e < e1; e++) {
-          if ((int) ((w >> (2 * (e - 32 * c))) & 3ull) != x + 1) continue;
+        const int e1 = min(n, 16 * c + 16);
+        for (int e = 16 * c; e < e1; e++) {
+          if ((int) ((w >> (4 * (e - 16 * c))) & 15ull) != x + 1) continue;
           const int ent = neigh[(size_t) e * pitch + k];
           s_stage[lane * Tp + slot] = (ent & 0x3FFFFFFF) | (j == 0 ? VR_FLAG : 0);
           j++;
@@ -164,7 +176,7 @@ __global__ __launch_bounds__(VR_BEADS) void k_vrow_build(const int nlocal, const
         if (s_scan[x][mid] > q0) hi = mid;
         else lo = mid + 1;
       }
-      lanemeta[((size_t) blk * VR_LANES + l) * 3 + x] = make_int2(lo, c);
+      lanemeta[((size_t) blk * VR_LANES + l) * VR_NLIST + x] = make_int2(lo, c);
     }
     __syncthreads();
   }
@@ -173,7 +185,7 @@ __global__ __launch_bounds__(VR_BEADS) void k_vrow_build(const int nlocal, const
 // ------------------------------------------------------------------------------------------------------ the sweep
 
 struct VrowDev {
-  const int *entP, *entQ, *entS;
+  const int *ent[VR_NLIST];
   const int2 *lanemeta;
   int vpitch;
 };
@@ -232,7 +244,7 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_vrow(const PairDev P, const
   const int vlane = blk * VR_LANES + (int) threadIdx.x;
 
   // one pass over one of the block's lists.  MODE 0: list P (every entry's partner is a bead of the block: its data
-  // come from LDS, its terms are formed), 1: list Q (no partner terms; gathers through L2), 2: list S (either kind)
+  // come from LDS, its terms are formed), 1: list Q (no partner terms; gathers through L2), 2: the skin lists (either kind)
   auto sweep = [&](auto mode_c, const int *ve, const int2 mt) {
     constexpr int MODE = decltype(mode_c)::value;
     const int cnt = mt.y;
@@ -506,11 +518,10 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_vrow(const PairDev P, const
     flush();
   };
 
-  const int2 *lm3 = V.lanemeta + (size_t) vlane * 3;
-  const int2 mtP = lm3[0], mtQ = lm3[1], mtS = lm3[2];
-  sweep(std::integral_constant<int, 0>{}, V.entP, mtP);
-  sweep(std::integral_constant<int, 1>{}, V.entQ, mtQ);
-  sweep(std::integral_constant<int, 2>{}, V.entS, mtS);
+  const int2 *lmv = V.lanemeta + (size_t) vlane * VR_NLIST;
+  sweep(std::integral_constant<int, 0>{}, V.ent[0], lmv[0]);
+  sweep(std::integral_constant<int, 1>{}, V.ent[1], lmv[1]);
+  for (int x = 2; x < VR_NLIST; x++) sweep(std::integral_constant<int, 2>{}, V.ent[x], lmv[x]);
   __syncthreads();  // every lane of the workgroup has made its adds
 
   const int k = k0 + (int) threadIdx.x;
@@ -586,6 +597,7 @@ hipError_t launch_vrow_ts(const PairDev &P, const AtomsDev &A, const ListDev &L,
 int vrow_blocks(int nlocal) { return (nlocal + VR_BEADS - 1) / VR_BEADS; }
 int vrow_beads() { return VR_BEADS; }
 int vrow_maxrow() { return VR_MAXROW; }
+int vrow_lists() { return VR_NLIST; }
 
 // slots per lane the lists of a full list with rows of at most `maxrow` entries can need: a block's kept entries are at
 // most VR_BEADS * (maxrow + padding), cut into VR_LANES pieces
@@ -599,29 +611,34 @@ size_t vrow_lds_bytes(const PairDev &P)
 }
 
 // the virtual rows of every block, from the resident full rows
-hipError_t launch_vrow_build(const PairDev &P, const AtomsDev &A, const ListDev &L, int *entP, int *entQ, int *entS, int cap,
-                             int vpitch, int2 *lanemeta, int *errflag, hipStream_t st)
+hipError_t launch_vrow_build(const PairDev &P, const AtomsDev &A, const ListDev &L, double skin, int *ent, size_t list_stride,
+                             int cap, int vpitch, int2 *lanemeta, int *errflag, hipStream_t st)
 {
   const int nb = vrow_blocks(A.nlocal);
   if (nb == 0) return hipSuccess;
   const size_t lds = (size_t) VR_STAGE_WORDS * sizeof(int);
   hipError_t e = hipFuncSetAttribute((const void *) k_vrow_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_vrow_build, dim3(nb), dim3(VR_BEADS), lds, st, A.nlocal, P.n_actual + 1, A.pos4, A.meta, P.cutsq, L.numneigh,
-                     L.neigh, L.pitch, entP, entQ, entS, cap, cap, cap, vpitch, lanemeta, errflag);
+  VrowLists lists;
+  for (int x = 0; x < VR_NLIST; x++) lists.ent[x] = ent + (size_t) x * list_stride;
+  hipLaunchKernelGGL(k_vrow_build, dim3(nb), dim3(VR_BEADS), lds, st, A.nlocal, P.n_actual + 1, A.pos4, A.meta, P.cutsq, skin,
+                     L.numneigh, L.neigh, L.pitch, lists, cap, vpitch, lanemeta, errflag);
   return hipGetLastError();
 }
 
-hipError_t launch_pair_vrow(const PairDev &P, const AtomsDev &A, const ListDev &L, const int *entP, const int *entQ,
-                            const int *entS, const int2 *lanemeta, int vpitch, bool ev, double *evpart, double *evout,
-                            int *errflag, hipStream_t st)
+hipError_t launch_pair_vrow(const PairDev &P, const AtomsDev &A, const ListDev &L, const int *ent, size_t list_stride,
+                            const int2 *lanemeta, int vpitch, bool ev, double *evpart, double *evout, int *errflag,
+                            hipStream_t st)
 {
   const int nblocks = vrow_blocks(A.nlocal);
   if (nblocks == 0) return hipSuccess;
   if (!P.fast || !P.tab_in_lds || P.tabstyle == 3) return hipErrorInvalidValue;
   const size_t lds = vrow_lds_bytes(P);
   if (lds + 4608 > 160 * 1024) return hipErrorInvalidValue;
-  VrowDev V{entP, entQ, entS, lanemeta, vpitch};
+  VrowDev V;
+  for (int x = 0; x < VR_NLIST; x++) V.ent[x] = ent + (size_t) x * list_stride;
+  V.lanemeta = lanemeta;
+  V.vpitch = vpitch;
   hipError_t e;
 #define UCG_VTS(ST)                                                                                               \
   switch (P.tabstyle) {                                                                                           \

@@ -51,14 +51,14 @@ def main():
     beads = pkg.synth.make_beads(5, seed=2024)
     beads.ucgp = np.clip(np.random.default_rng(7).uniform(size=beads.n), 1e-6, 1 - 1e-6)
     cases = {}
-    # sum_fixed: the summation mode the library takes for the deck (include/ucg_hip.h, ucg_pair_sum_fixed): fixed sums on
-    # virtual rows where the tables fit the LDS, else ordered sums; "*_ordered" = the same deck with option pair_vrow 0
-    for name, style, kw, extra, fixed in (("ucgld_spline1024", "table_ucgld", {}, (), True),
-                                          ("ucgld_spline1024_ordered", "table_ucgld", {}, (), False),
+    # sum_fixed: the summation mode of the library pair the vectors are for (include/ucg_hip.h, ucg_pair_sum_fixed): ordered
+    # sums by default, fixed sums for the "*_vrow" cases (the same deck with option pair_vrow 1: the virtual-row kernels)
+    for name, style, kw, extra, fixed in (("ucgld_spline1024", "table_ucgld", {}, (), False),
+                                          ("ucgld_spline1024_vrow", "table_ucgld", {}, (), True),
                                           ("ucgld_linear2000", "table_ucgld", dict(tabstyle="linear", tablength=2000), (), False),
-                                          ("bethe_pseudo_yes", "table_ucg_bethe", {}, ("pseudo", "yes"), True),
-                                          ("bethe_pseudo_yes_ordered", "table_ucg_bethe", {}, ("pseudo", "yes"), False),
-                                          ("bethe_mf", "table_ucg_bethe", {}, ("method", "mf"), True),
+                                          ("bethe_pseudo_yes", "table_ucg_bethe", {}, ("pseudo", "yes"), False),
+                                          ("bethe_pseudo_yes_vrow", "table_ucg_bethe", {}, ("pseudo", "yes"), True),
+                                          ("bethe_mf", "table_ucg_bethe", {}, ("method", "mf"), False),
                                           ("density", "table_ucg_bethe_density", dict(density=(11.3, 1.5), extra11=0.05), (), False)):
         deck = util.make_deck(kw.get("tabstyle", "spline"), kw.get("tablength", 1024), extra_keywords=extra,
                               **{k: v for k, v in kw.items() if k in ("density", "extra11")})
@@ -72,7 +72,7 @@ def main():
         e0 = sim.ev()["eng_vdwl"]
         assert sim.run(10, 0) == 0
         A1 = sim.arrays()
-        cases[name] = dict(style=style, sum_fixed=fixed, pair_vrow=0 if name.endswith("_ordered") else 1, tabstyle=deck.tabstyle, tablength=deck.tablength, extra=list(extra),
+        cases[name] = dict(style=style, sum_fixed=fixed, pair_vrow=1 if name.endswith("_vrow") else 0, tabstyle=deck.tabstyle, tablength=deck.tablength, extra=list(extra),
                            deck_kw={k: v for k, v in kw.items() if k in ("density", "extra11")},
                            table_sha256=file_sha(deck.table_file),
                            setup=dict(tag=inta(A0["tag"]), f=hexa(A0["f"]), scores=hexa(A0["scores"]),

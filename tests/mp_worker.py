@@ -59,6 +59,7 @@ def main():
         ctx.atoms_upload(n, 0, beads.ntypes, beads.x[sl], beads.v[sl], beads.type[sl], beads.tag[sl], beads.mask[sl],
                          beads.ucgstate[sl], beads.ucgl[sl], beads.ucgvl[sl], beads.ucgml[sl], beads.ucgp[sl], beads.mass)
         ctx.domain_set(beads.boxlo, beads.boxhi, 2.5, 0.3, every=2, delay=0, check=1)
+        ctx.set_option("pair_vrow", int(os.environ.get("UCG_TEST_PAIR_VROW", "0")))  # 1: the virtual-row kernels
         pair = util.gpu_pair(ctx, "table_ucgld", deck)
         ctx.set_option("rng_batch", int(os.environ.get("UCG_TEST_RNG_BATCH", "10")))
         ctx.fix_ucgld_langevin(1.0, 1.0, 1.0, 48279, me=rank)
@@ -90,6 +91,7 @@ def main():
         ctx.atoms_upload(n, 0, beads.ntypes, beads.x[sl], beads.v[sl], beads.type[sl], beads.tag[sl], beads.mask[sl],
                          beads.ucgstate[sl], beads.ucgl[sl], beads.ucgvl[sl], beads.ucgml[sl], beads.ucgp[sl], beads.mass)
         ctx.domain_set(beads.boxlo, beads.boxhi, 2.5, 0.3, every=2, delay=0, check=1)
+        ctx.set_option("pair_vrow", int(os.environ.get("UCG_TEST_PAIR_VROW", "0")))  # 1: the virtual-row kernels
         pair = util.gpu_pair(ctx, "table_ucgld", deck)
         tr = multi.Transport(dist, torch.device("cuda", 0), staged=True)
         sim = multi.RankSim(ctx, pair, tr, grid, use_langevin=False, use_ucgstate=False)
@@ -194,6 +196,7 @@ def main():
         ctx.atoms_upload(n, 0, beads.ntypes, beads.x[sl], beads.v[sl], beads.type[sl], beads.tag[sl], beads.mask[sl],
                          beads.ucgstate[sl], beads.ucgl[sl], beads.ucgvl[sl], beads.ucgml[sl], beads.ucgp[sl], beads.mass)
         ctx.domain_set(beads.boxlo, beads.boxhi, 2.5, 0.3, every=2, delay=0, check=1)
+        ctx.set_option("pair_vrow", int(os.environ.get("UCG_TEST_PAIR_VROW", "0")))  # 1: the virtual-row kernels
         pair = util.gpu_pair(ctx, style, deck)
         tr = multi.Transport(dist, torch.device("cuda", 0), staged=True)
         sim = multi.RankSim(ctx, pair, tr, grid, use_langevin=False, use_ucgstate=False)

@@ -49,7 +49,7 @@ def _fixes(case):
     return ((1.0, 1.0, 1.0, 48279) if ucgld else None), ("ld" if ucgld else ("mc", 4242, 0.3))
 
 
-CASES = ["ucgld_spline1024", "ucgld_spline1024_ordered", "ucgld_linear2000", "bethe_pseudo_yes", "bethe_pseudo_yes_ordered",
+CASES = ["ucgld_spline1024", "ucgld_spline1024_vrow", "ucgld_linear2000", "bethe_pseudo_yes", "bethe_pseudo_yes_vrow",
          "bethe_mf", "density"]
 
 
@@ -101,8 +101,7 @@ def test_gpu_reproduces_golden(fresh_ctx, pkg, name):
     ctx.set_units(1.0, 1.0, 1.0, 0.004)
     ctx.upload_beads(beads)
     ctx.domain_set(beads.boxlo, beads.boxhi, 2.5, 0.3, every=1, delay=0, check=1)
-    if not case["pair_vrow"]:
-        ctx.set_option("pair_vrow", 0)
+    ctx.set_option("pair_vrow", case["pair_vrow"])
     gp = util.gpu_pair(ctx, case["style"], deck)
     assert gp.sum_fixed == case["sum_fixed"]  # the summation mode the vectors were made in
     if lang:

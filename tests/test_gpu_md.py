@@ -132,21 +132,21 @@ def test_md_trajectory_bitwise(fresh_ctx, pkg, orc, style, extra, langevin, ucgs
         assert 0 < G["ucgstate"].sum() < beads.n
 
 
-@pytest.mark.parametrize("options", [dict(post_in_pair=0), dict(post_in_pair=0, md_no_fuse=1), dict(pair_vrow=0),
-                                     dict(pair_vrow=0, post_in_pair=0), dict(pair_vrow=0, gather_slots=4)])
+@pytest.mark.parametrize("options", [dict(post_in_pair=0), dict(post_in_pair=0, md_no_fuse=1), dict(gather_slots=4),
+                                     dict(pair_vrow=1), dict(pair_vrow=1, post_in_pair=0)])
 @pytest.mark.parametrize("style,ucgstate", [("table_ucgld", "ld"), ("table_ucg_bethe", ("mc", 9127, 0.2))])
 def test_resident_loop_variants_give_the_same_bits(fresh_ctx, pkg, orc, style, ucgstate, options):
     """the resident loop has three forms of an ordinary step -- hooks in the gather kernel's epilogue (default), pair
     kernel + fused per-bead kernel (post_in_pair = 0), and that with initial_integrate as its own launch
     (md_no_fuse = 1): all must reproduce the oracle bit for bit (the other trajectory tests run the default) -- on the
-    virtual-row kernels (default: fixed sums) and on the full-row gather kernels (pair_vrow = 0: ordered sums, whose
-    order the lanes per bead are part of)"""
+    full-row gather kernels (ordered sums, whose order the lanes per bead are part of) and on the virtual-row kernels
+    (option pair_vrow: fixed sums)"""
     deck = util.make_deck("spline", 1024)
     beads = pkg.synth.make_beads(8, seed=77)
     lang = (1.0, 1.0, 1.0, 48279) if style == "table_ucgld" else None
     slots = options.get("gather_slots", 1)
     op = util.oracle_pair(style, deck, slots=slots)
-    op.set_sum_fixed(options.get("pair_vrow", 1) == 1)
+    op.set_sum_fixed(options.get("pair_vrow", 0) == 1)
     sim = util.oracle_sim(beads, op, mode=1, dt=0.004, langevin=lang, nve=True, ucgstate=ucgstate, every=2)
     assert sim.setup(50) == 0 and sim.run(50, 20) == 0
     ctx = fresh_ctx
@@ -154,7 +154,7 @@ def test_resident_loop_variants_give_the_same_bits(fresh_ctx, pkg, orc, style, u
     for k, v in options.items():
         ctx.set_option(k, v)
     gp = util.gpu_pair(ctx, style, deck)
-    assert gp.sum_fixed == (options.get("pair_vrow", 1) == 1)
+    assert gp.sum_fixed == (options.get("pair_vrow", 0) == 1)
     if lang:
         ctx.fix_ucgld_langevin(*lang)
     if ucgstate == "ld":

@@ -368,14 +368,14 @@ def test_gather_slots_define_the_canonical_order(fresh_ctx, pkg, orc, slots, sty
 @pytest.mark.parametrize("slots", [0, 1, 4, 16])
 def test_interior_and_boundary_launches_add_up(fresh_ctx, pkg, style, slots):
     """ucg_pair_compute_part 1 (workgroups without ghost neighbours) + 2 (the rest) == ucg_pair_compute; slots 0 = the
-    virtual-row kernels (512 beads per workgroup), else the full-row gather kernels with that many lanes per bead"""
+    virtual-row kernels (option pair_vrow: 512 beads per workgroup), else the full-row gather kernels with that many
+    lanes per bead"""
     ctx = fresh_ctx
     deck = util.make_deck("spline", 1024)
     beads = pkg.synth.make_beads(30, seed=4)
     beads.ucgp = np.clip(np.random.default_rng(1).uniform(size=beads.n), 1e-6, 1 - 1e-6)
     ctx.set_units(1.0, 1.0, 1.0, 0.002)
-    if slots:
-        ctx.set_option("pair_vrow", 0)
+    ctx.set_option("pair_vrow", 0 if slots else 1)
     ctx.set_option("gather_slots", slots if slots else 1)
     ctx.upload_beads(beads)
     ctx.domain_set(beads.boxlo, beads.boxhi, 2.5, 0.3, every=1, delay=0, check=1)

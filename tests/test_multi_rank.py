@@ -264,15 +264,19 @@ def test_a_rank_local_failure_stops_every_rank_together(pkg):
 
 
 @pytest.mark.gpu
-def test_world2_thermostatted_run_equals_the_decomposed_oracle_bit_for_bit(pkg, orc):
+@pytest.mark.parametrize("vrow", [0, 1])
+def test_world2_thermostatted_run_equals_the_decomposed_oracle_bit_for_bit(pkg, orc, vrow, monkeypatch):
     """fix ucgld/langevin + fix ucgstate mc + fix nve/ucgld/wall/hard on two ranks against the oracle's statement of the
     same decomposed run (oracle/orc_md.c: orc_world -- bricks, per-rank bead order, RanMars(seed + me) streams drawn in
     local order, migration): every rank's beads in its local order, positions, velocities, lambda and states after 360
-    steps with migration, bit for bit; and the bead counts of the ranks along the run"""
+    steps with migration, bit for bit; and the bead counts of the ranks along the run.  vrow = 1: the virtual-row kernels
+    (option pair_vrow) against the oracle's fixed sums -- which depend on no order, the decomposition included"""
+    monkeypatch.setenv("UCG_TEST_PAIR_VROW", str(vrow))
     res = _launch("gpu_lang", world=2)
     deck = util.make_deck("spline", 1024)
     beads = pkg.synth.make_beads(10, seed=5)
     op = util.oracle_pair("table_ucgld", deck)
+    op.set_sum_fixed(bool(vrow))
     w = orc.World(beads, [2, 1, 1])
     w.set_run_params(dt=0.004, every=2, delay=0, check=1)
     w.attach(op, langevin=(1.0, 1.0, 1.0, 48279), nve="wall", ucgstate=("mc", 9127, 0.3))
@@ -293,15 +297,18 @@ def test_world2_thermostatted_run_equals_the_decomposed_oracle_bit_for_bit(pkg, 
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 4])
-def test_decomposed_forces_and_trajectory_equal_the_decomposed_oracle_bit_for_bit(pkg, orc, world):
+@pytest.mark.parametrize("world,vrow", [(2, 0), (4, 0), (2, 1)])
+def test_decomposed_forces_and_trajectory_equal_the_decomposed_oracle_bit_for_bit(pkg, orc, world, vrow, monkeypatch):
     """2 x 1 x 1 and 2 x 2 x 1 bricks: forces, ucgforce and scores of every rank at setup and positions / lambda after 40
     steps with re-neighbouring, in each rank's local order, against orc_world -- the canonical order of a decomposed run
-    is a function of the decomposition, and the oracle states it"""
+    is a function of the decomposition, and the oracle states it (vrow = 1: the virtual-row kernels, whose fixed sums
+    are not)"""
+    monkeypatch.setenv("UCG_TEST_PAIR_VROW", str(vrow))
     res = _launch("gpu", world=world)
     deck = util.make_deck("spline", 1024)
     beads = pkg.synth.make_beads(10, seed=5)
     op = util.oracle_pair("table_ucgld", deck)
+    op.set_sum_fixed(bool(vrow))
     w = orc.World(beads, pkg.multi.choose_procgrid(world))
     w.set_run_params(dt=0.004, every=2, delay=0, check=1)
     w.attach(op, langevin=None, nve=True, ucgstate=None)
