@@ -84,11 +84,6 @@ int ucg_ctx_set_units(ucg_ctx *ctx, double boltz, double ftm2v, double mvv2e, do
  *   "post_in_pair"  per-bead hooks in the gather kernel's epilogue (default 1), "md_no_fuse" = 1 runs every hook as
  *                   its own kernel
  *   "rows_untiled"  = 1 builds neighbour rows with the one-lane-per-bead kernels (the fallback of the tiled builder)
- *   "pair_once"     = 1 (table_ucgld, tables in LDS; set before ucg_neigh_rebuild) rows hold a pair of two owned beads of
- *                   one 512-bead workgroup block in ONE of their rows only; that lane also forms the partner's terms and
- *                   adds them as 2^-40 fixed-point integers (order-independent, so still bit-reproducible: its own
- *                   canonical order).  A term >= 2048 in magnitude sets error bit 4 and
- *                   ucg_pair_check_errors returns UCG_ERR_UNSUPPORTED: rerun without the option.  Off by default.
  *   "pair_vrow"     = 1 (set before ucg_pair_init) table_ucgld / table_ucg_bethe whose tables fit the LDS (one shared
  *                   r^2 grid, no BITMAP tables) run on balanced virtual rows: the pairs of two beads of one 512-bead
  *                   workgroup block are evaluated once, and a bead's terms are summed as fixed sums (ucg_pair_sum_fixed).

@@ -620,7 +620,7 @@ class Context:
         out = np.zeros(16, np.int64)
         self.chk(self.L.ucg_md_info(self.h, out.ctypes.data_as(c_ll_p)))
         keys = ["ntimestep", "nrebuild", "nlocal", "nghost", "list_entries", "pair_error_steps", "maxrow", "pitch",
-                "nbx", "nby", "nbz", "once_beads", "once_maxin"]
+                "nbx", "nby", "nbz"]
         return dict(zip(keys, [int(v) for v in out[:len(keys)]]))
 
     def md_thermo(self):

@@ -99,7 +99,6 @@ ListDev ucg_ctx::list_dev() const
   L.numneigh = numneigh.get();
   L.blockflag = nullptr;
   L.blockwant = 0;
-  L.once_beads = list_once_beads;
   L.post = PostDev{};
   return L;
 }
@@ -415,16 +414,6 @@ int ucg_pair_init(ucg_pair *p, int ntypes, double T)
       if (bitmap && ctx->gather_slots > 1)
         return fail(ctx, UCG_ERR_UNSUPPORTED, "bitmap tables run with one lane per bead (option gather_slots 0 or 1)");
       int slots0 = ctx->gather_slots > 0 ? ctx->gather_slots : 1;
-      // option pair_once: table_ucgld with its tables, 512 own beads (36 B each) and their 6 fixed-point
-      // accumulators (48 B each) in the 160 KB of LDS next to the static model arrays; two lanes per bead
-      p->once = ctx->pair_once && M.style == STYLE_UCGLD && fast && D.tab_in_lds && ctx->stage_own && !ctx->fma_contract &&
-                bytes + 512 * (36 + 48) + 4608 <= 160 * 1024;
-      if (p->once) {
-        slots0 = 2;
-        ctx->once_beads_wanted = 512;
-      } else if (ctx->pair_once) {
-        ctx->once_beads_wanted = 0;
-      }
       // option pair_vrow (off by default): both gather styles on virtual rows (ucg_pair_vrow.hip) when the tables, 512 own beads
       // and their fixed-point accumulators fit the LDS next to the static model arrays.  Decided here, once: it fixes how
       // a bead's terms are summed (fixed sums, ucg_pair_sum_fixed), which callers comparing bits need to know.
@@ -435,7 +424,7 @@ int ucg_pair_init(ucg_pair *p, int ntypes, double T)
         D.sum_dec[c] = std::ldexp(1.0, -38);
       }
       D.sum_rsq_safe = 1.0e300;
-      if (ctx->pair_vrow && !p->once && (M.style == STYLE_UCGLD || M.style == STYLE_BETHE) && fast && D.tab_in_lds && !bitmap &&
+      if (ctx->pair_vrow && (M.style == STYLE_UCGLD || M.style == STYLE_BETHE) && fast && D.tab_in_lds && !bitmap &&
           !ctx->fma_contract) {
         PairDev probe = D;
         probe.fast = 1;
@@ -693,12 +682,7 @@ static int pair_compute_impl(ucg_pair *p, int eflag, int vflag, double *eng_vdwl
         if (ctx->special_lj[i] != 1.0)
           return fail(ctx, UCG_ERR_UNSUPPORTED, "the device list builder knows no bond topology (no special-bond bits): "
                                                 "special_lj other than 1 needs a list uploaded with ucg_neigh_upload_full");
-    if (ctx->list_once_beads > 0 && !p->once)
-      return fail(ctx, UCG_ERR_INVALID, "the neighbour rows were built for option pair_once (own-block pairs in one row only); "
-                                        "this pair style cannot sweep them");
-    if (p->once && ctx->list_once_maxin > 2048)
-      return fail(ctx, UCG_ERR_UNSUPPORTED, "option pair_once: a bead is the partner of more than 2048 own-block pairs");
-    if (ctx->gather_slots == 0 && p->dev.tabstyle != BITMAP && !p->once) {
+    if (ctx->gather_slots == 0 && p->dev.tabstyle != BITMAP) {
       // auto: the kernel's time is (rounds of workgroups over the 256 CUs) x (lifetime of one workgroup),
       // the latter ~ row length / lanes per bead + a fixed part; pick the lanes per bead that minimise it
       // (matches the measured order at 125 k / 250 k / 500 k / 1 M beads per GPU)
@@ -897,8 +881,7 @@ int ucg_pair_check_errors(ucg_pair *p)
     if (p->vrow)
       return fail(ctx, UCG_ERR_UNSUPPORTED, "a pair term left the range of the fixed sums (|term| >= 2^24 units of the tables' "
                                             "reference force / energy): the tables or lambda are far outside any physical range");
-    return fail(ctx, UCG_ERR_UNSUPPORTED, "option pair_once: a pair term left the range of the fixed-point accumulators "
-                                          "(|term| >= 2048); run without the option");
+    return fail(ctx, UCG_ERR_HIP, "a pair kernel reported an unknown error flag");
   });
 }
 
@@ -1142,10 +1125,8 @@ int ucg_neigh_upload_full(ucg_ctx *ctx, int inum, const int *numneigh, const lon
     ctx->list_pitch = pitch;
     ctx->list_maxrow = maxrow;
     ctx->list_entries = total;
-    ctx->list_stored = total;
     ctx->list_from_builder = false;
     ctx->list_gen++;
-    ctx->list_once_beads = 0;  // a caller's full list holds every pair in both rows
     return UCG_OK;
   });
 }
@@ -1155,7 +1136,7 @@ int ucg_neigh_download(ucg_ctx *ctx, int *inum, int *numneigh, long long *first,
   if (!ctx) return UCG_ERR_INVALID;
   return guarded(ctx, [&]() -> int {
     if (inum) *inum = ctx->list_inum;
-    if (total) *total = ctx->list_stored;
+    if (total) *total = ctx->list_entries;
     if (!numneigh && !neigh) return UCG_OK;
     const int n = ctx->list_inum;
     std::vector<int> nn((size_t) n);
@@ -1636,11 +1617,6 @@ int ucg_ctx_set_option(ucg_ctx *ctx, const char *name, int value)
   }
   if (std::strcmp(name, "pair_vrow") == 0) {
     ctx->pair_vrow = value != 0;
-    return UCG_OK;
-  }
-  if (std::strcmp(name, "pair_once") == 0) {
-    ctx->pair_once = value != 0;
-    if (!ctx->pair_once) ctx->once_beads_wanted = 0;
     return UCG_OK;
   }
   if (std::strcmp(name, "hot_block") == 0) {

@@ -144,8 +144,6 @@ struct ucg_ctx {
   bool fma_contract = false;           // option "fma_contract": gather kernels compiled with FMA contraction (not bit-exact)
   int rng_batch = 10;                  // option "rng_batch": steps of per-bead draws generated per k_ranmars launch (1 = one launch per step)
   bool rows_untiled = false;           // option "rows_untiled": build rows with the one-lane-per-bead kernels
-  bool pair_once = false;              // option "pair_once": own-block pairs evaluated once (see ucg_pair.hip, ONCE variants)
-  int once_beads_wanted = 0;           // set by ucg_pair_init when the option applies to that pair: beads per workgroup
   bool pair_vrow = false;              // option "pair_vrow" (default off: measured slower than the full-row kernels, DESIGN.md
                                        // 4.1): the gather styles run on virtual rows where they can (ucg_pair_vrow.hip:
                                        // own-block pairs once, fixed sums)
@@ -168,13 +166,10 @@ struct ucg_ctx {
   ucg::DevBuf<int> ghost_src;  // owned bead each ghost images (single-rank periodic images)
   bool ghost_src_valid = false;
   int list_pitch = 0, list_maxrow = 0, list_inum = 0;
-  long long list_entries = 0;  // as a FULL list (an own-block pair kept in one row of pair_once rows counts twice)
-  long long list_stored = 0;   // entries actually stored in the rows
+  long long list_entries = 0;  // entries of the full list
   double skin = 0.0;           // Neighbor::skin as given to ucg_domain_set (0 when the caller builds the lists)
   long long list_gen = 0;      // changes whenever the rows change (device build or upload): what derived lists key on
   bool list_from_builder = false;  // rows made by the device builder (which sets no special-bond bits)
-  int list_once_beads = 0;   // > 0: the rows hold own-block pairs once (workgroups of this many beads)
-  int list_once_maxin = 0;   // ... and no bead is the partner of more than this many such pairs kept elsewhere
   // shared RanMars jump table
   ucg::DevBuf<unsigned int> rm_jump;
   int rm_chunks = 0;
@@ -233,7 +228,6 @@ struct ucg_pair {
   std::vector<int> tabmap;  // host table id -> device table id (or -1)
   std::string err;
   size_t tab_lds_bytes = 0;
-  bool once = false;  // option pair_once applies: gather_slots 2, rows with own-block pairs once
   // option pair_vrow applies (decided at ucg_pair_init: it fixes the summation mode, ucg_pair_sum_fixed): the virtual
   // rows made from the resident full rows (ucg_pair_vrow.hip)
   bool vrow = false;

@@ -104,9 +104,6 @@ struct ListDev {
   // workgroups that touch no ghost): run only workgroups with blockflag[chunk] == blockwant
   const int *blockflag;
   int blockwant;
-  // > 0: rows were built for the "own-block pairs once" kernels with workgroups of this many beads: a pair of
-  // two beads of one workgroup is in the row of ONE of them only (ucg_neigh.hip: once_evaluates)
-  int once_beads;
   PostDev post;
 };
 

@@ -42,7 +42,6 @@ struct Domain {
   DevBuf<int> bin_of, ghost_code, counter, rowclass, blockflags, blockoffset;
   DevBuf<int4> cells;     // per bin {owned start, owned end, ghost start, ghost end}
   DevBuf<int4> blockstat; // per brick of the tiled row builder {max row, max skin, entries, -}
-  DevBuf<int2> blockdrop; // ... {most entries dropped from one row, entries dropped} (pair_once rows)
   DevBuf<double4> bpos;   // builder records {x, y, z, (double) tag}
   DevBuf<double4> xhold, tmp4;
   DevBuf<unsigned long long> keys_in, keys_out;
@@ -61,9 +60,6 @@ struct DomainDev {
   int nbin[3], sten[3];
   double cutneighsq, triggersq;
   double cls_sq[3];  // build-time distance classes of a row: force cutoff, then thirds of the skin
-  // "own-block pairs once" rows (option pair_once): > 0 = log2 of the beads per workgroup of the gather kernel; a
-  // pair of two OWNED beads of one workgroup is then kept in the row of one of them only (once_evaluates)
-  int once_shift, nlocal;
 };
 
 void domain_destroy(ucg_ctx *ctx)
@@ -92,8 +88,6 @@ DomainDev make_dev(const Domain &D)
     d.procgrid[k] = D.procgrid[k];
   }
   d.me = D.me;
-  d.once_shift = 0;
-  d.nlocal = 0;
   d.cutneighsq = D.cutneigh * D.cutneigh;
   d.triggersq = 0.25 * D.skin * D.skin;
   for (int c = 0; c < 3; c++) {
@@ -112,17 +106,6 @@ __device__ __forceinline__ int coord2bin(const DomainDev &D, double x, double y,
   by = by < 0 ? 0 : (by > D.nbin[1] - 1 ? D.nbin[1] - 1 : by);
   bz = bz < 0 ? 0 : (bz > D.nbin[2] - 1 ? D.nbin[2] - 1 : bz);
   return (bz * D.nbin[1] + by) * D.nbin[0] + bx;
-}
-
-// "own-block pairs once": does bead k (and not its partner m) keep the pair (k, m) in its row?  Antisymmetric
-// (exactly one of the two beads says yes) and balanced (a bead keeps every other one of its own-block partners,
-// whatever its place in the block), so every lane of the gather kernel does about the same work.  Pairs with a
-// ghost or with a bead of another workgroup stay in both rows.
-__device__ __forceinline__ bool once_drops(const DomainDev &D, const int k, const int m)
-{
-  if (D.once_shift == 0 || m >= D.nlocal || (k >> D.once_shift) != (m >> D.once_shift)) return false;
-  const bool k_evaluates = (k < m) != (((k + m) & 1) != 0);
-  return !k_evaluates;
 }
 
 // Morton (Z-order) code of a bin, 9 bits per dimension: beads sorted along this curve form
@@ -317,10 +300,10 @@ __global__ __launch_bounds__(NB) void k_rows_discover(const DomainDev D, int nlo
                                                      int *scratch, int pitch, int cap, const double3 binsize,
                                                      int *maxrow, unsigned long long *total)
 {
-  __shared__ int s_max[NB / 64], s_maxd[NB / 64];
-  __shared__ unsigned long long s_tot[NB / 64], s_totd[NB / 64];
+  __shared__ int s_max[NB / 64];
+  __shared__ unsigned long long s_tot[NB / 64];
   const int k = blockIdx.x * NB + threadIdx.x;
-  int cnt = 0, ndrop = 0;
+  int cnt = 0;
   if (k < nlocal) {
     const double4 pk = pos4[k];  // builder record: w = tag
     const double tk = pk.w;
@@ -357,8 +340,7 @@ __global__ __launch_bounds__(NB) void k_rows_discover(const DomainDev D, int nlo
               const double dely = pk.y - pm.y;
               const double delz = pk.z - pm.z;
               const double rsq = delx * delx + dely * dely + delz * delz;
-              if (rsq < D.cutneighsq && once_drops(D, k, m)) ndrop++;
-              else if (rsq < D.cutneighsq) {
+              if (rsq < D.cutneighsq) {
                 int rc;
                 if (rsq < D.cls_sq[0]) { rc = 0; c0++; }
                 else if (rsq < D.cls_sq[1]) { rc = 1; c1++; }
@@ -381,33 +363,24 @@ __global__ __launch_bounds__(NB) void k_rows_discover(const DomainDev D, int nlo
     rowclass[2 * pitch + k] = c2;
   }
   // block max / total -> one atomic each per block (integer: order-free)
-  int mx = cnt, mxd = ndrop;
-  unsigned long long tot = (unsigned long long) cnt, totd = (unsigned long long) ndrop;
+  int mx = cnt;
+  unsigned long long tot = (unsigned long long) cnt;
   for (int off = 32; off > 0; off >>= 1) {
     mx = max(mx, __shfl_down(mx, off, 64));
-    mxd = max(mxd, __shfl_down(mxd, off, 64));
     tot += __shfl_down(tot, off, 64);
-    totd += __shfl_down(totd, off, 64);
   }
   if ((threadIdx.x & 63) == 0) {
     s_max[threadIdx.x >> 6] = mx;
-    s_maxd[threadIdx.x >> 6] = mxd;
     s_tot[threadIdx.x >> 6] = tot;
-    s_totd[threadIdx.x >> 6] = totd;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int w = 1; w < NB / 64; w++) {
       mx = max(mx, s_max[w]);
-      mxd = max(mxd, s_maxd[w]);
       tot += s_tot[w];
-      totd += s_totd[w];
     }
     atomicMax(maxrow, mx);
     atomicAdd(total, tot);
-    // rowstat[4]: most entries dropped from one row (own-block pairs kept by the partner), rowstat[5]: their total
-    atomicMax(maxrow + 8, mxd);
-    atomicAdd(total + 4, totd);
   }
 }
 
@@ -462,17 +435,15 @@ struct __attribute__((aligned(16))) TileCand {
 // the bead are skipped; candidates are fetched four at a time and committed in order: class 0
 // (inside the force cutoff) straight to the front of the bead's row, the skin classes -- tagged
 // in bits 30-31 -- to a side buffer from which the caller appends them class by class.
-template <bool ONCE>
 __device__ __forceinline__ void tile_walk(const DomainDev &D, const double3 &binsize, const int k, const double4 &pk,
                                           const int tk, const int bx, const int by, const int bz, const int r0x,
                                           const int r0y, const int r0z, const int *s_start, const TileCand *s_cand,
-                                          int &c0, int &ns, int &ndrop, int *neigh, int *skin, const int pitch,
+                                          int &c0, int &ns, int *neigh, int *skin, const int pitch,
                                           const int cap, const int capskin)
 {
   const double prune = D.cutneighsq * (1.0 + 1.0e-9) + 1.0e-12;
   c0 = 0;
   ns = 0;
-  ndrop = 0;
   const int xlo_bin = max(bx - D.sten[0], 0), xhi_bin = min(bx + D.sten[0], D.nbin[0] - 1);
   for (int dz = -D.sten[2]; dz <= D.sten[2]; dz++) {
     const int cz = bz + dz;
@@ -514,10 +485,7 @@ __device__ __forceinline__ void tile_walk(const DomainDev &D, const double3 &bin
         for (int u = 0; u < 4; u++) {
           // branch-free bookkeeping (plain integer adds and selects: keeps the counters in registers); the
           // skin classes are only tagged here and counted when the side buffer is read back
-          const bool inlist = (j + u < j1) && (pm[u].idx != k) && (rsq[u] < D.cutneighsq);
-          const bool drop = ONCE && inlist && once_drops(D, k, pm[u].idx);  // plain rows: compiled out
-          const bool ok = inlist && !drop;
-          if (ONCE) ndrop += drop ? 1 : 0;
+          const bool ok = (j + u < j1) && (pm[u].idx != k) && (rsq[u] < D.cutneighsq);
           const int in0 = rsq[u] < D.cls_sq[0], in1 = rsq[u] < D.cls_sq[1], in2 = rsq[u] < D.cls_sq[2];
           const int cls = 3 - in0 - in1 - in2;
           const int orient = (tk <= pm[u].tag) ? 1 : 0;
@@ -534,16 +502,15 @@ __device__ __forceinline__ void tile_walk(const DomainDev &D, const double3 &bin
   }
 }
 
-template <bool ONCE>
 __global__ __launch_bounds__(TILE_B) void k_rows_tile(const DomainDev D, const double4 *pos4, const int *tag,
                                                       const int *bin_of, const int4 *cells, int *rowcount, int *neigh,
                                                       int *skin, int pitch, int cap, int capskin, const double3 binsize,
-                                                      const int3 nbrick, int4 *blockstat, int2 *blockdrop, int *fallback)
+                                                      const int3 nbrick, int4 *blockstat, int *fallback)
 {
   __shared__ TileCand s_cand[TILE_CAP];
   __shared__ int s_start[TILE_NREG + 1], s_cnt[TILE_NREG];
   __shared__ int s_range[4];  // first bead, end bead, owned beads in the brick's bins, staged candidates
-  __shared__ int s_max[TILE_B / 64], s_maxs[TILE_B / 64], s_maxd[TILE_B / 64], s_totd[TILE_B / 64];
+  __shared__ int s_max[TILE_B / 64], s_maxs[TILE_B / 64];
   __shared__ unsigned long long s_tot[TILE_B / 64];
   constexpr int NREG = TILE_NREG;
   const int t = threadIdx.x;
@@ -618,18 +585,16 @@ __global__ __launch_bounds__(TILE_B) void k_rows_tile(const DomainDev D, const d
     }
   }
   __syncthreads();
-  int mx = 0, mxs = 0, mxd = 0, totd = 0;
+  int mx = 0, mxs = 0;
   unsigned long long tot = 0;
   for (int k = kbeg + t; k < kend; k += TILE_B) {
     const double4 pk = pos4[k];
     const int tk = tag[k];
     const int b = bin_of[k];
     const int bx = b % D.nbin[0], by = (b / D.nbin[0]) % D.nbin[1], bz = b / (D.nbin[0] * D.nbin[1]);
-    int c0, ns, nd;
-    tile_walk<ONCE>(D, binsize, k, pk, tk, bx, by, bz, r0x, r0y, r0z, s_start, s_cand, c0, ns, nd, neigh, skin, pitch, cap, capskin);
+    int c0, ns;
+    tile_walk(D, binsize, k, pk, tk, bx, by, bz, r0x, r0y, r0z, s_start, s_cand, c0, ns, neigh, skin, pitch, cap, capskin);
     const int cnt = c0 + ns;
-    mxd = max(mxd, nd);
-    totd += nd;
     if (cnt <= cap && ns <= capskin) {
       // append the skin classes behind class 0, each in discovery order (the lane reads back its own writes):
       // count the classes, then place the entries
@@ -658,77 +623,58 @@ __global__ __launch_bounds__(TILE_B) void k_rows_tile(const DomainDev D, const d
   for (int off = 32; off > 0; off >>= 1) {
     mx = max(mx, __shfl_down(mx, off, 64));
     mxs = max(mxs, __shfl_down(mxs, off, 64));
-    mxd = max(mxd, __shfl_down(mxd, off, 64));
     tot += __shfl_down(tot, off, 64);
-    totd += __shfl_down(totd, off, 64);
   }
   if ((t & 63) == 0) {
     s_max[t >> 6] = mx;
     s_maxs[t >> 6] = mxs;
-    s_maxd[t >> 6] = mxd;
     s_tot[t >> 6] = tot;
-    s_totd[t >> 6] = totd;
   }
   __syncthreads();
   if (t == 0) {
     for (int w = 1; w < TILE_B / 64; w++) {
       mx = max(mx, s_max[w]);
       mxs = max(mxs, s_maxs[w]);
-      mxd = max(mxd, s_maxd[w]);
       tot += s_tot[w];
-      totd += s_totd[w];
     }
     // one record per brick (the fold kernel reduces them: same-address atomics from thousands of bricks serialise)
     blockstat[blockIdx.x] = make_int4(mx, mxs, (int) tot, 0);
-    blockdrop[blockIdx.x] = make_int2(mxd, totd);
   }
 }
 
 // maxima and total of the per-brick records -> rowstat {max row | total | (fallback flag, untouched) | max skin}
-__global__ __launch_bounds__(1024) void k_rowstat_fold(int nblocks, const int4 *blockstat, const int2 *blockdrop,
-                                                       unsigned long long *rowstat)
+__global__ __launch_bounds__(1024) void k_rowstat_fold(int nblocks, const int4 *blockstat, unsigned long long *rowstat)
 {
-  __shared__ int s_mx[16], s_ms[16], s_md[16];
-  __shared__ unsigned long long s_t[16], s_td[16];
-  int mx = 0, ms = 0, md = 0;
-  unsigned long long tot = 0, totd = 0;
+  __shared__ int s_mx[16], s_ms[16];
+  __shared__ unsigned long long s_t[16];
+  int mx = 0, ms = 0;
+  unsigned long long tot = 0;
   for (int b = threadIdx.x; b < nblocks; b += 1024) {
     const int4 v = blockstat[b];
-    const int2 d = blockdrop[b];
     mx = max(mx, v.x);
     ms = max(ms, v.y);
-    md = max(md, d.x);
     tot += (unsigned long long) v.z;
-    totd += (unsigned long long) d.y;
   }
   for (int off = 32; off > 0; off >>= 1) {
     mx = max(mx, __shfl_down(mx, off, 64));
     ms = max(ms, __shfl_down(ms, off, 64));
-    md = max(md, __shfl_down(md, off, 64));
     tot += __shfl_down(tot, off, 64);
-    totd += __shfl_down(totd, off, 64);
   }
   if ((threadIdx.x & 63) == 0) {
     s_mx[threadIdx.x >> 6] = mx;
     s_ms[threadIdx.x >> 6] = ms;
-    s_md[threadIdx.x >> 6] = md;
     s_t[threadIdx.x >> 6] = tot;
-    s_td[threadIdx.x >> 6] = totd;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int w = 1; w < 16; w++) {
       mx = max(mx, s_mx[w]);
       ms = max(ms, s_ms[w]);
-      md = max(md, s_md[w]);
       tot += s_t[w];
-      totd += s_td[w];
     }
     rowstat[0] = (unsigned long long) mx;
     rowstat[1] = tot;
     rowstat[3] = (unsigned long long) ms;
-    rowstat[4] = (unsigned long long) md;  // most entries dropped from one row (own-block pairs kept by the partner)
-    rowstat[5] = totd;                      // ... and their total = the own-block pairs that are in one row only
   }
 }
 
@@ -928,11 +874,6 @@ void build_bins_and_rows(ucg_ctx *ctx)
   hipStream_t st = ctx->stream;
   const int n = ctx->nlocal, ng = ctx->nghost;
   DomainDev dd = make_dev(D);
-  // option pair_once (set up by ucg_pair_init): rows for the "own-block pairs once" gather kernels; fix
-  // cluster_switch sweeps a FULL list, so it keeps the rows whole
-  const int once_beads = (ctx->once_beads_wanted > 0 && !ctx->cs) ? ctx->once_beads_wanted : 0;
-  dd.nlocal = n;
-  for (dd.once_shift = 0; (1 << dd.once_shift) < once_beads; dd.once_shift++) {}
   // (2) bin ranges of both classes
   const size_t nb1 = (size_t) D.nbins + 1;
   D.cells.reserve(nb1);
@@ -947,8 +888,8 @@ void build_bins_and_rows(ucg_ctx *ctx)
   D.rowstat.reserve(8);
   const double3 bs = make_double3(D.binsize[0], D.binsize[1], D.binsize[2]);
   int cap = D.row_capacity > 0 ? D.row_capacity : 96;
-  int maxrow = 0, maxdrop = 0;
-  long long total = 0, totdrop = 0;
+  int maxrow = 0;
+  long long total = 0;
   bool tiled = !ctx->rows_untiled && D.sten[0] <= 2 && D.sten[1] <= 2 && D.sten[2] <= 2;
   if (tiled) {
     const int3 nbrick = make_int3((D.nbin[0] + TILE_BX - 1) / TILE_BX, (D.nbin[1] + 3) / 4, (D.nbin[2] + 3) / 4);
@@ -959,18 +900,11 @@ void build_bins_and_rows(ucg_ctx *ctx)
       D.scratch.reserve((size_t) pitch * (size_t) capskin);
       UCG_HIP(hipMemsetAsync(D.rowstat.get(), 0, 8 * sizeof(unsigned long long), st));
       D.blockstat.reserve((size_t) nblocks + 1);
-      D.blockdrop.reserve((size_t) nblocks + 1);
       UCG_HIP(hipMemsetAsync(D.blockstat.get(), 0, (size_t) nblocks * sizeof(int4), st));
-      UCG_HIP(hipMemsetAsync(D.blockdrop.get(), 0, (size_t) nblocks * sizeof(int2), st));
-      if (once_beads)
-        hipLaunchKernelGGL(k_rows_tile<true>, dim3((unsigned) nblocks), dim3(TILE_B), 0, st, dd, ctx->pos4.get(), ctx->tag.get(),
-                           D.bin_of.get(), D.cells.get(), ctx->numneigh.get(), ctx->neigh.get(), D.scratch.get(), pitch, cap,
-                           capskin, bs, nbrick, D.blockstat.get(), D.blockdrop.get(), (int *) (D.rowstat.get() + 2));
-      else
-        hipLaunchKernelGGL(k_rows_tile<false>, dim3((unsigned) nblocks), dim3(TILE_B), 0, st, dd, ctx->pos4.get(), ctx->tag.get(),
-                           D.bin_of.get(), D.cells.get(), ctx->numneigh.get(), ctx->neigh.get(), D.scratch.get(), pitch, cap,
-                           capskin, bs, nbrick, D.blockstat.get(), D.blockdrop.get(), (int *) (D.rowstat.get() + 2));
-      hipLaunchKernelGGL(k_rowstat_fold, dim3(1), dim3(1024), 0, st, (int) nblocks, D.blockstat.get(), D.blockdrop.get(),
+      hipLaunchKernelGGL(k_rows_tile, dim3((unsigned) nblocks), dim3(TILE_B), 0, st, dd, ctx->pos4.get(), ctx->tag.get(),
+                         D.bin_of.get(), D.cells.get(), ctx->numneigh.get(), ctx->neigh.get(), D.scratch.get(), pitch, cap,
+                         capskin, bs, nbrick, D.blockstat.get(), (int *) (D.rowstat.get() + 2));
+      hipLaunchKernelGGL(k_rowstat_fold, dim3(1), dim3(1024), 0, st, (int) nblocks, D.blockstat.get(),
                          D.rowstat.get());
       unsigned long long stat[6];
       UCG_HIP(hipMemcpyAsync(stat, D.rowstat.get(), sizeof stat, hipMemcpyDeviceToHost, st));
@@ -981,8 +915,6 @@ void build_bins_and_rows(ucg_ctx *ctx)
       }
       maxrow = (int) (stat[0] & 0xFFFFFFFFull);
       total = (long long) stat[1];
-      maxdrop = (int) (stat[4] & 0xFFFFFFFFull);
-      totdrop = (long long) stat[5];
       const int maxskin = (int) (stat[3] & 0xFFFFFFFFull);
       const bool fits = maxrow <= cap && maxskin <= capskin;
       D.skin_capacity = maxskin + 8;
@@ -1008,8 +940,6 @@ void build_bins_and_rows(ucg_ctx *ctx)
       UCG_HIP(hipStreamSynchronize(st));
       maxrow = (int) (stat[0] & 0xFFFFFFFFull);
       total = (long long) stat[1];
-      maxdrop = (int) (stat[4] & 0xFFFFFFFFull);
-      totdrop = (long long) stat[5];
       if (maxrow <= cap) break;
       cap = maxrow + 16;  // a row did not fit: grow and rediscover
     }
@@ -1024,12 +954,9 @@ void build_bins_and_rows(ucg_ctx *ctx)
   ctx->list_inum = n;
   ctx->list_pitch = pitch;
   ctx->list_maxrow = maxrow;
-  ctx->list_entries = total + totdrop;  // as a FULL list: an own-block pair kept in one row stands for two entries
-  ctx->list_stored = total;
+  ctx->list_entries = total;
   ctx->list_from_builder = true;
   ctx->list_gen++;
-  ctx->list_once_beads = once_beads;
-  ctx->list_once_maxin = maxdrop;
 
   D.xhold.reserve((size_t) n);
   hipLaunchKernelGGL(k_store_xhold, dim3(nblk(n)), dim3(NB), 0, st, n, ctx->pos4.get(), D.xhold.get());
@@ -1627,8 +1554,6 @@ int ucg_md_info(ucg_ctx *ctx, long long *out)
     out[9] = ctx->dom->nbin[1];
     out[10] = ctx->dom->nbin[2];
   }
-  out[11] = ctx->list_once_beads;  // > 0: rows hold own-block pairs once (option pair_once), workgroups of this many beads
-  out[12] = ctx->list_once_maxin;
   return UCG_OK;
 }
 

@@ -50,39 +50,13 @@ __device__ __forceinline__ void gather_bead_split(const AtomsDev &A, const doubl
   }
 }
 
-// ---- ONCE variants ("own-block pairs once", option pair_once): rows built for them (ListDev::once_beads) hold an
-// own-block pair -- both beads among the ONCE_BEADS beads of one workgroup -- only in the row of ONE of its beads
-// (ucg_neigh.hip: once_evaluates).  That lane evaluates the pair and also forms what the pair adds to the PARTNER
-// -- the very numbers the reference's half-list sweep adds to it (UCG/pair_table_ucgld.cpp:500-502, :514-517,
-// :523-530: fpair, the energies and the weights do not depend on which bead is "i") -- and adds them to the
-// partner's six LDS accumulators as 64-bit FIXED-POINT integers (2^-40 units, ds_add_u64): integer addition is
-// associative, so the accumulated value does not depend on the order in which the lanes arrive and the result
-// stays bit-reproducible.  A bead's total is (its lanes' double sums, row order, fixed tree) + (its accumulators,
-// converted back).  The oracle's canonical order implements the same (orc_pair_set_once).  Each term must be
-// smaller than ONCE_LIMIT = 2048 in magnitude (thousands of them then fit the 64 bits); a larger one sets error
-// bit 4 (the caller then has to run without the option).
-constexpr int ONCE_BEADS = PAIR_BLOCK / 2;             // two lanes per bead
-constexpr double ONCE_MAGIC = 6144.0;                   // 1.5 * 2^12: ulp = 2^-40, so bits(v + MAGIC) - bits(MAGIC) = round(v * 2^40)
-constexpr double ONCE_UNIT = 9.094947017729282e-13;     // 2^-40
-constexpr double ONCE_LIMIT = 2048.0;                   // v + MAGIC stays inside [2^12, 2^13)
-
-__device__ __forceinline__ void once_add(unsigned long long *acc, const double v, int &err)
-{
-  if (!(fabs(v) < ONCE_LIMIT)) err |= 4;
-  // the low word of bits(MAGIC) is zero: the 64-bit difference costs one 32-bit subtraction
-  atomicAdd(acc, (unsigned long long) (__double_as_longlong(v + ONCE_MAGIC) - __double_as_longlong(ONCE_MAGIC)));
-}
-
-__device__ __forceinline__ double once_decode(const unsigned long long s) { return (double) (long long) s * ONCE_UNIT; }
-
 // SCE (table_ucg_bethe): -1 = P.pseudo_flag decides at run time; 0 = pseudo-likelihood scores only (`pseudo yes`), the
 // full-SCE code and the per-row reciprocals it keeps in registers are compiled out; 1 = full SCE (`pseudo no`)
-template <int STYLE, int TS, bool EV, bool LDS_TAB, bool FAST, int SLOTS, bool ONCE = false, bool ONETYPE = false, int SCE = -1>
+template <int STYLE, int TS, bool EV, bool LDS_TAB, bool FAST, int SLOTS, bool ONETYPE = false, int SCE = -1>
 __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, const AtomsDev A,
                                                            const ListDev Lst, double *evpart,
                                                            int *errflag)
 {
-  static_assert(!ONCE || (LDS_TAB && FAST && SLOTS == 2 && STYLE == 0), "ONCE: tables + own beads + accumulators in LDS, two lanes per bead");
   extern __shared__ double4 s_tab[];
   __shared__ double s_red[(PAIR_BLOCK / 64) * 8];
   // the small per-model arrays (bounded by UCG_MAX_ACTUAL / UCG_MAX_TABLES at upload time)
@@ -100,15 +74,11 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
   // along a Morton curve, so ~3/4 of a bead's neighbours are beads of its own workgroup and are then
   // read from LDS instead of through the vector L1, whose tag rate (one line per lane per load) is
   // what bounds this kernel otherwise.  Same values either way.
-  const bool stage_own = ONCE || P.stage_own != 0;
+  const bool stage_own = P.stage_own != 0;
   // tables through L1 / L2 with one actual type's block in LDS all the same (PairDev::hot_type)
-  const int hot_ent = (!LDS_TAB && FAST && !ONCE && TS != 3) ? P.hot_ent : 0;
+  const int hot_ent = (!LDS_TAB && FAST && TS != 3) ? P.hot_ent : 0;
   double4 *s_ownpos = s_tab + (LDS_TAB ? ntabent : hot_ent);
   int *s_ownmeta = reinterpret_cast<int *>(s_ownpos + PAIR_BLOCK / SLOTS);
-  // ONCE: six accumulators per bead, field-major (a wavefront's adds to one field spread over all banks)
-  unsigned long long *s_acc = reinterpret_cast<unsigned long long *>(s_ownmeta + PAIR_BLOCK / SLOTS);
-  if (ONCE)
-    for (int t = threadIdx.x; t < 6 * ONCE_BEADS; t += blockDim.x) s_acc[t] = 0ull;
   const int k0 = chunk_id * (PAIR_BLOCK / SLOTS);
   if (stage_own) {
     for (int t = threadIdx.x; t < PAIR_BLOCK / SLOTS; t += blockDim.x) {
@@ -230,7 +200,6 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
     double4 pm;
     int mm;
     gather_bead_split(A, s_ownpos, s_ownmeta, k0, nown, ent & 0x1FFFFFFF, pm, mm);
-    const int sk = UCG_META_STATE(mk);
     rp += rstep;
     for (int e = slot; e < n; e += SLOTS) {
       rp += rstep;
@@ -295,29 +264,6 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
             evdwl = w00 * q.u00 + e1st + e2nd + w11 * q.u11;
           }
           uf -= lm * (q.u11 - q.u01) + (1. - lm) * (q.u10 - q.u00);
-          if (ONCE) {
-            const unsigned ml = (unsigned) (m - k0);
-            if (ml < nown) {
-              // the partner's side of this pair: the transposed quad (u'[a][b] = u[b][a]) with lambda_k as the
-              // neighbour's weight and this bead's state selecting the score terms; minus the same force
-              unsigned long long *ap = s_acc + ml;
-              once_add(ap, -(dx * fpair), err);
-              once_add(ap + ONCE_BEADS, -(dy * fpair), err);
-              once_add(ap + 2 * ONCE_BEADS, -(dz * fpair), err);
-              once_add(ap + 3 * ONCE_BEADS, -(lk * (q.u11 - q.u10) + (1. - lk) * (q.u01 - q.u00)), err);
-              once_add(ap + 4 * ONCE_BEADS, -div_kT(sk ? q.u10 : q.u00, kT, rkT, kTp2), err);
-              once_add(ap + 5 * ONCE_BEADS, -div_kT(sk ? q.u11 : q.u01, kT, rkT, kTp2), err);
-              if (EV) {  // the pair is seen once: its whole energy and virial (two halves elsewhere)
-                ev[0] += 0.5 * evdwl;
-                ev[1] += 0.5 * (dx * dx * fpair);
-                ev[2] += 0.5 * (dy * dy * fpair);
-                ev[3] += 0.5 * (dz * dz * fpair);
-                ev[4] += 0.5 * (dx * dy * fpair);
-                ev[5] += 0.5 * (dx * dz * fpair);
-                ev[6] += 0.5 * (dy * dz * fpair);
-              }
-            }
-          }
         } else {
           // Bethe closure in the reference's orientation (UCG/pair_table_ucg_bethe.cpp:544-604)
           const double cu01 = k_is_i ? q.u01 : q.u10, cu10 = k_is_i ? q.u10 : q.u01;
@@ -421,7 +367,6 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
       mm = mm_n;
     }
   }
-  if (ONCE) __syncthreads();  // every lane of the workgroup has made its adds
   if (active) {
     if (SLOTS > 1) {
       // fixed tree over the bead's lanes: s[l] += s[l + off], off = SLOTS/2 ... 1
@@ -434,15 +379,6 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
         s0 += __shfl_down(s0, off, SLOTS);
         s1 += __shfl_down(s1, off, SLOTS);
       }
-    }
-    if (ONCE && slot == 0) {
-      const unsigned long long *ap = s_acc + (k - k0);
-      fx += once_decode(ap[0]);
-      fy += once_decode(ap[ONCE_BEADS]);
-      fz += once_decode(ap[2 * ONCE_BEADS]);
-      uf += once_decode(ap[3 * ONCE_BEADS]);
-      s0 += once_decode(ap[4 * ONCE_BEADS]);
-      s1 += once_decode(ap[5 * ONCE_BEADS]);
     }
     if (slot == 0) {
       const PostDev &Q = Lst.post;
@@ -518,33 +454,16 @@ hipError_t launch_style_ts(const PairDev &P, const AtomsDev &A, const ListDev &L
                                  : (size_t) P.ntab * P.tablength * sizeof(double4);
   const size_t ownbytes = P.stage_own ? (size_t) (PAIR_BLOCK / SLOTS) * (sizeof(double4) + sizeof(int)) : 0;
   const size_t ldsbytes = (P.tab_in_lds ? tabbytes : (P.fast ? (size_t) P.hot_ent * sizeof(double4) : 0)) + ownbytes;
-  if (L.once_beads) {
-    // rows built for the ONCE variant can only be swept by it (own-block pairs are in one row only)
-    if constexpr (STYLE == 0 && SLOTS == 2) {
-      if (L.once_beads != ONCE_BEADS || !P.tab_in_lds || !P.fast || !P.stage_own) return hipErrorInvalidValue;
-      const size_t lds = ldsbytes + (size_t) 6 * ONCE_BEADS * sizeof(unsigned long long);
-      if (lds + 4608 > 160 * 1024) return hipErrorInvalidValue;
-      auto kern = ev ? k_pair_gather<STYLE, TS, true, true, true, 2, true> : k_pair_gather<STYLE, TS, false, true, true, 2, true>;
-      if (P.n_actual == 1)
-        kern = ev ? k_pair_gather<STYLE, TS, true, true, true, 2, true, true> : k_pair_gather<STYLE, TS, false, true, true, 2, true, true>;
-      hipError_t e = hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-      if (e != hipSuccess) return e;
-      hipLaunchKernelGGL(kern, dim3(nblocks), dim3(PAIR_BLOCK), lds, st, P, A, L, evpart, errflag);
-      return hipGetLastError();
-    } else {
-      return hipErrorInvalidValue;
-    }
-  }
 #define UCG_LAUNCH(EVF, LDSF, FASTF)                                                                   \
   do {                                                                                                 \
     auto kern = k_pair_gather<STYLE, TS, EVF, LDSF, FASTF, SLOTS>;                                     \
     if constexpr (LDSF && FASTF && SLOTS <= 2) {                                                       \
       if constexpr (STYLE == 1) {                                                                      \
         if (P.n_actual == 1)                                                                           \
-          kern = P.pseudo_flag ? k_pair_gather<STYLE, TS, EVF, LDSF, FASTF, SLOTS, false, true, 1>     \
-                               : k_pair_gather<STYLE, TS, EVF, LDSF, FASTF, SLOTS, false, true, 0>;    \
+          kern = P.pseudo_flag ? k_pair_gather<STYLE, TS, EVF, LDSF, FASTF, SLOTS, true, 1>     \
+                               : k_pair_gather<STYLE, TS, EVF, LDSF, FASTF, SLOTS, true, 0>;    \
       } else if (P.n_actual == 1) {                                                                    \
-        kern = k_pair_gather<STYLE, TS, EVF, LDSF, FASTF, SLOTS, false, true>;                         \
+        kern = k_pair_gather<STYLE, TS, EVF, LDSF, FASTF, SLOTS, true>;                         \
       }                                                                                                \
     }                                                                                                  \
     if (ldsbytes > 48 * 1024) {                                                                        \
