@@ -61,10 +61,3 @@ def fresh_ctx(pkg):
     yield ctx
     ctx.close()
 
-
-@pytest.fixture(autouse=True)
-def _forget_oracle_pairs():
-    """tests/util.py keeps the oracle pairs a test made (to put them into the library pair's summation mode)"""
-    yield
-    import util
-    util.forget_oracle_pairs()

@@ -22,45 +22,10 @@ def make_deck(tabstyle="spline", tablength=1024, **kw):
 
 GATHER_SLOTS = 1  # the library's default lanes per bead (ucg_pair_gather_slots); part of the canonical order
 
-# How a library pair sums a bead's terms (ordered double sums, or order-free fixed sums where it runs on virtual rows:
-# include/ucg_hip.h, ucg_pair_sum_fixed) is decided by the library at ucg_pair_init.  The oracle states both; which one a
-# comparison needs is taken from the library pair: gpu_pair() puts every oracle pair this test made for the same style
-# and deck into the library pair's mode (so the oracle has to compute AFTER the library pair exists -- a comparison
-# that did it the other way round fails on the bits, it does not pass by accident).
-_ORACLE_PAIRS = []
-_HAVE_GPU = None
-
-
-def forget_oracle_pairs():
-    del _ORACLE_PAIRS[:]
-
-
-def _match_sum_mode(style, deck, fixed):
-    for st, dk, op in _ORACLE_PAIRS:
-        if st == style and dk is deck:
-            op.set_sum_fixed(fixed)
-
-
-def _library_default_sum_fixed(make_pair):
-    """the summation mode a library pair takes for this deck on a context with default options (False without a GPU:
-    the CPU tier never compares with the library)"""
-    pkg = load_package()
-    global _HAVE_GPU
-    if _HAVE_GPU is False:
-        return False
-    try:
-        ctx = pkg.capi.Context(0)
-    except Exception:  # no device (the CPU tier): nothing to match
-        _HAVE_GPU = False
-        return False
-    _HAVE_GPU = True
-    try:
-        gp = make_pair(ctx)
-        fixed = gp.sum_fixed
-        gp.close()
-    finally:
-        ctx.close()
-    return fixed
+# How a library pair sums a bead's terms -- ordered double sums (the default), or order-free fixed sums where option
+# pair_vrow puts it on virtual rows (include/ucg_hip.h, ucg_pair_sum_fixed) -- is decided by the library at ucg_pair_init.
+# The oracle states both; oracle pairs made here start with ordered sums, and a test that switches the option on puts its
+# oracle pair into the same mode (op.set_sum_fixed(True)) and asserts gp.sum_fixed.
 
 
 def oracle_pair(style, deck, T=1.0, ntypes=2, slots=GATHER_SLOTS):
@@ -70,25 +35,15 @@ def oracle_pair(style, deck, T=1.0, ntypes=2, slots=GATHER_SLOTS):
     p.coeff(deck.pair_coeff_args(), ntypes)
     p.init(ntypes, T, 1.0)
     p.set_gather_slots(slots)
-    # starts in the mode the library takes by default; a test whose context options change that gets the oracle pair
-    # switched when it makes its library pair (gpu_pair)
-    p.set_sum_fixed(_library_default_sum_fixed(lambda ctx: _gpu_pair_raw(ctx, style, deck, T, ntypes)))
-    _ORACLE_PAIRS.append((style, deck, p))
     return p
 
 
-def _gpu_pair_raw(ctx, style, deck, T=1.0, ntypes=2):
+def gpu_pair(ctx, style, deck, T=1.0, ntypes=2):
     pkg = load_package()
     p = pkg.capi.Pair(ctx, style)
     p.settings(deck.pair_style_args())
     p.coeff(deck.pair_coeff_args(), ntypes)
     p.init(ntypes, T)
-    return p
-
-
-def gpu_pair(ctx, style, deck, T=1.0, ntypes=2):
-    p = _gpu_pair_raw(ctx, style, deck, T, ntypes)
-    _match_sum_mode(style, deck, p.sum_fixed)
     return p
 
 
@@ -155,22 +110,14 @@ def oracle_pair_multi(style, deck, T=1.0, slots=GATHER_SLOTS):
         p.coeff(cmd, deck.ntypes)
     p.init(deck.ntypes, T, 1.0)
     p.set_gather_slots(slots)
-    p.set_sum_fixed(_library_default_sum_fixed(lambda ctx: _gpu_pair_multi_raw(ctx, style, deck, T)))
-    _ORACLE_PAIRS.append((style, deck, p))
     return p
 
 
-def _gpu_pair_multi_raw(ctx, style, deck, T=1.0):
+def gpu_pair_multi(ctx, style, deck, T=1.0):
     pkg = load_package()
     p = pkg.capi.Pair(ctx, style)
     p.settings(deck.pair_style_args())
     for cmd in deck.pair_coeff_commands():
         p.coeff(cmd, deck.ntypes)
     p.init(deck.ntypes, T)
-    return p
-
-
-def gpu_pair_multi(ctx, style, deck, T=1.0):
-    p = _gpu_pair_multi_raw(ctx, style, deck, T)
-    _match_sum_mode(style, deck, p.sum_fixed)
     return p
