@@ -49,7 +49,8 @@ __device__ __forceinline__ int roundup_align(int n) { return ((n + VR_ALIGN - 1)
 
 // One workgroup per block of VR_BEADS beads, one thread per bead.
 //  1. every thread walks its bead's full row (coalesced: the rows are stored [entry][bead]) and classifies each entry
-//     (dropped / P / Q / S: two bits, kept in registers);
+//     (dropped, or one of the five lists: four bits, kept in registers; the distances need the neighbours' positions:
+//     gathers through L2, which is what this kernel's time goes to -- 1.16 ms at 1 M beads);
 //  2. the padded per-bead counts of each list are scanned over the block: the bead's offset in the list, the list's
 //     length, the row length T = the length cut into 1024 pieces;
 //  3. list by list: the threads walk their rows again (L2) and put the kept entries at their places in an LDS image of
