@@ -204,13 +204,16 @@ def test_tables_longer_than_the_lds_trajectories_bitwise(fresh_ctx, pkg, orc, st
         assert util.bits_equal(G[k], O[k]), k
 
 
-@pytest.mark.parametrize("style,ncell,steps", [("table_ucgld", 64, 16), ("table_ucg_bethe", 64, 16), ("table_ucgld", 100, 12),
-                                               ("table_ucg_bethe_density", 64, 12)])
-def test_baseline_size_trajectory_bitwise_vs_oracle(fresh_ctx, pkg, orc, style, ncell, steps):
+@pytest.mark.parametrize("style,ncell,steps,vrow", [("table_ucgld", 64, 16, 0), ("table_ucg_bethe", 64, 16, 0), ("table_ucgld", 100, 12, 0),
+                                                    ("table_ucg_bethe_density", 64, 12, 0), ("table_ucgld", 64, 16, 1),
+                                                    ("table_ucg_bethe", 64, 16, 1)])
+def test_baseline_size_trajectory_bitwise_vs_oracle(fresh_ctx, pkg, orc, style, ncell, steps, vrow):
     """BASELINE.json config 2 at its full size -- 262 144 beads (64^3), pair_table_ucgld + fix ucgld/langevin (+ fix
     ucgstate ld, fix nve/ucgld/wall/hard) -- against the ORACLE, bit for bit, over a re-neighbouring: 256 workgroups of the
     gather kernel (one full round of the chip), ~1800 bricks of the row builder, 69 k periodic images.  The Bethe style
-    runs the same size once, and the headline workload (1 000 000 beads: 977 workgroups, 164 k images) a dozen steps."""
+    runs the same size once, and the headline workload (1 000 000 beads: 977 workgroups, 164 k images) a dozen steps.
+    vrow = 1: the same on the virtual-row kernels (option pair_vrow: 512 workgroups, five lists each) against the
+    oracle's fixed sums."""
     bethe, dens = style == "table_ucg_bethe", style == "table_ucg_bethe_density"
     kw = dict(density=(11.3, 1.5), extra11=0.05) if dens else {}
     deck = util.make_deck("spline", 1024, extra_keywords=("method", "bethe", "pseudo", "yes", "prior", "ucgl") if bethe else (), **kw)
@@ -220,11 +223,14 @@ def test_baseline_size_trajectory_bitwise_vs_oracle(fresh_ctx, pkg, orc, style, 
     ust = ("mc", 9127, 0.01) if dens else ("plain" if bethe else "ld")
     # at dt = 0.004 the fastest of these beads crosses half the skin after ~8 steps
     op = util.oracle_pair(style, deck)
+    op.set_sum_fixed(bool(vrow))
     sim = util.oracle_sim(beads, op, mode=1, dt=0.004, langevin=lang, nve="wall", ucgstate=ust, every=2)
     assert sim.setup(steps) == 0 and sim.run(steps, 0) == 0
     ctx = fresh_ctx
     _setup_gpu(ctx, beads, 0.004, 2)
+    ctx.set_option("pair_vrow", vrow)
     gp = util.gpu_pair(ctx, style, deck)
+    assert gp.sum_fixed == bool(vrow)
     if lang:
         ctx.fix_ucgld_langevin(*lang)
         ctx.fix_ucgstate("ld")
