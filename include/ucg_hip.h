@@ -156,8 +156,10 @@ int ucg_pair_tabindex(const ucg_pair *p, int *out, int cap);
  * style) of the owned atoms.  eng_vdwl / virial[6] (xx,yy,zz,xy,xz,yz) may be
  * NULL when eflag / vflag are 0. */
 int ucg_pair_compute(ucg_pair *p, int eflag, int vflag, double *eng_vdwl, double *virial);
-/* device-side table-range violations of the last compute (0 = none); the glue
- * turns a nonzero return into error->one() like UCG/pair_table_ucgld.cpp:437-444 */
+/* ucg_pair_check_errors: device-side error flags of the computes since the last call (0 = none): UCG_ERR_TABLE_INNER /
+ * UCG_ERR_TABLE_OUTER = a pair distance outside the tables' range -- the glue turns those into error->one() like
+ * UCG/pair_table_ucgld.cpp:437-444; with option "pair_vrow": UCG_ERR_UNSUPPORTED when a block's virtual rows do not fit
+ * (a row of more than 128 entries, a list of more than 32 768 entries) or a term left the range of the fixed sums. */
 /* the same compute() in two launches for decomposed runs (table_ucgld / table_ucg_bethe, no
  * energy/virial): part 1 = the workgroups none of whose beads has a ghost neighbour -- they can run
  * while the halo is in flight --, part 2 = the rest, after ucg_halo_unpack.  Together they write
