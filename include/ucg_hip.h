@@ -203,6 +203,8 @@ int ucg_atoms_download(ucg_ctx *ctx, int with_ghosts, double *x, double *v, doub
                        int *tag, int *ucgstate, int *num_ucgstates, double *ucgl, double *ucgvl,
                        double *ucgml, double *ucgp, double *ucgforce, double *ucgsoftmaxscores);
 int ucg_atoms_counts(const ucg_ctx *ctx, int *nlocal, int *nghost);
+/* atom->mask of the owned atoms in the device's current order (beads migrate and are re-sorted in the resident loops) */
+int ucg_atoms_download_mask(ucg_ctx *ctx, int *mask);
 /* which owned atom each ghost is a periodic image of (host-built ghosts only; the device
  * builder records it itself).  table_ucg_bethe_density needs it to give ghosts their owner's
  * prior and CV force -- the forward_comm the reference declares but never performs
@@ -297,10 +299,19 @@ typedef struct ucg_comm_ops {
 } ucg_comm_ops;
 typedef struct ucg_rccl_id { char internal[128]; } ucg_rccl_id; /* = ncclUniqueId */
 int ucg_comm_attach(ucg_ctx *ctx, const ucg_comm_ops *ops);
+/* the same callbacks for a caller without device-aware transport (plain MPI in a LAMMPS build: MPI_Alltoallv on bytes): the
+ * library stages every message through pinned HOST buffers of its own, so alltoallv receives HOST pointers (`stream` is NULL
+ * and everything queued before has completed); nothing else differs from ucg_comm_attach */
+int ucg_comm_attach_host(ucg_ctx *ctx, const ucg_comm_ops *ops);
 int ucg_comm_rccl_unique_id(ucg_rccl_id *out);
 int ucg_comm_attach_rccl(ucg_ctx *ctx, const ucg_rccl_id *id, int rank, int world);
 int ucg_comm_detach(ucg_ctx *ctx);
 int ucg_comm_info(const ucg_ctx *ctx, int *rank, int *world, int *is_rccl, long long *nrebuild);
+/* what the attached communicator really is: out[0] = 1 RCCL / 0 callbacks, out[1] = ranks RCCL itself reports for the
+ * communicator (ncclCommCount; 0 without RCCL), out[2] = device RCCL reports (ncclCommCuDevice; -1), out[3] = 1 when the
+ * callbacks are host-staged (ucg_comm_attach_host).  bench.py prints it, so that a scaling line cannot pass a host-staged
+ * rehearsal off as an RCCL run */
+int ucg_comm_transport(const ucg_ctx *ctx, int *out4);
 int ucg_comm_allreduce_f64(ucg_ctx *ctx, double *buf, int n, int op);
 
 /* ------------------------------------------------ host mirrors of a drop-in caller
@@ -368,6 +379,15 @@ int ucg_fix_langevin_post_force(ucg_ctx *ctx, int groupbit, long long ntimestep,
                                 long long beginstep, long long endstep);
 int ucg_fix_langevin_end_of_step(ucg_ctx *ctx, int groupbit, double *lambda_temp);
 double ucg_fix_langevin_t_target(const ucg_ctx *ctx);
+/* reset_target (:358-361): t_target = t_start = t_stop = t_new */
+int ucg_fix_langevin_reset_target(ucg_ctx *ctx, double t_new);
+/* reset_dt (:366-376) AS SHIPPED: only gfactor2 is rebuilt, from atom->mass[type] (not ucgml) and the context's current
+ * dt; gfactor1 keeps its value.  mass_by_type is ntypes+1 long (NULL: the masses of the last
+ * ucg_atoms_upload) */
+int ucg_fix_langevin_reset_dt(ucg_ctx *ctx, int ntypes, const double *mass_by_type);
+/* fix_modify temp with a compute that removes a velocity bias (tbiasflag == BIAS, :162-165): post_force_templated<1>
+ * (:283-291) zeroes the random force of a bead whose lambda velocity is exactly 0.  bias = 0 is the default. */
+int ucg_fix_langevin_set_bias(ucg_ctx *ctx, int bias);
 
 /* ---------------------------------------------------------------- fix ucgstate
  * replaces FixUCGState::post_force (UCG/fix_ucgstate.cpp:88-132);
@@ -440,6 +460,12 @@ int ucg_md_post_fused(ucg_ctx *ctx, int use_langevin, int use_ucgstate, int use_
                       int groupbit, long long ntimestep, long long beginstep, long long endstep);
 int ucg_md_setup(ucg_ctx *ctx, long long nsteps_planned);
 int ucg_md_run(ucg_ctx *ctx, long long nsteps, int thermo_every);
+/* the same loop for a caller that owns the output schedule (the run_style of the LAMMPS glue): nsteps steps with energy /
+ * virial / lambda temperature evaluated on the LAST one iff ev_on_last (an Output::next step) and on no other */
+int ucg_md_run_until(ucg_ctx *ctx, long long nsteps, int ev_on_last);
+/* update->beginstep / endstep of `run N start S stop E` (the ramp of fix ucgld/langevin's target, :318-330) when they are
+ * not the [ntimestep, ntimestep + nsteps_planned] ucg_md_setup assumes; call after ucg_md_setup */
+int ucg_md_set_window(ucg_ctx *ctx, long long beginstep, long long endstep);
 /* out[0..15]: ntimestep, nrebuild, nlocal, nghost, list entries, pair errors, ... */
 int ucg_md_info(ucg_ctx *ctx, long long *out16);
 /* last thermo: eng_vdwl, virial[6], lambda_temp, state-1 population */

@@ -60,6 +60,8 @@ SYMBOLS = [
     "ucg_profile_enable", "ucg_profile_read",
     "ucg_comm_attach", "ucg_comm_rccl_unique_id", "ucg_comm_attach_rccl", "ucg_comm_detach", "ucg_comm_info",
     "ucg_comm_allreduce_f64", "ucg_pair_density_aux_download", "ucg_pair_density_aux_upload",
+    "ucg_comm_attach_host", "ucg_comm_transport", "ucg_fix_langevin_reset_target", "ucg_fix_langevin_reset_dt",
+    "ucg_fix_langevin_set_bias", "ucg_md_run_until", "ucg_md_set_window", "ucg_atoms_download_mask",
     "ucg_ghosts_upload_images", "ucg_host_bind", "ucg_host_modified", "ucg_host_sync", "ucg_host_status", "ucg_verlet_hooks_run",
 ]
 
@@ -226,6 +228,14 @@ def lib():
     L.ucg_host_sync.argtypes = [vp, C.c_int]
     L.ucg_host_status.argtypes = [vp, c_int_p, c_int_p, c_ll_p]
     L.ucg_verlet_hooks_run.argtypes = [vp, vp, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_ll_p]
+    L.ucg_comm_attach_host.argtypes = [vp, C.POINTER(CommOps)]
+    L.ucg_comm_transport.argtypes = [vp, c_int_p]
+    L.ucg_fix_langevin_reset_target.argtypes = [vp, C.c_double]
+    L.ucg_fix_langevin_reset_dt.argtypes = [vp, C.c_int, c_double_p]
+    L.ucg_fix_langevin_set_bias.argtypes = [vp, C.c_int]
+    L.ucg_md_run_until.argtypes = [vp, C.c_longlong, C.c_int]
+    L.ucg_md_set_window.argtypes = [vp, C.c_longlong, C.c_longlong]
+    L.ucg_atoms_download_mask.argtypes = [vp, c_int_p]
     _LIB = L
     return L
 
@@ -525,6 +535,16 @@ class Context:
     def fix_ucgld_langevin_t_target(self):
         return self.L.ucg_fix_langevin_t_target(self.h)
 
+    def fix_ucgld_langevin_reset_target(self, t_new):
+        self.chk(self.L.ucg_fix_langevin_reset_target(self.h, float(t_new)))
+
+    def fix_ucgld_langevin_reset_dt(self, ntypes, mass_by_type=None):
+        m = None if mass_by_type is None else _f64(mass_by_type)
+        self.chk(self.L.ucg_fix_langevin_reset_dt(self.h, int(ntypes), None if m is None else _dp(m)))
+
+    def fix_ucgld_langevin_set_bias(self, bias):
+        self.chk(self.L.ucg_fix_langevin_set_bias(self.h, int(bool(bias))))
+
     # ---- fix ucgstate
     def fix_ucgstate(self, mode=None, seed=0, rate=0.01, me=0):
         """mode: None (plain) | "ld" | "mc" -- `fix ID grp ucgstate [ld | mc seed rate]`"""
@@ -615,6 +635,17 @@ class Context:
 
     def md_run(self, nsteps, thermo_every=0):
         self.chk(self.L.ucg_md_run(self.h, nsteps, thermo_every))
+
+    def md_run_until(self, nsteps, ev_on_last=False):
+        self.chk(self.L.ucg_md_run_until(self.h, int(nsteps), int(bool(ev_on_last))))
+
+    def md_set_window(self, beginstep, endstep):
+        self.chk(self.L.ucg_md_set_window(self.h, int(beginstep), int(endstep)))
+
+    def download_mask(self):
+        out = np.zeros(max(self.counts()[0], 1), np.int32)
+        self.chk(self.L.ucg_atoms_download_mask(self.h, _ip(out)))
+        return out[:self.counts()[0]]
 
     def md_info(self):
         out = np.zeros(16, np.int64)

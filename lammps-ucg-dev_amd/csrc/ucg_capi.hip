@@ -874,6 +874,7 @@ int ucg_pair_check_errors(ucg_pair *p)
     UCG_HIP(hipMemsetAsync(p->d_err.get(), 0, sizeof(int), ctx->stream));
     if (flag & 1) return fail(ctx, UCG_ERR_TABLE_INNER, "Pair distance < table inner cutoff");
     if (flag & 2) return fail(ctx, UCG_ERR_TABLE_OUTER, "Pair distance > table outer cutoff");
+    if (flag & 8) p->vr_gen = -1;  // the unusable virtual rows are made (and found wanting) again by the next compute: reported every time
     if (flag & 8)
       return fail(ctx, UCG_ERR_UNSUPPORTED, "the virtual rows of a block of 512 beads do not fit (a row of more than 128 entries, or "
                                             "more than 32 768 kept entries in one of the block's lists): set option pair_vrow 0 "
@@ -1083,6 +1084,16 @@ int ucg_atoms_counts(const ucg_ctx *ctx, int *nlocal, int *nghost)
   if (nlocal) *nlocal = ctx->nlocal;
   if (nghost) *nghost = ctx->nghost;
   return UCG_OK;
+}
+
+int ucg_atoms_download_mask(ucg_ctx *ctx, int *mask)
+{
+  if (!ctx || !mask) return UCG_ERR_INVALID;
+  return guarded(ctx, [&]() -> int {
+    if (ctx->nlocal) d2h(ctx, mask, ctx->mask.get(), (size_t) ctx->nlocal);
+    sync(ctx);
+    return UCG_OK;
+  });
 }
 
 int ucg_force_clear(ucg_ctx *ctx)
@@ -1364,6 +1375,7 @@ int ucg_fix_langevin_post_force(ucg_ctx *ctx, int groupbit, long long ntimestep,
     Lg.gfactor1 = L.gf1.get();
     Lg.gfactor2 = L.gf2.get();
     Lg.tsqrt = L.tsqrt;
+    Lg.bias = L.bias ? 1 : 0;
     Lg.draws = rng_next(ctx, L.rng, L.draws, L.batch, ctx->nlocal);
     mirror_need(ctx, UCG_F_UCGVL | UCG_F_UCGFORCE | UCG_F_F);
     UCG_HIP(launch_langevin(ctx->atoms_dev(), Lg, groupbit, ctx->stream));
@@ -1378,6 +1390,7 @@ int ucg_fix_langevin_end_of_step(ucg_ctx *ctx, int groupbit, double *lambda_temp
   return guarded(ctx, [&]() -> int {
     const int nb = (ctx->nlocal + 255) / 256 + 1;
     ctx->redpart.reserve((size_t) nb * 4);
+    mirror_need(ctx, UCG_F_UCGVL | UCG_F_STATE);  // sum of ml vl^2 (:303-312) + the state-1 population of the thermo line
     UCG_HIP(launch_lambda_ke(ctx->atoms_dev(), groupbit, ctx->mvv2e, ctx->redpart.get(), ctx->redout.get(), ctx->stream));
     double out[4];
     d2h(ctx, out, ctx->redout.get(), 4);
@@ -1392,6 +1405,50 @@ int ucg_fix_langevin_end_of_step(ucg_ctx *ctx, int groupbit, double *lambda_temp
 }
 
 double ucg_fix_langevin_t_target(const ucg_ctx *ctx) { return ctx ? ctx->lang.t_target : 0.0; }
+
+int ucg_fix_langevin_reset_target(ucg_ctx *ctx, double t_new)
+{
+  if (!ctx) return UCG_ERR_INVALID;
+  FixLangevin &L = ctx->lang;
+  if (!L.active) return fail(ctx, UCG_ERR_INVALID, "fix ucgld/langevin not created");
+  L.t_target = L.t_start = L.t_stop = t_new;  // UCG/fix_ucgld_langevin.cpp:358-361
+  return UCG_OK;
+}
+
+int ucg_fix_langevin_reset_dt(ucg_ctx *ctx, int ntypes, const double *mass_by_type)
+{
+  if (!ctx || ntypes < 1) return UCG_ERR_INVALID;
+  return guarded(ctx, [&]() -> int {
+    FixLangevin &L = ctx->lang;
+    if (!L.active || !L.inited) return fail(ctx, UCG_ERR_INVALID, "fix ucgld/langevin not initialised");
+    if (ntypes != L.ntypes) return fail(ctx, UCG_ERR_INVALID, "ucg_fix_langevin_reset_dt: ntypes differs from the one given to init");
+    std::vector<double> mass((size_t) ntypes + 1, 0.0), g2((size_t) ntypes + 1, 0.0);
+    if (mass_by_type) {
+      for (int i = 0; i <= ntypes; i++) mass[(size_t) i] = mass_by_type[i];
+    } else {
+      if (ctx->ntypes != ntypes) return fail(ctx, UCG_ERR_INVALID, "ucg_fix_langevin_reset_dt: no masses on the device for this ntypes");
+      d2h(ctx, mass.data(), ctx->mass.get(), (size_t) ntypes + 1);
+      sync(ctx);
+    }
+    // reset_dt() as shipped (UCG/fix_ucgld_langevin.cpp:366-376): `if (atom->mass)` -- always true for atom style ucg --
+    // gfactor2 from atom->mass[i] (init() used atom->ucgml[i]), ratio[i] = 1; gfactor1 is left alone
+    for (int i = 1; i <= ntypes; i++) {
+      g2[(size_t) i] = std::sqrt(mass[(size_t) i]) / ctx->ftm2v;
+      g2[(size_t) i] *= std::sqrt(24.0 * ctx->boltz / L.t_period / ctx->dt / ctx->mvv2e);
+      g2[(size_t) i] *= 1.0 / std::sqrt(1.0);
+    }
+    h2d(ctx, L.gf2.get(), g2.data(), (size_t) ntypes + 1);
+    sync(ctx);
+    return UCG_OK;
+  });
+}
+
+int ucg_fix_langevin_set_bias(ucg_ctx *ctx, int bias)
+{
+  if (!ctx) return UCG_ERR_INVALID;
+  ctx->lang.bias = bias != 0;
+  return UCG_OK;
+}
 
 int ucg_fix_ucgstate_create(ucg_ctx *ctx, int ld_flag, int mc_flag, int mc_seed, double mc_rate, int me)
 {
@@ -1447,6 +1504,7 @@ int ucg_md_post_fused(ucg_ctx *ctx, int use_langevin, int use_ucgstate, int use_
       Lg.gfactor1 = L.gf1.get();
       Lg.gfactor2 = L.gf2.get();
       Lg.tsqrt = L.tsqrt;
+      Lg.bias = L.bias ? 1 : 0;
       Lg.draws = rng_next(ctx, L.rng, L.draws, L.batch, ctx->nlocal);
     }
     const unsigned int *mc_draws = nullptr;
@@ -1457,6 +1515,9 @@ int ucg_md_post_fused(ucg_ctx *ctx, int use_langevin, int use_ucgstate, int use_
         mc_draws = rng_next(ctx, S.rng, S.draws, S.batch, ctx->nlocal);
       }
     }
+    // reads and writes every per-bead field: what the caller announced with ucg_host_modified goes up first (mirror_wrote
+    // below would otherwise discard the announcement)
+    mirror_need(ctx, UCG_F_ALL);
     UCG_HIP(launch_post_fused(ctx->atoms_dev(), use_langevin != 0, Lg, use_ucgstate != 0, S.ld_flag, S.mc_flag, S.mc_rate,
                               mc_draws, use_nve != 0, fuse_next_initial != 0, ctx->dt, 0.5 * ctx->dt * ctx->ftm2v,
                               groupbit, use_nve >= 2 ? (ctx->wall_bias ? 3 : 2) : 0, ctx->wall_barrier, ctx->stream));
@@ -1494,6 +1555,7 @@ int ucg_md_pair_post(ucg_ctx *ctx, ucg_pair *p, int use_langevin, int use_ucgsta
       Q.gfactor1 = L.gf1.get();
       Q.gfactor2 = L.gf2.get();
       Q.tsqrt = L.tsqrt;
+      Q.lang_bias = L.bias ? 1 : 0;
       Q.lang_draws = rng_next(ctx, L.rng, L.draws, L.batch, ctx->nlocal);  // the draws do not depend on the forces
     }
     FixUcgState &S = ctx->ucgst;
@@ -1506,6 +1568,7 @@ int ucg_md_pair_post(ucg_ctx *ctx, ucg_pair *p, int use_langevin, int use_ucgsta
         Q.mc_draws = rng_next(ctx, S.rng, S.draws, S.batch, ctx->nlocal);
       }
     }
+    mirror_need(ctx, UCG_F_ALL);  // as ucg_md_post_fused: host-side edits go up before the launch that overwrites everything
     ctx->pos4_alt.reserve_exact(ctx->pos4.capacity());
     ctx->meta_alt.reserve_exact(ctx->meta.capacity());
     Q.pos_out = ctx->pos4_alt.get();
@@ -1609,6 +1672,14 @@ int ucg_ctx_set_option(ucg_ctx *ctx, const char *name, int value)
       return UCG_ERR_INVALID;
     }
     ctx->rng_batch = value;
+    return UCG_OK;
+  }
+  if (std::strcmp(name, "fault_inject_step") == 0) {
+    ctx->fault_step = value;
+    return UCG_OK;
+  }
+  if (std::strcmp(name, "fault_inject_setup") == 0) {
+    ctx->fault_setup = value != 0;
     return UCG_OK;
   }
   if (std::strcmp(name, "rows_untiled") == 0) {

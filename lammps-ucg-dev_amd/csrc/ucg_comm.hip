@@ -39,6 +39,8 @@ struct Rccl {
   int (*AllReduce)(const void *s, void *r, size_t count, int dtype, int op, void *comm, hipStream_t st) = nullptr;
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
+  int (*CommCount)(void *comm, int *count) = nullptr;
+  int (*CommCuDevice)(void *comm, int *device) = nullptr;
   const char *(*GetErrorString)(int) = nullptr;
   std::string err;
   bool loaded = false;  // every symbol resolved (a half-loaded library must not be called through)
@@ -82,6 +84,8 @@ struct Rccl {
     UCG_SYM(AllReduce, "ncclAllReduce");
     UCG_SYM(GroupStart, "ncclGroupStart");
     UCG_SYM(GroupEnd, "ncclGroupEnd");
+    UCG_SYM(CommCount, "ncclCommCount");
+    UCG_SYM(CommCuDevice, "ncclCommCuDevice");
     UCG_SYM(GetErrorString, "ncclGetErrorString");
 #undef UCG_SYM
     loaded = true;
@@ -103,6 +107,18 @@ struct CommState {
   long long nsend = 0, nrecv = 0;
   long long nrebuild = 0;
   bool cluster_synced = false;
+  // UCG_RCCL_SELF_SEND=1 (read once, at ucg_comm_attach_rccl): keep the block a rank sends to itself on RCCL instead of a
+  // device copy -- the one-rank tests run the grouped send / receive path that way
+  bool self_copy = true;
+  // ucg_comm_attach_host: the callbacks' alltoallv works on HOST memory; messages are staged through these pinned buffers
+  bool host_staged = false;
+  char *hsend = nullptr, *hrecv = nullptr;
+  size_t hsend_cap = 0, hrecv_cap = 0;
+  ~CommState()
+  {
+    if (hsend) (void) hipHostFree(hsend);
+    if (hrecv) (void) hipHostFree(hrecv);
+  }
 };
 
 void comm_destroy(ucg_ctx *ctx)
@@ -134,15 +150,35 @@ void cb_check(int rc, const char *what)
 void alltoallv(ucg_ctx *ctx, const void *send, const long long *sendbytes, void *recv, const long long *recvbytes)
 {
   CommState &C = *ctx->comm;
+  if (!C.rccl && C.host_staged) {
+    size_t ns = 0, nr = 0;
+    for (int r = 0; r < C.world; r++) {
+      ns += (size_t) sendbytes[r];
+      nr += (size_t) recvbytes[r];
+    }
+    auto grow = [](char *&p, size_t &cap, size_t want) {
+      if (want <= cap) return;
+      if (p) (void) hipHostFree(p);
+      p = nullptr;
+      cap = want + want / 4 + 4096;
+      UCG_HIP(hipHostMalloc((void **) &p, cap, hipHostMallocDefault));
+    };
+    grow(C.hsend, C.hsend_cap, ns);
+    grow(C.hrecv, C.hrecv_cap, nr);
+    if (ns) UCG_HIP(hipMemcpyAsync(C.hsend, send, ns, hipMemcpyDeviceToHost, ctx->stream));
+    UCG_HIP(hipStreamSynchronize(ctx->stream));
+    cb_check(C.ops.alltoallv(C.ops.user, C.hsend, sendbytes, C.hrecv, recvbytes, nullptr), "alltoallv");
+    if (nr) UCG_HIP(hipMemcpyAsync(recv, C.hrecv, nr, hipMemcpyHostToDevice, ctx->stream));
+    return;
+  }
   if (!C.rccl) {
     cb_check(C.ops.alltoallv(C.ops.user, send, sendbytes, recv, recvbytes, (void *) ctx->stream), "alltoallv");
     return;
   }
   // the block a rank sends to itself (its own periodic images: every grid with a dimension of one rank) never leaves the
   // device: a plain copy on the stream instead of an ncclSend / ncclRecv pair to self
-  // (UCG_RCCL_SELF_SEND=1 keeps the self block on RCCL: the one-rank tests run the grouped send / receive path that way)
-  const char *selfenv = getenv("UCG_RCCL_SELF_SEND");
-  const bool self_copy = !(selfenv && selfenv[0] == '1');
+  // (CommState::self_copy = false keeps the self block on RCCL: the one-rank tests run the grouped send / receive path that way)
+  const bool self_copy = C.self_copy;
   long long so = 0, ro = 0;
   bool peers = false;
   for (int r = 0; r < C.world; r++) {
@@ -258,11 +294,26 @@ struct LocalStatus {
   void run(ucg_ctx *ctx, F &&fn)
   {
     if (bad != UCG_OK) return;
-    const int rc = fn();
+    int rc;
+    try {
+      rc = fn();
+    } catch (const InputError &e) {
+      ctx->err = e.msg;
+      rc = UCG_ERR_INPUT;
+    } catch (const HipFailure &e) {
+      ctx->err = std::string("HIP error: ") + hipGetErrorString(e.code) + " in " + e.what;
+      rc = UCG_ERR_HIP;
+    }  // (a CommFailure is not rank-local: it propagates)
     if (rc != UCG_OK) {
       bad = rc;
       msg = ctx->err;
     }
+  }
+  void fail(int code, const std::string &why)
+  {
+    if (bad != UCG_OK) return;
+    bad = code;
+    msg = why;
   }
   // all ranks: the worst code; a rank that was fine itself reports UCG_ERR_COMM-style text
   int agree(ucg_ctx *ctx, const char *where)
@@ -278,7 +329,7 @@ struct LocalStatus {
 
 // CommBrick::exchange + borders: every bead to the rank that owns its wrapped position, then the images every
 // rank's extended brick needs; afterwards bins and rows are rebuilt (ucg_border_unpack).  Ends with a status agreement.
-int multi_rebuild(ucg_ctx *ctx)
+int multi_rebuild(ucg_ctx *ctx, const LocalStatus *held = nullptr)
 {
   CommState &C = *ctx->comm;
   const size_t w = (size_t) C.world;
@@ -286,6 +337,7 @@ int multi_rebuild(ucg_ctx *ctx)
   ucg_record_bytes(&arec, &hrec);
   std::vector<long long> sc(w, 0), rc(w, 0), sb(w, 0), rb(w, 0);
   LocalStatus st;
+  if (held && held->bad != UCG_OK) st = *held;  // a rank that has already failed sends nothing and reports at the agreement
   auto zero = [&]() {
     if (st.bad != UCG_OK) std::fill(sc.begin(), sc.end(), 0LL);
   };
@@ -406,49 +458,52 @@ int multi_pair_compute(ucg_ctx *ctx, int ev, LocalStatus *ls = nullptr)
   return UCG_OK;
 }
 
-// FixClusterSwitch across ranks: the reductions the reference does with MPI_Allreduce
-int multi_cluster_sync_after_create(ucg_ctx *ctx)
+// FixClusterSwitch across ranks: the reductions the reference does with MPI_Allreduce.  Local calls run through `st`
+// (a rank-local failure is held and the rank keeps taking part in every collective with whatever it has), the
+// collectives are unconditional: their number and sizes are the same on every rank.
+void multi_cluster_sync_after_create(ucg_ctx *ctx, LocalStatus &st)
 {
-  long long s[3];
-  UCG_RC(ucg_fix_cluster_switch_scalars(ctx, s));
+  long long s[3] = {0, 0, 0};
+  st.run(ctx, [&] { return ucg_fix_cluster_switch_scalars(ctx, s); });
   allreduce_ll(ctx, &s[0], 1, 1);
   allreduce_ll(ctx, &s[1], 2, 0);
-  UCG_RC(ucg_fix_cluster_switch_set_scalars(ctx, s[0], s[1], s[2]));
-  const int n = ucg_fix_cluster_switch_maxmol(ctx) + 1;
-  std::vector<int> a((size_t) n);
+  st.run(ctx, [&] { return ucg_fix_cluster_switch_set_scalars(ctx, s[0], s[1], s[2]); });
+  // maxmol is the all-reduced value on every rank that is still fine; a failed rank takes the peers' size from s[0]
+  const int n = (int) s[0] + 1;
+  std::vector<int> a((size_t) (n > 0 ? n : 1), 0);
   for (int which : {1, 2, 4}) {  // mol_state, mol_restrict, presence
-    UCG_RC(ucg_fix_cluster_switch_array(ctx, which, a.data()));
+    st.run(ctx, [&] { return ucg_fix_cluster_switch_array(ctx, which, a.data()); });
     allreduce_int_array(ctx, a, 1);
-    UCG_RC(ucg_fix_cluster_switch_set_array(ctx, which, a.data()));
+    st.run(ctx, [&] { return ucg_fix_cluster_switch_set_array(ctx, which, a.data()); });
   }
   ctx->comm->cluster_synced = true;
-  return UCG_OK;
 }
 
 // check_cluster + attempt_switch on fresh lists (UCG/fix_cluster_switch.cpp:452-469)
-int multi_cluster_step(ucg_ctx *ctx)
+void multi_cluster_step(ucg_ctx *ctx, LocalStatus &st)
 {
-  const int n = ucg_fix_cluster_switch_maxmol(ctx) + 1;
-  std::vector<int> a((size_t) n);
+  const int n = ucg_fix_cluster_switch_maxmol(ctx) + 1;  // all-reduced at creation: the same on every rank
+  std::vector<int> a((size_t) (n > 0 ? n : 1), 0);
   int changed = 0;
-  UCG_RC(ucg_fix_cluster_switch_sweep(ctx, 1, &changed));
+  st.run(ctx, [&] { return ucg_fix_cluster_switch_sweep(ctx, 1, &changed); });
   for (;;) {
-    UCG_RC(ucg_fix_cluster_switch_array(ctx, 5, a.data()));
+    st.run(ctx, [&] { return ucg_fix_cluster_switch_array(ctx, 5, a.data()); });
     allreduce_int_array(ctx, a, 2);
-    UCG_RC(ucg_fix_cluster_switch_set_array(ctx, 5, a.data()));
-    long long any = changed;
+    st.run(ctx, [&] { return ucg_fix_cluster_switch_set_array(ctx, 5, a.data()); });
+    long long any = st.bad == UCG_OK ? changed : 0;  // a failed rank sweeps no more: the others' labels still converge
     allreduce_ll(ctx, &any, 1, 1);
     if (!any) break;
-    UCG_RC(ucg_fix_cluster_switch_sweep(ctx, 0, &changed));
+    changed = 0;
+    st.run(ctx, [&] { return ucg_fix_cluster_switch_sweep(ctx, 0, &changed); });
   }
-  UCG_RC(ucg_fix_cluster_switch_finalize(ctx));
-  UCG_RC(ucg_fix_cluster_switch_attempt_local(ctx));
-  UCG_RC(ucg_fix_cluster_switch_array(ctx, 3, a.data()));
+  st.run(ctx, [&] { return ucg_fix_cluster_switch_finalize(ctx); });
+  st.run(ctx, [&] { return ucg_fix_cluster_switch_attempt_local(ctx); });
+  st.run(ctx, [&] { return ucg_fix_cluster_switch_array(ctx, 3, a.data()); });
   allreduce_int_array(ctx, a, 1);
-  UCG_RC(ucg_fix_cluster_switch_set_array(ctx, 3, a.data()));
-  UCG_RC(ucg_fix_cluster_switch_attempt_apply(ctx));
-  UCG_RC(ucg_fix_cluster_switch_advance(ctx));
-  return multi_halo_forward(ctx);  // comm->forward_comm(this): the ghosts' new atom types
+  st.run(ctx, [&] { return ucg_fix_cluster_switch_set_array(ctx, 3, a.data()); });
+  st.run(ctx, [&] { return ucg_fix_cluster_switch_attempt_apply(ctx); });
+  st.run(ctx, [&] { return ucg_fix_cluster_switch_advance(ctx); });
+  multi_halo_forward(ctx, &st);  // comm->forward_comm(this): the ghosts' new atom types
 }
 
 template <typename F>
@@ -495,27 +550,38 @@ int md_setup_multi(ucg_ctx *ctx)
     return UCG_ERR_INVALID;
   }
   return guarded_comm(ctx, [&]() -> int {
-    if (ctx->cs && !ctx->comm->cluster_synced) UCG_RC(multi_cluster_sync_after_create(ctx));
-    UCG_RC(multi_rebuild(ctx));
+    // Every local call runs through `ls`: a rank that fails anywhere in the setup keeps taking part in the collectives
+    // that follow (the halos of the density style, the thermo all-reduce) and all ranks return together from the final
+    // agreement (include/ucg_hip.h, "communicator of a decomposed run").
+    LocalStatus ls;
+    if (ctx->fault_setup) ls.fail(UCG_ERR_INVALID, "injected rank-local failure in the setup (option fault_inject_setup)");
+    if (ctx->cs && !ctx->comm->cluster_synced) {
+      multi_cluster_sync_after_create(ctx, ls);
+      UCG_RC(ls.agree(ctx, "in the survey of fix cluster_switch"));
+    }
+    UCG_RC(multi_rebuild(ctx, &ls));  // (ends with an agreement of its own)
     if (ctx->md_lang && !ctx->lang.inited) {
       // Fix_UCGLD_Langevin::init(): reads atom->ucgml[1..ntypes] of the LOCAL bead order (App. B #5)
-      std::vector<double> ml((size_t) ctx->ntypes + 1, 0.0);
-      const int cnt = ctx->ntypes + 1 <= ctx->nlocal ? ctx->ntypes + 1 : ctx->nlocal;
-      if (cnt > 0) {
-        UCG_HIP(hipMemcpyAsync(ml.data(), ctx->ucgml.get(), (size_t) cnt * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        UCG_HIP(hipStreamSynchronize(ctx->stream));
-      }
-      for (int i = cnt; i <= ctx->ntypes; i++) ml[(size_t) i] = cnt > 0 ? ml[0] : 1.0;
-      UCG_RC(ucg_fix_langevin_init_from_ucgml(ctx, ctx->ntypes, ml.data()));
+      ls.run(ctx, [&]() -> int {
+        std::vector<double> ml((size_t) ctx->ntypes + 1, 0.0);
+        const int cnt = ctx->ntypes + 1 <= ctx->nlocal ? ctx->ntypes + 1 : ctx->nlocal;
+        if (cnt > 0) {
+          UCG_HIP(hipMemcpyAsync(ml.data(), ctx->ucgml.get(), (size_t) cnt * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+          UCG_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        for (int i = cnt; i <= ctx->ntypes; i++) ml[(size_t) i] = cnt > 0 ? ml[0] : 1.0;
+        return ucg_fix_langevin_init_from_ucgml(ctx, ctx->ntypes, ml.data());
+      });
     }
-    UCG_RC(multi_pair_compute(ctx, 1));
-    if (ctx->md_lang) UCG_RC(ucg_fix_langevin_post_force(ctx, ctx->groupbit, ctx->ntimestep, ctx->beginstep, ctx->endstep));
-    if (ctx->md_ucgst) UCG_RC(ucg_fix_ucgstate_post_force(ctx));
-    return poll_pair_errors(ctx);
+    multi_pair_compute(ctx, 1, &ls);
+    if (ctx->md_lang)
+      ls.run(ctx, [&] { return ucg_fix_langevin_post_force(ctx, ctx->groupbit, ctx->ntimestep, ctx->beginstep, ctx->endstep); });
+    if (ctx->md_ucgst) ls.run(ctx, [&] { return ucg_fix_ucgstate_post_force(ctx); });
+    return poll_pair_errors(ctx, &ls);
   });
 }
 
-int md_run_multi(ucg_ctx *ctx, long long nsteps, int thermo_every)
+int md_run_multi(ucg_ctx *ctx, long long nsteps, int thermo_every, int ev_on_last)
 {
   return guarded_comm(ctx, [&]() -> int {
     ucg_pair *p = ctx->md_pair;
@@ -525,19 +591,10 @@ int md_run_multi(ucg_ctx *ctx, long long nsteps, int thermo_every)
     // next status agreement -- the re-neighbour decision's all-reduce, an error poll, the re-neighbouring itself -- where
     // every rank returns together; nothing local runs on this rank after the failure
     LocalStatus ls;
-    // test aid (tests/test_multi_rank.py): UCG_FAULT_INJECT="<rank> <timestep>" makes that rank fail locally at that step
-    int fault_rank = -1;
-    long long fault_step = -1;
-    if (const char *fi = getenv("UCG_FAULT_INJECT")) {
-      if (sscanf(fi, "%d %lld", &fault_rank, &fault_step) != 2) fault_rank = -1;
-    }
     for (long long s = 0; s < nsteps; s++) {
       ctx->ntimestep++;
-      if (fault_rank == ctx->comm->rank && fault_step == ctx->ntimestep && ls.bad == UCG_OK) {
-        ls.bad = UCG_ERR_INVALID;
-        ls.msg = "injected rank-local failure (UCG_FAULT_INJECT)";
-      }
-      const int ev = (thermo_every > 0 && (ctx->ntimestep % thermo_every == 0)) ? 1 : 0;
+      if (ctx->fault_step == ctx->ntimestep) ls.fail(UCG_ERR_INVALID, "injected rank-local failure (option fault_inject_step)");
+      const int ev = ((thermo_every > 0 && (ctx->ntimestep % thermo_every == 0)) || (ev_on_last && s + 1 == nsteps)) ? 1 : 0;
       if (ctx->md_nve && !initial_done)
         ls.run(ctx, [&] { return ctx->md_nve == 2 ? ucg_fix_nve_wall_hard_initial(ctx, ctx->groupbit) : ucg_fix_nve_initial(ctx, ctx->groupbit); });
       int due = 0, flag = 0;
@@ -558,8 +615,11 @@ int md_run_multi(ucg_ctx *ctx, long long nsteps, int thermo_every)
         UCG_RC(multi_rebuild(ctx));
         if (ctx->cs) {
           int forced = 0, switching = 0;
-          UCG_RC(ucg_fix_cluster_switch_due(ctx, &forced, &switching));
-          if (switching) UCG_RC(multi_cluster_step(ctx));
+          UCG_RC(ucg_fix_cluster_switch_due(ctx, &forced, &switching));  // (a function of the timestep alone: in step on every rank)
+          if (switching) {
+            multi_cluster_step(ctx, ls);
+            UCG_RC(poll_pair_errors(ctx, &ls));  // agreement: a rank that failed inside the switch stops everyone here
+          }
         }
       } else {
         multi_halo_forward(ctx, &ls);
@@ -608,6 +668,28 @@ int ucg_comm_attach(ucg_ctx *ctx, const ucg_comm_ops *ops)
   return UCG_OK;
 }
 
+int ucg_comm_attach_host(ucg_ctx *ctx, const ucg_comm_ops *ops)
+{
+  const int rc = ucg_comm_attach(ctx, ops);
+  if (rc == UCG_OK) ctx->comm->host_staged = true;
+  return rc;
+}
+
+int ucg_comm_transport(const ucg_ctx *ctx, int *out4)
+{
+  if (!ctx || !ctx->comm || !out4) return UCG_ERR_INVALID;
+  const CommState &C = *ctx->comm;
+  out4[0] = C.rccl ? 1 : 0;
+  out4[1] = 0;
+  out4[2] = -1;
+  out4[3] = C.host_staged ? 1 : 0;
+  if (C.rccl && C.nccl && g_rccl.loaded) {
+    // asked of RCCL itself, not of what the caller passed to ucg_comm_attach_rccl
+    if (g_rccl.CommCount(C.nccl, &out4[1]) != 0 || g_rccl.CommCuDevice(C.nccl, &out4[2]) != 0) return UCG_ERR_COMM;
+  }
+  return UCG_OK;
+}
+
 int ucg_comm_rccl_unique_id(ucg_rccl_id *out)
 {
   if (!out) return UCG_ERR_INVALID;
@@ -636,6 +718,8 @@ int ucg_comm_attach_rccl(ucg_ctx *ctx, const ucg_rccl_id *id, int rank, int worl
   ctx->comm = new CommState();
   ctx->comm->attached = true;
   ctx->comm->rccl = true;
+  const char *selfenv = getenv("UCG_RCCL_SELF_SEND");
+  ctx->comm->self_copy = !(selfenv && selfenv[0] == '1');
   ctx->comm->nccl = comm;
   ctx->comm->rank = rank;
   ctx->comm->world = world;

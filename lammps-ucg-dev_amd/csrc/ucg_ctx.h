@@ -91,6 +91,7 @@ struct FixLangevin {
   double t_start = 0, t_stop = 0, t_period = 0, t_target = 0, tsqrt = 0;
   int seed = 0, ntypes = 0;
   bool inited = false;
+  bool bias = false;  // fix_modify temp with a bias-removing compute: post_force_templated<1> (ucg_fix_langevin_set_bias)
   DevBuf<double> gf1, gf2;
   RanMarsDev rng{};
   DevBuf<unsigned int> hist0, hist1, draws;
@@ -195,6 +196,10 @@ struct ucg_ctx {
   long long ntimestep = 0, beginstep = 0, endstep = 0;
   int groupbit = 1;
   long long nrebuild = 0, pair_error_steps = 0;
+  // test aid, options "fault_inject_step" / "fault_inject_setup" (tests/test_multi_rank.py): the rank whose context has them
+  // set fails locally at that timestep of ucg_md_run / inside ucg_md_setup; off (-1 / false) unless a test sets them
+  long long fault_step = -1;
+  bool fault_setup = false;
   double thermo[9] = {0};
   ucg::HostMirror mirror;
   // profiling
@@ -252,7 +257,7 @@ void domain_destroy(ucg_ctx *ctx);
 void cluster_destroy(ucg_ctx *ctx);
 void comm_destroy(ucg_ctx *ctx);
 int md_setup_multi(ucg_ctx *ctx);
-int md_run_multi(ucg_ctx *ctx, long long nsteps, int thermo_every);
+int md_run_multi(ucg_ctx *ctx, long long nsteps, int thermo_every, int ev_on_last);
 bool cluster_forces_rebuild(const ucg_ctx *ctx);
 void cluster_pre_exchange(ucg_ctx *ctx);
 }

@@ -86,6 +86,7 @@ struct PostDev {
   int enabled;
   int lang, ucgst, nve;  // which hooks (nve: 0 none, 1 nve/ucgld, 2 nve/ucgld/wall/hard, 3 + bias_potential)
   int ld_flag, mc_flag, groupbit;
+  int lang_bias;         // LangevinDev::bias
   double mc_rate, tsqrt, dtv, dtf, barrier;
   const double *gfactor1, *gfactor2;
   const unsigned int *lang_draws, *mc_draws;

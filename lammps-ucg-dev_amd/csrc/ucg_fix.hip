@@ -106,8 +106,10 @@ __global__ __launch_bounds__(FIX_BLOCK) void k_langevin(const AtomsDev A, const 
   const double gamma2 = Lg.gfactor2[t] * Lg.tsqrt;
   // RanMars::uniform() is an exact multiple of 2^-24
   const double uni = (double) Lg.draws[i] * 5.9604644775390625e-08;
-  const double fran = gamma2 * (uni - 0.5);
-  const double fdrag = gamma1 * A.vel4[i].w;
+  double fran = gamma2 * (uni - 0.5);
+  const double vl = A.vel4[i].w;
+  if (Lg.bias && vl == 0.0) fran = 0.0;  // post_force_templated<1> (UCG/fix_ucgld_langevin.cpp:283-291)
+  const double fdrag = gamma1 * vl;
   double4 f = A.frc4[i];
   f.w += fdrag + fran;
   A.frc4[i] = f;
@@ -190,7 +192,8 @@ __global__ __launch_bounds__(FIX_BLOCK) void k_post_fused(const AtomsDev A, cons
     const double gamma1 = Lg.gfactor1[t];
     const double gamma2 = Lg.gfactor2[t] * Lg.tsqrt;
     const double uni = (double) Lg.draws[i] * 5.9604644775390625e-08;
-    const double fran = gamma2 * (uni - 0.5);
+    double fran = gamma2 * (uni - 0.5);
+    if (Lg.bias && v.w == 0.0) fran = 0.0;
     const double fdrag = gamma1 * v.w;
     f.w += fdrag + fran;
     f_dirty = true;

@@ -49,6 +49,7 @@ struct LangevinDev {
   const double *gfactor1, *gfactor2;  // [ntypes+1]
   double tsqrt;
   const unsigned int *draws;  // 24-bit RanMars integers, one per owned bead
+  int bias;                   // post_force_templated<1>: no random force on a bead whose lambda velocity is exactly 0
 };
 hipError_t launch_nve_initial(const AtomsDev &A, double dtv, double dtf, int groupbit, int wall, hipStream_t st);
 hipError_t launch_nve_final(const AtomsDev &A, double dtf, int groupbit, int wall, hipStream_t st);

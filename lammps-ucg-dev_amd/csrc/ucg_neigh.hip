@@ -1360,6 +1360,9 @@ int ucg_halo_forward(ucg_ctx *ctx)
   if (!ctx) return UCG_ERR_INVALID;
   if (int rc = need_domain(ctx)) return rc;
   return guarded(ctx, [&]() -> int {
+    // fields_comm (UCG/atom_vec_ucg.cpp:71): the ghosts get their owners' x, ucgstate, ucgl, ucgp -- a host-side edit of any
+    // of them announced with ucg_host_modified has to be on the device first, or owners and ghosts would disagree
+    mirror_need(ctx, UCG_F_X | UCG_F_STATE | UCG_F_UCGL | UCG_F_UCGP);
     halo_forward(ctx);
     return UCG_OK;
   });
@@ -1481,12 +1484,26 @@ int ucg_md_setup(ucg_ctx *ctx, long long nsteps_planned)
   return ucg_pair_check_errors(ctx->md_pair);
 }
 
-int ucg_md_run(ucg_ctx *ctx, long long nsteps, int thermo_every)
+static int md_run_impl(ucg_ctx *ctx, long long nsteps, int thermo_every, int ev_on_last);
+
+int ucg_md_run(ucg_ctx *ctx, long long nsteps, int thermo_every) { return md_run_impl(ctx, nsteps, thermo_every, 0); }
+
+int ucg_md_run_until(ucg_ctx *ctx, long long nsteps, int ev_on_last) { return md_run_impl(ctx, nsteps, 0, ev_on_last ? 1 : 0); }
+
+int ucg_md_set_window(ucg_ctx *ctx, long long beginstep, long long endstep)
+{
+  if (!ctx || endstep < beginstep) return UCG_ERR_INVALID;
+  ctx->beginstep = beginstep;
+  ctx->endstep = endstep;
+  return UCG_OK;
+}
+
+static int md_run_impl(ucg_ctx *ctx, long long nsteps, int thermo_every, int ev_on_last)
 {
   if (!ctx || !ctx->md_pair) return UCG_ERR_INVALID;
   if (int rc = need_domain(ctx)) return rc;
   if (int rc = guarded(ctx, [&]() -> int { mirror_need(ctx, UCG_F_ALL); mirror_wrote(ctx, UCG_F_ALL); return UCG_OK; })) return rc;
-  if (ctx->comm) return md_run_multi(ctx, nsteps, thermo_every);  // decomposed run: csrc/ucg_comm.hip
+  if (ctx->comm) return md_run_multi(ctx, nsteps, thermo_every, ev_on_last);  // decomposed run: csrc/ucg_comm.hip
   // Per step (upstream Verlet::run):
   //   initial_integrate | decide -> rebuild or halo refresh | pair | post_force fixes | final_integrate | end_of_step
   // The per-bead hooks after the pair kernel run as ONE fused kernel; when no thermo output has to
@@ -1495,7 +1512,7 @@ int ucg_md_run(ucg_ctx *ctx, long long nsteps, int thermo_every)
   bool initial_done = false;
   for (long long s = 0; s < nsteps; s++) {
     ctx->ntimestep++;
-    const int ev = (thermo_every > 0 && (ctx->ntimestep % thermo_every == 0)) ? 1 : 0;
+    const int ev = ((thermo_every > 0 && (ctx->ntimestep % thermo_every == 0)) || (ev_on_last && s + 1 == nsteps)) ? 1 : 0;
     int rc;
     if (ctx->md_nve && !initial_done &&
         (rc = ctx->md_nve == 2 ? ucg_fix_nve_wall_hard_initial(ctx, ctx->groupbit) : ucg_fix_nve_initial(ctx, ctx->groupbit)))
@@ -1904,6 +1921,7 @@ int ucg_decide_local(ucg_ctx *ctx, int *due, int *flag)
       }
       const DomainDev dd = make_dev(D);
       D.blockflags.reserve((size_t) nblk(ctx->nlocal) + 1);
+      mirror_need(ctx, UCG_F_X);  // the distance check reads the owned positions
       if (ctx->nlocal > 0)
         hipLaunchKernelGGL(k_check_distance, dim3(nblk(ctx->nlocal)), dim3(NB), 0, ctx->stream, dd, ctx->nlocal,
                            ctx->pos4.get(), D.xhold.get(), D.blockflags.get());

@@ -33,21 +33,23 @@ namespace ucg {
 namespace {
 
 // A neighbour's record {x, y, z, lambda | type, state}: from the workgroup's LDS copy when it is one of its own beads,
-// else through L1 / L2.  Written as one select of the two pointers, which the compiler turns into generic-address
-// (flat) loads.  Measured alternative (round 2): two branches, an LDS read and a global load each under its lane mask,
-// are SLOWER (422 -> 472 us at 1 M beads): both write the same registers, so every LDS read waits for the other
-// lanes' outstanding global loads (vmcnt), and the two serial branch bodies cost more than the flat path.
+// else through L1 / L2.  ONE instruction stream: the LDS or the global address is selected per lane as a generic
+// pointer and read with generic-address (flat) loads.  The alternative -- an LDS read and a global load, each under its
+// lane mask -- is SLOWER (round 2: 422 -> 472 us at 1 M beads; round 3's build fell into it unnoticed, 407 -> 455 us on one
+// box, profiles/r04_ab_r02_vs_r03.json): both branches write the same registers, so every LDS read waits for the other
+// lanes' outstanding global loads (vmcnt), and the two serial branch bodies cost more than the flat path.  The compiler
+// turns a plain `cond ? lds[i] : global[j]` into either form depending on the surrounding code, so the selected pointers
+// are passed through an empty asm statement: behind it their address space is unknown and flat loads are the only choice.
 __device__ __forceinline__ void gather_bead_split(const AtomsDev &A, const double4 *s_ownpos, const int *s_ownmeta, const int k0,
                                                   const unsigned nown, const int m, double4 &pm, int &mm)
 {
   const unsigned ml = (unsigned) (m - k0);
-  if (ml < nown) {
-    pm = s_ownpos[ml];
-    mm = s_ownmeta[ml];
-  } else {
-    pm = A.pos4[m];
-    mm = A.meta[m];
-  }
+  const bool own = ml < nown;
+  const double4 *pp = own ? s_ownpos + ml : A.pos4 + m;
+  const int *mp = own ? s_ownmeta + ml : A.meta + m;
+  asm volatile("" : "+v"(pp), "+v"(mp));
+  pm = *pp;
+  mm = *mp;
 }
 
 // SCE (table_ucg_bethe): -1 = P.pseudo_flag decides at run time; 0 = pseudo-likelihood scores only (`pseudo yes`), the

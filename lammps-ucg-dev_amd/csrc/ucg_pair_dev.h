@@ -299,7 +299,8 @@ __device__ __forceinline__ void pair_epilogue(const AtomsDev &A, const PostDev &
       const double gamma1 = Q.gfactor1[tk];
       const double gamma2 = Q.gfactor2[tk] * Q.tsqrt;
       const double uni = (double) Q.lang_draws[k] * 5.9604644775390625e-08;
-      const double fran = gamma2 * (uni - 0.5);
+      double fran = gamma2 * (uni - 0.5);
+      if (Q.lang_bias && v.w == 0.0) fran = 0.0;
       const double fdrag = gamma1 * v.w;
       f.w += fdrag + fran;
     }

@@ -14,13 +14,33 @@
 
 typedef int MPI_Comm;
 typedef int MPI_Datatype;
+typedef int MPI_Op;
 #define MPI_INT 1
+#define MPI_BYTE 2
+#define MPI_LONG_LONG 3
+#define MPI_DOUBLE 4
+#define MPI_SUM 1
+#define MPI_MAX 2
+#define MPI_MIN 3
+#define MPI_SUCCESS 0
+#define MPI_IN_PLACE ((void *) 1)
+#define MPI_COMM_NULL 0
 int MPI_Bcast(void *, int, MPI_Datatype, int, MPI_Comm);
+int MPI_Comm_split(MPI_Comm, int color, int key, MPI_Comm *newcomm);
+int MPI_Comm_free(MPI_Comm *);
+int MPI_Alltoall(const void *, int, MPI_Datatype, void *, int, MPI_Datatype, MPI_Comm);
+int MPI_Alltoallv(const void *, const int *, const int *, MPI_Datatype, void *, const int *, const int *, MPI_Datatype, MPI_Comm);
+int MPI_Allreduce(const void *, void *, int, MPI_Datatype, MPI_Op, MPI_Comm);
 
 namespace LAMMPS_NS {
 
 typedef int tagint;
+typedef int imageint;
 typedef int64_t bigint;
+#define IMGMASK 1023
+#define IMGMAX 512
+#define IMGBITS 10
+#define IMG2BITS 20
 #define NEIGHMASK 0x1FFFFFFF
 #define SBBITS 30
 #define FLERR __FILE__, __LINE__
@@ -40,6 +60,9 @@ class Modify;
 class Output;
 class Pair;
 class Fix;
+class Compute;
+class Group;
+class Timer;
 
 class Pointers {
  public:
@@ -58,7 +81,11 @@ class Pointers {
   Force *&force;
   Modify *&modify;
   Output *&output;
+  Group *&group;
+  Timer *&timer;
   MPI_Comm &world;
+  FILE *&screen;
+  FILE *&logfile;
 };
 
 class LAMMPS {
@@ -73,7 +100,10 @@ class LAMMPS {
   Force *force;
   Modify *modify;
   Output *output;
+  Group *group;
+  Timer *timer;
   MPI_Comm world;
+  FILE *screen, *logfile;
 };
 
 class Error : protected Pointers {
@@ -84,6 +114,8 @@ class Error : protected Pointers {
   template <typename... Args> [[noreturn]] void all(const std::string &file, int line, const std::string &fmt, Args &&...args);
   template <typename... Args> [[noreturn]] void all(const std::string &file, int line, int errptr, const std::string &fmt, Args &&...args);
   template <typename... Args> [[noreturn]] void one(const std::string &file, int line, const std::string &fmt, Args &&...args);
+  void warning(const std::string &file, int line, const std::string &msg);
+  template <typename... Args> void warning(const std::string &file, int line, const std::string &fmt, Args &&...args);
 };
 
 class Memory : protected Pointers {
@@ -98,6 +130,9 @@ bool strmatch(const std::string &text, const std::string &pattern);
 double numeric(const char *file, int line, const std::string &str, bool do_abort, LAMMPS *lmp);
 int inumeric(const char *file, int line, const std::string &str, bool do_abort, LAMMPS *lmp);
 void sfread(const char *file, int line, void *s, size_t size, size_t num, FILE *fp, const char *filename, Error *error);
+void missing_cmd_args(const std::string &file, int line, const std::string &cmd, Error *error);
+char *strdup(const std::string &text);
+void logmesg(LAMMPS *lmp, const std::string &mesg);
 }    // namespace utils
 
 class Atom : protected Pointers {
@@ -106,7 +141,8 @@ class Atom : protected Pointers {
   enum { ATOMIC = 0, MOLECULAR = 1, TEMPLATE = 2 };
   enum { MAP_NONE = 0, MAP_ARRAY = 1, MAP_HASH = 2, MAP_YES = 3 };
   Atom(LAMMPS *);
-  int nlocal, nghost, ntypes;
+  int nlocal, nghost, ntypes, nmax;
+  bigint natoms;
   int map_style;
   int molecule_flag, q_flag;
   AtomVec *avec;
@@ -114,11 +150,16 @@ class Atom : protected Pointers {
   int *type, *mask;
   tagint *molecule;
   double **x, **v, **f;
+  double *q;
+  imageint *image;
   double *mass, *rmass;
   int *num_bond, *num_angle, *num_dihedral, *num_improper;
   int **nspecial;
   void add_peratom(const std::string &name, void *address, int datatype, int cols, int threadflag = 0);
   int map(tagint global);
+  void map_init(int check = 1);
+  void map_set();
+  void setup();
 };
 
 class AtomVec : protected Pointers {
@@ -131,6 +172,7 @@ class AtomVec : protected Pointers {
   int forceclearflag;
   std::vector<std::string> fields_grow, fields_copy, fields_comm, fields_comm_vel, fields_reverse, fields_border,
       fields_border_vel, fields_exchange, fields_restart, fields_create, fields_data_atom, fields_data_vel;
+  virtual void grow(int);
   virtual void grow_pointers() {}
   virtual void force_clear(int, size_t) {}
   virtual void data_atom_post(int) {}
@@ -144,21 +186,36 @@ class AtomVec : protected Pointers {
 class Integrate : protected Pointers {
  public:
   Integrate(LAMMPS *, int, char **);
+  virtual void init();
+  virtual void setup(int flag) = 0;
+  virtual void setup_minimal(int) = 0;
+  virtual void run(int) = 0;
+  virtual void force_clear() = 0;
+  virtual void cleanup() {}
+  virtual void reset_dt() {}
+  virtual double memory_usage() { return 0; }
+
+ protected:
+  int eflag, vflag;
 };
 class Respa : public Integrate {
  public:
   Respa(LAMMPS *, int, char **);
   int nlevels;
   double *step;
+  void copy_f_flevel(int);
+  void copy_flevel_f(int);
 };
 
 class Update : protected Pointers {
  public:
   Update(LAMMPS *);
   double dt;
-  bigint ntimestep, beginstep, endstep;
+  bigint ntimestep, beginstep, endstep, firststep, laststep;
+  int setupflag, whichflag;
   char *integrate_style;
   Integrate *integrate;
+  void update_time();
 };
 
 class Force : protected Pointers {
@@ -174,6 +231,33 @@ class Modify : protected Pointers {
   Modify(LAMMPS *);
   int nfix;
   Fix **fix;
+  Compute *get_compute_by_id(const std::string &) const;
+  void post_run();
+  void setup(int);
+};
+
+class Compute : protected Pointers {
+ public:
+  Compute(LAMMPS *, int, char **);
+  char *id;
+  int igroup;
+  int tempflag, tempbias;
+  virtual double compute_scalar() { return 0.0; }
+};
+
+class Group : protected Pointers {
+ public:
+  Group(LAMMPS *);
+  char **names;
+};
+
+class Timer : protected Pointers {
+ public:
+  enum ttype { RESET = -2, START = -1, TOTAL = 0, PAIR, BOND, KSPACE, NEIGH, COMM, MODIFY, OUTPUT, SYNC, ALL };
+  Timer(LAMMPS *);
+  void stamp();
+  void stamp(enum ttype);
+  void init_timeout();
 };
 
 class Domain : protected Pointers {
@@ -181,18 +265,28 @@ class Domain : protected Pointers {
   Domain(LAMMPS *);
   double boxlo[3], boxhi[3], prd[3];
   int triclinic;
+  int xperiodic, yperiodic, zperiodic;
+  void pbc();
+  void reset_box();
+  void box_too_small_check();
 };
 
 class Output : protected Pointers {
  public:
   Output(LAMMPS *);
   bigint next;    // next timestep with any output (thermo, dump, restart)
+  bigint next_thermo;
+  void setup(int memflag = 1);
+  void write(bigint);
 };
 
 class Comm : protected Pointers {
  public:
   Comm(LAMMPS *);
+  enum { LAYOUT_UNIFORM, LAYOUT_NONUNIFORM, LAYOUT_TILED };
   int me, nprocs;
+  int layout;
+  int procgrid[3], myloc[3];
   virtual void forward_comm(Pair *, int size = 0);
 };
 
@@ -260,6 +354,7 @@ enum {
 class Fix : protected Pointers {
  public:
   Fix(LAMMPS *, int, char **);
+  ~Fix() override = default;
   char *id, *style;
   int igroup, groupbit;
   int nevery, time_integrate, dynamic_group_allow, force_reneighbor;
@@ -275,6 +370,10 @@ class Fix : protected Pointers {
   virtual void final_integrate_respa(int, int) {}
   virtual void end_of_step() {}
   virtual void pre_exchange() {}
+  virtual void post_run() {}
+  virtual void post_force_respa(int, int, int) {}
+  virtual void reset_target(double) {}
+  virtual int modify_param(int, char **) { return 0; }
   virtual void reset_dt() {}
   virtual double compute_scalar() { return 0.0; }
   virtual double compute_vector(int) { return 0.0; }

@@ -1,0 +1,1 @@
+#include "lammps_api_decl.h"

@@ -95,10 +95,17 @@ def main():
         pair = util.gpu_pair(ctx, "table_ucgld", deck)
         tr = multi.Transport(dist, torch.device("cuda", 0), staged=True)
         sim = multi.RankSim(ctx, pair, tr, grid, use_langevin=False, use_ucgstate=False)
-        sim.setup(40)
-        os.environ["UCG_FAULT_INJECT"] = "1 7"
+        where = os.environ.get("UCG_TEST_FAULT", "step")
         code, msg = 0, ""
         try:
+            if where == "setup":  # inside ucg_md_setup, after the re-neighbouring's own agreement
+                if rank == 1:
+                    ctx.set_option("fault_inject_setup", 1)
+                sim.setup(40)
+            else:
+                sim.setup(40)
+                if rank == 1:
+                    ctx.set_option("fault_inject_step", 7)
             sim.run(40)
         except capi.UcgError as e:
             code, msg = e.code, e.msg

@@ -193,3 +193,86 @@ def test_host_built_ghosts_and_list_are_refreshed_on_the_device(pkg):
     for c, g in ((A, gpa), (B, gpb)):
         g.close()
         c.close()
+
+
+@pytest.mark.parametrize("entry", ["halo_forward", "decide_local", "langevin_end_of_step", "md_post_fused", "md_pair_post"])
+def test_every_entry_point_uploads_host_edits_before_it_reads_or_overwrites_them(pkg, entry):
+    """ucg_halo_forward, ucg_decide_local, ucg_fix_langevin_end_of_step read device fields, and
+    ucg_md_post_fused / ucg_md_pair_post overwrite all of them, without asking the mirror protocol first -- a field the caller
+    had announced with ucg_host_modified was refreshed from stale device data (ghosts) or silently dropped.  Here the caller
+    edits x / ucgvl between two hooks, and every such entry point must act on the EDITED values: compared with a second
+    context on which the same edit is made directly on the device copy (ucg_atoms_upload_owned)."""
+    deck = util.make_deck("spline", 1024)
+    beads = pkg.synth.make_beads(8, seed=77)
+    C = pkg.capi.Context
+    lang = (1.0, 1.0, 1.0, 48279)
+    out = []
+    for bound in (True, False):
+        ctx, gp = _setup(pkg, beads, deck, "table_ucgld", 0.004, 1, lang, "ld", True)
+        M = _mirror_arrays(beads.n)
+        if bound:
+            ctx.host_bind(M)
+        ctx.md_setup(10)
+        ctx.verlet_hooks_run(gp, 3, nve="wall", langevin=True, ucgstate=True)
+        if bound:
+            ctx.host_sync(C.F_ALL)
+            A = M
+        else:
+            A = ctx.atoms_download()
+        # the caller's edit: every bead shifted by a tenth of the skin (no re-neighbouring is triggered, but the distance
+        # check and the ghosts see it) and lambda's velocity reversed
+        x = A["x"] + 0.03
+        vl = -A["ucgvl"]
+        if bound:
+            M["x"][:] = x
+            M["ucgvl"][:] = vl
+            ctx.host_modified(C.F_X | C.F_UCGVL)
+            up0 = ctx.host_status()["uploads"]
+        else:
+            ctx.atoms_upload_owned(x=x, ucgvl=vl)
+        res = {}
+        if entry == "halo_forward":
+            ctx.halo_forward()
+            G = ctx.atoms_download(with_ghosts=True)
+            res["ghost_x"] = G["x"][G["nlocal"]:]
+        elif entry == "decide_local":
+            # the positions held at the last re-neighbouring differ from the edited ones by 0.03 * sqrt(3) < skin / 2 = 0.15;
+            # a second edit of 0.2 per coordinate must trip the check
+            due, flag = ctx.decide_local()
+            res["first"] = np.array([due, flag])
+            x2 = x + 0.2
+            if bound:
+                M["x"][:] = x2
+                ctx.host_modified(C.F_X)
+            else:
+                ctx.atoms_upload_owned(x=x2)
+            due, flag = ctx.decide_local()
+            assert due == 1 and flag == 1
+            res["second"] = np.array([due, flag])
+        elif entry == "langevin_end_of_step":
+            res["lambda_temp"] = np.array([ctx.fix_ucgld_langevin_end_of_step()])
+            assert res["lambda_temp"][0] > 0.0
+        elif entry == "md_post_fused":
+            ctx.md_post_fused(True, True, 2, False, 4, 0, 10)
+        else:
+            ctx.halo_forward()
+            ctx.md_pair_post(gp, True, True, 2, 4, 0, 10)
+        # what the entry point reads must have gone up (one upload); an announced field it does not touch may stay behind
+        reads = {"halo_forward": C.F_X, "decide_local": C.F_X, "langevin_end_of_step": C.F_UCGVL}.get(entry, C.F_X | C.F_UCGVL)
+        if bound:
+            st = ctx.host_status()
+            assert st["host_newer"] & reads == 0 and st["uploads"] > up0, st
+            if entry.startswith("md_"):
+                assert st["host_newer"] == 0, st
+        G = ctx.atoms_download()
+        for k in ("x", "v", "ucgl", "ucgvl"):
+            if k == "ucgvl" and not reads & C.F_UCGVL:
+                continue
+            if k in ("x", "ucgl") and not reads & C.F_X:
+                continue
+            res[k] = G[k]
+        out.append(res)
+        gp.close()
+        ctx.close()
+    for k in out[0]:
+        assert util.bits_equal(out[0][k], out[1][k]), (entry, k)

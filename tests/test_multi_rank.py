@@ -264,6 +264,17 @@ def test_a_rank_local_failure_stops_every_rank_together(pkg):
 
 
 @pytest.mark.gpu
+def test_a_rank_local_failure_in_the_setup_stops_every_rank_together(pkg, monkeypatch):
+    """the same promise for ucg_md_setup -- a rank that fails there (here: from its start) sends nothing in
+    the re-neighbouring, and BOTH ranks return from its closing agreement; neither goes on into a collective alone"""
+    monkeypatch.setenv("UCG_TEST_FAULT", "setup")
+    res = _launch("gpu_fault", world=2, timeout=240)
+    assert res[1]["code"] == 1 and "injected" in res[1]["msg"]
+    assert res[0]["code"] != 0 and "another rank" in res[0]["msg"]
+    assert res[0]["ntimestep"] == res[1]["ntimestep"] == 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("vrow", [0, 1])
 def test_world2_thermostatted_run_equals_the_decomposed_oracle_bit_for_bit(pkg, orc, vrow, monkeypatch):
     """fix ucgld/langevin + fix ucgstate mc + fix nve/ucgld/wall/hard on two ranks against the oracle's statement of the
