@@ -55,6 +55,8 @@ typedef struct ucg_pair ucg_pair;
 /* ------------------------------------------------------------------ context */
 
 int ucg_abi_version(void);
+/* visible HIP devices (0 when there is none or the runtime fails); touches no device */
+int ucg_device_count(void);
 /* device < 0: use the current HIP device */
 int ucg_ctx_create(int device, ucg_ctx **out);
 void ucg_ctx_destroy(ucg_ctx *ctx);

@@ -120,6 +120,12 @@ extern "C" {
 
 int ucg_abi_version(void) { return UCG_ABI_VERSION; }
 
+int ucg_device_count(void)
+{
+  int n = 0;
+  return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
 int ucg_ctx_create(int device, ucg_ctx **out)
 {
   if (!out) return UCG_ERR_INVALID;
@@ -372,6 +378,9 @@ int ucg_pair_init(ucg_pair *p, int ntypes, double T)
     D.tab = p->d_tab.get();
     D.tabpar = p->d_tabpar.get();
     D.pairtab = p->d_pairtab.get();
+    // one actual type whose mixed-state tables are one table (tabindex is symmetric after init_one, App. B #26): what the
+    // ONETYPE kernels assume at compile time
+    D.onetype_same10 = (M.n_actual == 1 && pairtab[((size_t) 1 * na1 + 1) * 4 + 1] == pairtab[((size_t) 1 * na1 + 1) * 4 + 2]) ? 1 : 0;
     D.cutsq = p->d_cutsq.get();
     D.mu = p->d_mu.get();
     D.prior_type = p->d_prior_type.get();

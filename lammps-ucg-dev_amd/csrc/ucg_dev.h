@@ -24,6 +24,7 @@ namespace ucg {
 struct PairDev {
   int style, tabstyle, tablength, tlm1;
   int n_actual;        // actual types are 1..n_actual
+  int onetype_same10;  // n_actual == 1 and tables (0,1) and (1,0) of the pair (1,1) are one table: the ONETYPE kernels apply
   int ntab;            // tables resident on the device (those reachable through tabindex)
   int tab_in_lds;      // 1: the kernels stage all tables in LDS
   int pseudo_flag, prior_flag, method_flag;

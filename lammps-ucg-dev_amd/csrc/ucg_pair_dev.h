@@ -109,23 +109,34 @@ __device__ __forceinline__ int grid_locate(const double4 par, const int tlm1, co
 
 // the same for the FAST kernels (one shared grid): instead of two compares and flag updates per pair they keep the
 // smallest r^2 and the largest raw knot index seen, and the two range tests are made once per row (range_flags)
+// (rsq < innersq  <=>  rsq - innersq < 0, the subtraction the knot index needs anyway: the inner test is the OR of the
+// differences' sign words -- one 32-bit instruction per pair where a running fmin cost three fp64 ones)
 struct RangeTrack {
-  double rsq_min;
+  int neg_or;
   int it_max;
 };
-__device__ __forceinline__ RangeTrack range_track_init() { return RangeTrack{1.0e300, -1}; }
+__device__ __forceinline__ RangeTrack range_track_init() { return RangeTrack{0, -1}; }
 __device__ __forceinline__ int grid_locate_track(const double4 par, const int tlm1, const double rsq, RangeTrack &rt)
 {
-  rt.rsq_min = fmin(rt.rsq_min, rsq);
-  const int raw = static_cast<int>((rsq - par.x) * par.z);
+  const double d = rsq - par.x;
+  rt.neg_or |= __double2hiint(d);
+  const int raw = static_cast<int>(d * par.z);
   rt.it_max = max(rt.it_max, raw);
   int it = min(raw, tlm1 - 1);
   if (it < 0) it = 0;
   return it;
 }
-__device__ __forceinline__ int range_flags(const double4 par, const int tlm1, const RangeTrack &rt)
+__device__ __forceinline__ int range_flags(const double4 /*par*/, const int tlm1, const RangeTrack &rt)
 {
-  return (rt.rsq_min < par.x ? 1 : 0) | (rt.it_max >= tlm1 ? 2 : 0);
+  return (rt.neg_or < 0 ? 1 : 0) | (rt.it_max >= tlm1 ? 2 : 0);
+}
+
+// a wavefront-uniform double, moved to scalar registers
+__device__ __forceinline__ double uniform_f64(const double v)
+{
+  const unsigned long long b = (unsigned long long) __double_as_longlong(v);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned) b), hi = __builtin_amdgcn_readfirstlane((unsigned) (b >> 32));
+  return __longlong_as_double((long long) (((unsigned long long) hi << 32) | lo));
 }
 
 struct Basis {
@@ -218,15 +229,19 @@ __device__ __forceinline__ void table_eval(TabPtr tab, const double4 par, const 
 
 // own-frame quad: u[a][b] = table(F(tk,a), F(tm,b)); equals the reference's u[b][a] when the
 // row owner is the pair's "j" (tabindex is symmetric after init_one)
-template <int TS, bool FAST, typename TabPtr>
+// SAME10: the caller knows t10 == t01 at compile time (one actual type: tabindex is symmetric after init_one, SURVEY.md
+// App. B #26), so the mixed-state values are one evaluation and one set of registers.  parF: the shared grid's parameters
+// held by the caller (scalar registers), instead of a read of s_par[0] per pair.
+template <int TS, bool FAST, bool SAME10 = false, typename TabPtr>
 __device__ __forceinline__ void eval_quad(TabPtr tab, const double4 *s_par, const int *pt, const int tablength,
                                           const int tlm1, const int fast_stride, const double rsq,
                                           const double factor_lj, Quad &q, int &err, RangeTrack &rt,
-                                          const double2 *lds_hot = nullptr, const bool hot = false, const int hot_k0 = -1)
+                                          const double2 *lds_hot = nullptr, const bool hot = false, const int hot_k0 = -1,
+                                          const double4 *parF = nullptr)
 {
   const int t00 = pt[0], t01 = pt[1], t10 = pt[2], t11 = pt[3];
   if (FAST) {
-    const double4 par = s_par[0];
+    const double4 par = parF ? *parF : s_par[0];
     const int it = grid_locate_track(par, tlm1, rsq, rt);
     const Basis B = grid_basis<TS>(par, it, rsq);
     // hot lanes (PairDev::hot_type: both beads of the actual type whose three tables are staged in LDS) read the LDS
@@ -243,7 +258,7 @@ __device__ __forceinline__ void eval_quad(TabPtr tab, const double4 *s_par, cons
     const int o00 = hb ? 0 : 2 * t00, o01 = hb ? 2 : 2 * t01, o10 = hb ? 2 : 2 * t10, o11 = hb ? 4 : 2 * t11;
     knot_eval_fast<TS>(rec + o00, st, par.w, B, q.f00, q.u00);
     knot_eval_fast<TS>(rec + o01, st, par.w, B, q.f01, q.u01);
-    if (t10 == t01) {
+    if (SAME10 || t10 == t01) {
       q.f10 = q.f01;
       q.u10 = q.u01;
     } else {

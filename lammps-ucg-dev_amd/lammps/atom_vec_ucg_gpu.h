@@ -22,6 +22,9 @@ AtomStyle(ucg,AtomVecUCG);
 
 namespace LAMMPS_NS {
 
+// neigh_modify delay of a run whose re-neighbour decision the package takes on the device (fix_ucg_gpu.cpp); never a user's value
+constexpr int UCG_GPU_DELAY_SENTINEL = 2000000000;
+
 class AtomVecUCG : virtual public AtomVec {
  public:
   AtomVecUCG(class LAMMPS *);

@@ -7,8 +7,10 @@
 #include "atom.h"
 #include "atom_vec_ucg_gpu.h"
 #include "comm.h"
+#include "compute.h"
 #include "error.h"
 #include "force.h"
+#include "group.h"
 #include "modify.h"
 #include "neighbor.h"
 #include "output.h"
@@ -43,6 +45,8 @@ void FixUCGGPUBase::init()
   check(ucg_ctx_set_units(ctx, force->boltz, force->ftm2v, force->mvv2e, update->dt, force->special_lj));
   const int *r = (const int *) force->pair->extract("ucg_resident", dim);
   resident = r ? *r : 0;
+  const int *d = (const int *) force->pair->extract("ucg_driver", dim);
+  driver = d ? *d : 0;
 }
 
 void FixUCGGPUBase::check(int rc)
@@ -82,10 +86,28 @@ FixNVEUCGLDGPU::FixNVEUCGLDGPU(LAMMPS *lmp, int narg, char **arg) : FixUCGGPUBas
   time_integrate = 1;
 }
 
+FixNVEUCGLDGPU::~FixNVEUCGLDGPU()
+{
+  restore_neigh_modify();
+}
+
 int FixNVEUCGLDGPU::setmask()
 {
-  // UCG/fix_nve_ucgld.cpp:27-34, plus the two hooks of the resident mode (no-ops otherwise)
-  return INITIAL_INTEGRATE | FINAL_INTEGRATE | INITIAL_INTEGRATE_RESPA | FINAL_INTEGRATE_RESPA | PRE_EXCHANGE | END_OF_STEP;
+  // UCG/fix_nve_ucgld.cpp:27-34, plus the hooks of the resident mode (no-ops otherwise)
+  return INITIAL_INTEGRATE | FINAL_INTEGRATE | INITIAL_INTEGRATE_RESPA | FINAL_INTEGRATE_RESPA | PRE_EXCHANGE | END_OF_STEP | POST_RUN;
+}
+
+void FixNVEUCGLDGPU::restore_neigh_modify()
+{
+  if (!neigh_taken) return;
+  neighbor->delay = saved_delay;
+  neighbor->every = saved_every;
+  neigh_taken = false;
+}
+
+void FixNVEUCGLDGPU::post_run()
+{
+  restore_neigh_modify();
 }
 
 void FixNVEUCGLDGPU::init()
@@ -95,14 +117,23 @@ void FixNVEUCGLDGPU::init()
   // atom style ucg has per-type masses (mass_type = PER_TYPE, UCG/atom_vec_ucg.cpp:36), so the reference's rmass branch
   // (UCG/fix_nve_ucgld.cpp:64-78, 124-138) is reachable only through atom_style hybrid with a per-atom-mass style
   if (atom->rmass) error->all(FLERR, "USER-UCG/GPU integrators use the per-type masses of atom style ucg");
+  restore_neigh_modify();    // (a run that ended in an error never reached post_run)
   if (resident) {
     // Neighbor::decide() would read x on the host every `every` steps: the distance check runs on the device instead
-    // (ucg_decide_local, with the neigh_modify settings the pair style saved) and a positive outcome is handed to LAMMPS
-    // through force_reneighbor / next_reneighbor; LAMMPS' own criterion is switched off by an unreachable delay
+    // (ucg_decide_local, with the neigh_modify settings the pair style saved in init_style(), which ran before this) and a
+    // positive outcome is handed to LAMMPS through force_reneighbor / next_reneighbor; LAMMPS' own criterion is switched
+    // off by an unreachable delay FOR THIS RUN ONLY: post_run() puts the user's values back (left in
+    // place they reached the pair style's next init_style() as "the user's delay" and the device never re-neighboured
+    // again in a second `run`)
     force_reneighbor = 1;
     next_reneighbor = -1;
-    neighbor->delay = 2000000000;
+    saved_delay = neighbor->delay;
+    saved_every = neighbor->every;
+    neigh_taken = true;
+    neighbor->delay = UCG_GPU_DELAY_SENTINEL;
     neighbor->every = 1;
+  } else {
+    force_reneighbor = 0;
   }
 }
 
@@ -226,14 +257,28 @@ FixUCGLDLangevinGPU::FixUCGLDLangevinGPU(LAMMPS *lmp, int narg, char **arg) : Fi
   if (seed <= 0) error->all(FLERR, "Illegal fix langevin command");
 }
 
+FixUCGLDLangevinGPU::~FixUCGLDLangevinGPU()
+{
+  delete[] id_temp;
+}
+
 int FixUCGLDLangevinGPU::setmask()
 {
-  return POST_FORCE | END_OF_STEP;    // :137-144 without the rRESPA hook
+  return POST_FORCE | POST_FORCE_RESPA | END_OF_STEP;    // :137-144
 }
 
 void FixUCGLDLangevinGPU::init()
 {
   FixUCGGPUBase::init();
+  // :151-160, :173-176: the compute of fix_modify temp and whether it removes a velocity bias
+  tbiasflag = 0;
+  if (id_temp) {
+    temperature = modify->get_compute_by_id(id_temp);
+    if (!temperature) error->all(FLERR, "Temperature compute ID {} for fix {} does not exist", id_temp, style);
+    if (temperature->tempflag == 0) error->all(FLERR, "Compute ID {} for fix {} does not compute temperature", id_temp, style);
+    if (temperature->tempbias) tbiasflag = 1;
+  }
+  if (utils::strmatch(update->integrate_style, "^respa")) nlevels_respa = (dynamic_cast<Respa *>(update->integrate))->nlevels;
   if (!created) {
     // RanMars(seed + comm->me), :85
     check(ucg_fix_langevin_create(ctx, t_start, t_stop, t_period, seed, comm->me));
@@ -244,16 +289,66 @@ void FixUCGLDLangevinGPU::init()
   std::vector<double> ml((size_t) atom->ntypes + 1, 0.0);
   for (int i = 1; i <= atom->ntypes; i++) ml[(size_t) i] = (i < atom->nlocal) ? avec->ucgml[i] : (atom->nlocal ? avec->ucgml[0] : 1.0);
   check(ucg_fix_langevin_init_from_ucgml(ctx, atom->ntypes, ml.data()));
+  check(ucg_fix_langevin_set_bias(ctx, tbiasflag));    // post_force_templated<1> when BIAS (:203-210)
 }
 
 void FixUCGLDLangevinGPU::setup(int vflag)
 {
-  post_force(vflag);    // :187-197
+  // :187-197
+  if (utils::strmatch(update->integrate_style, "^verlet")) post_force(vflag);
+  else {
+    auto respa = dynamic_cast<Respa *>(update->integrate);
+    respa->copy_flevel_f(nlevels_respa - 1);
+    post_force_respa(vflag, nlevels_respa - 1, 0);
+    respa->copy_f_flevel(nlevels_respa - 1);
+  }
+}
+
+void FixUCGLDLangevinGPU::post_force_respa(int vflag, int ilevel, int /*iloop*/)
+{
+  if (ilevel == nlevels_respa - 1) post_force(vflag);    // :216-219
+}
+
+void FixUCGLDLangevinGPU::reset_target(double t_new)
+{
+  t_target = t_start = t_stop = t_new;    // :358-361
+  if (ctx && created) check(ucg_fix_langevin_reset_target(ctx, t_new));
+}
+
+void FixUCGLDLangevinGPU::reset_dt()
+{
+  // :366-376 AS SHIPPED: gfactor2 from atom->mass[type] (init() used atom->ucgml[type index]), gfactor1 untouched.  Before
+  // the first init() there is nothing to reset: init() forms both prefactors from update->dt.
+  if (!ctx || !created || !atom->mass) return;
+  check(ucg_ctx_set_units(ctx, force->boltz, force->ftm2v, force->mvv2e, update->dt, force->special_lj));
+  check(ucg_fix_langevin_reset_dt(ctx, atom->ntypes, atom->mass));
+}
+
+int FixUCGLDLangevinGPU::modify_param(int narg, char **arg)
+{
+  // :380-398
+  if (strcmp(arg[0], "temp") == 0) {
+    if (narg < 2) utils::missing_cmd_args(FLERR, "fix_modify", error);
+    delete[] id_temp;
+    id_temp = utils::strdup(arg[1]);
+    temperature = modify->get_compute_by_id(id_temp);
+    if (!temperature) error->all(FLERR, "Could not find fix_modify temperature compute ID: {}", id_temp);
+    if (temperature->tempflag == 0) error->all(FLERR, "Fix_modify temperature compute {} does not compute temperature", id_temp);
+    if (temperature->igroup != igroup && comm->me == 0)
+      error->warning(FLERR, "Group for fix_modify temp != fix group: {} vs {}", group->names[igroup], group->names[temperature->igroup]);
+    return 2;
+  }
+  return 0;
 }
 
 void FixUCGLDLangevinGPU::post_force(int)
 {
   // :226-297 (compute_target :318-353 inside the library: needs the run's begin/end steps)
+  if (tbiasflag) {
+    // post_force_templated<1> evaluates the bias compute first (:268); it reads LAMMPS' velocities
+    if (resident) check(ucg_host_sync(ctx, UCG_F_V));
+    temperature->compute_scalar();
+  }
   to_device(VL | LF | F);
   check(ucg_fix_langevin_post_force(ctx, groupbit, update->ntimestep, update->beginstep, update->endstep));
   t_target = ucg_fix_langevin_t_target(ctx);
@@ -366,15 +461,21 @@ int FixClusterSwitchGPU::setmask()
 void FixClusterSwitchGPU::init()
 {
   FixUCGGPUBase::init();
-  if (comm->nprocs > 1)
-    error->all(FLERR, "USER-UCG/GPU fix cluster_switch: with several ranks the reductions of include/ucg_hip.h (survey, labels, "
-                      "accept flags) have to be wired to MPI_Allreduce here -- not done in this glue yet");
-  // molecule ids in the order of the last ucg_atoms_upload (the pair style's), then the fix itself
-  std::vector<int> mol((size_t) atom->nlocal);
-  for (int i = 0; i < atom->nlocal; i++) mol[(size_t) i] = (int) atom->molecule[i];
-  check(ucg_atoms_upload_molecule(ctx, mol.data()));
+  if (!driver)
+    error->all(FLERR, "USER-UCG/GPU fix cluster_switch works on the device-built lists of the resident step loop: use "
+                      "`run_style verlet/ucg/gpu` (or the reference's CPU fix cluster_switch with the stock run_style)");
+  // the device objects are made by the run style's setup(), once the atoms and their molecule ids are uploaded
+}
+
+void FixClusterSwitchGPU::create_on_device(ucg_ctx *c)
+{
+  // the constructor's survey (UCG/fix_cluster_switch.cpp:62-160) needs the atoms: once, like the reference's constructor;
+  // on several ranks the library reduces it over the attached communicator at the next ucg_md_setup
+  if (created) return;
+  ctx = c;
   check(ucg_fix_cluster_switch_create(ctx, groupbit, mol_seed, mol_offset, cutoff, seed, switchFreq, rateFile.c_str(),
                                       contactFile.c_str()));
+  created = true;
 }
 
 double FixClusterSwitchGPU::compute_vector(int n)

@@ -9,7 +9,10 @@
      fix ID group cluster_switch molSeed molOffset cutoff seed rateFreq N rateFile F contactFile F
                                                              (UCG/fix_cluster_switch.cpp:37-60)
 
-   The device context is the pair style's (Pair::extract("ucg_ctx")).  Two modes, chosen by the pair style in init_style():
+   The device context is the pair style's (Pair::extract("ucg_ctx")).  Under `run_style verlet/ucg/gpu` (verlet_ucg_gpu.h) the
+   whole step loop runs inside the library -- any number of ranks, RCCL or MPI between them -- and the hooks below are not
+   called at all: the fixes only carry their parameters to the device in init().  Under the stock `run_style verlet` there
+   are two modes, chosen by the pair style in init_style():
    * resident (one rank, every fix of the deck is one of these): the device arrays are authoritative between the hooks and
      LAMMPS' arrays are mirrors bound with ucg_host_bind; a hook launches its kernel and moves nothing.  The integrator
      takes Neighbor::decide() over (distance check on the device, re-neighbouring forced through force_reneighbor /
@@ -48,6 +51,7 @@ class FixUCGGPUBase : public Fix {
  protected:
   ucg_ctx *ctx = nullptr;
   int resident = 0;    // the pair style's extract("ucg_resident")
+  int driver = 0;      // the pair style's extract("ucg_driver"): run_style verlet/ucg/gpu owns the step loop
   void check(int rc);
   enum { X = 1, V = 2, F = 4, STATE = 8, NSTATES = 16, L = 32, VL = 64, P = 128, LF = 256, SCORES = 512 };
   void to_device(int fields);
@@ -57,6 +61,7 @@ class FixUCGGPUBase : public Fix {
 class FixNVEUCGLDGPU : public FixUCGGPUBase {
  public:
   FixNVEUCGLDGPU(class LAMMPS *, int, char **);
+  ~FixNVEUCGLDGPU() override;
   int setmask() override;
   void init() override;
   void initial_integrate(int) override;
@@ -65,12 +70,19 @@ class FixNVEUCGLDGPU : public FixUCGGPUBase {
   void end_of_step() override;
   void initial_integrate_respa(int, int, int) override;
   void final_integrate_respa(int, int) override;
+  void post_run() override;
   void reset_dt() override;
+  bool is_wall() const { return wall; }
 
  protected:
   bool wall = false;
   double *step_respa = nullptr;
   void set_step(double dt);
+  // resident mode takes Neighbor::decide() over for the duration of ONE run: the user's neigh_modify values are put back in
+  // post_run() (and by the destructor), so the next `run` -- resident or not -- starts from what the input deck said
+  bool neigh_taken = false;
+  int saved_delay = 0, saved_every = 1;
+  void restore_neigh_modify();
 };
 
 class FixNVEUCGLDWallHardGPU : public FixNVEUCGLDGPU {
@@ -79,6 +91,7 @@ class FixNVEUCGLDWallHardGPU : public FixNVEUCGLDGPU {
   int setmask() override;
   void init() override;
   void post_force(int) override;
+  int has_bias_potential() const { return bias_potential_flag; }
 
  protected:
   int bias_potential_flag = 0;
@@ -92,14 +105,26 @@ class FixUCGLDLangevinGPU : public FixUCGGPUBase {
   void init() override;
   void setup(int) override;
   void post_force(int) override;
+  void post_force_respa(int, int, int) override;
   void end_of_step() override;
+  void reset_target(double) override;
+  void reset_dt() override;
+  int modify_param(int, char **) override;
   double compute_scalar() override;
   void *extract(const char *, int &) override;
+  ~FixUCGLDLangevinGPU() override;
+  // run_style verlet/ucg/gpu reports the values of the last output step here (the hooks above are not called under it)
+  void set_from_driver(double t_target_now, double lambda_temp_now) { t_target = t_target_now; lambda_temp = lambda_temp_now; }
 
  protected:
   double t_start, t_stop, t_period, t_target, lambda_temp = 0.0;
   int seed;
   bool created = false;
+  // fix_modify temp (UCG/fix_ucgld_langevin.cpp:380-398) and the bias flag init() derives from it (:162-165)
+  char *id_temp = nullptr;
+  class Compute *temperature = nullptr;
+  int tbiasflag = 0;
+  int nlevels_respa = 1;
 };
 
 class FixUCGStateGPU : public FixUCGGPUBase {
@@ -116,18 +141,22 @@ class FixUCGStateGPU : public FixUCGGPUBase {
   bool created = false;
 };
 
-// fix cluster_switch needs the RESIDENT lists (the device-built full list and ghosts): it is offered for the
-// resident loop only, where ucg_md_run calls its pre_exchange work at the forced re-neighbour steps.  In a
-// drop-in run the reference's own CPU fix cluster_switch keeps working unchanged on LAMMPS' arrays (it only
-// changes atom->type, which the pair style uploads at the next re-neighbour step).
+// fix cluster_switch needs the RESIDENT lists (the device-built full list and ghosts): it runs inside the library's step
+// loop, i.e. under `run_style verlet/ucg/gpu`, where ucg_md_run does its pre_exchange work at the forced re-neighbour steps
+// and -- on several ranks -- the MPI_Allreduce steps of UCG/fix_cluster_switch.cpp:114-120, 157-158, 664, 750 through the
+// attached communicator.  Under the stock run_style the reference's own CPU fix cluster_switch keeps working unchanged on
+// LAMMPS' arrays (it only changes atom->type, which the pair style uploads at the next re-neighbour step).
 class FixClusterSwitchGPU : public FixUCGGPUBase {
  public:
   FixClusterSwitchGPU(class LAMMPS *, int, char **);
   int setmask() override;
   void init() override;
   double compute_vector(int) override;
+  // called by run_style verlet/ucg/gpu once the atoms and their molecule ids are on the device
+  void create_on_device(ucg_ctx *);
 
  protected:
+  bool created = false;
   int mol_seed, mol_offset, seed, switchFreq;
   double cutoff;
   std::string rateFile, contactFile;

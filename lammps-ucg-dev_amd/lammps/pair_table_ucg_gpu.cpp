@@ -26,18 +26,31 @@
 #include "neigh_list.h"
 #include "neighbor.h"
 #include "update.h"
+#include "utils.h"
 
 #include "ucg_hip.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
 using namespace LAMMPS_NS;
 
+// One process per GPU: the rank's device is its node-local rank modulo the visible devices (the launchers' usual variables;
+// none set = the current device, i.e. whatever ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES leave as device 0)
+static int pick_device()
+{
+  const int ndev = ucg_device_count();
+  if (ndev <= 1) return -1;
+  for (const char *var : {"OMPI_COMM_WORLD_LOCAL_RANK", "MV2_COMM_WORLD_LOCAL_RANK", "MPI_LOCALRANKID", "SLURM_LOCALID", "LOCAL_RANK"})
+    if (const char *v = getenv(var)) return atoi(v) % ndev;
+  return -1;
+}
+
 PairTableUCGGPU::PairTableUCGGPU(LAMMPS *lmp, int style) : Pair(lmp), ucg_style(style)
 {
   no_virial_fdotr_compute = 1;    // the pair virial is returned by the kernel (reference: silently 0)
-  if (ucg_ctx_create(-1, &ctx) != UCG_OK)
+  if (ucg_ctx_create(pick_device(), &ctx) != UCG_OK)
     error->all(FLERR, "USER-UCG/GPU: no usable HIP device (there is no CPU fallback in this package)");
   check(ucg_pair_create(ctx, style, &gpair), true);
 }
@@ -109,10 +122,15 @@ void PairTableUCGGPU::init_style()
   check(ucg_pair_init(gpair, atom->ntypes, T), true);
   // resident mode: one rank, orthogonal box, and no fix that is not of this package (any other fix may read or write
   // LAMMPS' arrays at a hook this package does not see)
-  user_every = neighbor->every;
-  user_delay = neighbor->delay;
-  user_check = neighbor->dist_check;
-  resident = (comm->nprocs == 1 && !domain->triclinic) ? 1 : 0;
+  // neigh_modify as the input deck gave it.  The integrator of this package replaces the delay for the duration of a
+  // resident run and restores it in post_run(); should a run have ended without post_run(), the sentinel is not a setting
+  if (neighbor->delay != UCG_GPU_DELAY_SENTINEL) {
+    user_every = neighbor->every;
+    user_delay = neighbor->delay;
+    user_check = neighbor->dist_check;
+  }
+  driver = utils::strmatch(update->integrate_style, "^verlet/ucg/gpu") ? 1 : 0;
+  resident = (!driver && comm->nprocs == 1 && !domain->triclinic) ? 1 : 0;
   for (int ifix = 0; ifix < modify->nfix && resident; ifix++) {
     const char *st = modify->fix[ifix]->style;
     if (strcmp(st, "nve/ucgld") && strcmp(st, "nve/ucgld/wall/hard") && strcmp(st, "ucgld/langevin") && strcmp(st, "ucgstate")) resident = 0;
@@ -226,6 +244,8 @@ void PairTableUCGGPU::unpack_forward_comm(int n, int first, double *buf)
 
 void PairTableUCGGPU::compute(int eflag, int vflag)
 {
+  if (driver) error->all(FLERR, "USER-UCG/GPU: Pair::compute() called under run_style verlet/ucg/gpu, which runs the step loop "
+                                "inside the library (a command that needs forces outside a run?)");
   ev_init(eflag, vflag);
   auto avec = AtomVecUCG::get(lmp);
   const int nlocal = atom->nlocal;
@@ -343,5 +363,6 @@ void *PairTableUCGGPU::extract(const char *str, int &dim)
   dim = 0;
   if (strcmp(str, "ucg_ctx") == 0) return (void *) ctx;
   if (strcmp(str, "ucg_resident") == 0) return (void *) &resident;
+  if (strcmp(str, "ucg_driver") == 0) return (void *) &driver;
   return nullptr;
 }

@@ -55,6 +55,7 @@ class PairTableUCGGPU : public Pair {
   // between the hooks, LAMMPS' arrays are bound as lazily synchronised mirrors (ucg_host_bind), ghosts are refreshed and
   // the re-neighbour decision is taken on the device.  The USER-UCG/GPU fixes ask for it through extract("ucg_resident").
   int resident = 0;
+  int driver = 0;    // run_style verlet/ucg/gpu runs the whole step loop inside the library: compute() is not called
   int user_every = 1, user_delay = 0, user_check = 1;    // neigh_modify as the input gave it (the integrator takes decide() over)
   void bind_mirrors();
   std::vector<double> aux;    // [nall][2]: priors, then CV forces, of owned + ghost atoms (density style under MPI)
@@ -62,6 +63,12 @@ class PairTableUCGGPU : public Pair {
   int tabstyle = 0, tablength = 0;    // as given to pair_style: what the reference keeps in restart files
   void check(int rc, bool all);
   void upload_list();
+
+ public:
+  // for run_style verlet/ucg/gpu (verlet_ucg_gpu.cpp)
+  ucg_ctx *device_context() const { return ctx; }
+  ucg_pair *device_pair() const { return gpair; }
+  int style_index() const { return ucg_style; }
 };
 
 class PairTableUCGLDGPU : public PairTableUCGGPU {

@@ -8,10 +8,11 @@ OUT=${UCG_ASAN_DIR:-/tmp/ucg_asan}
 mkdir -p "$OUT"
 cd "$ROOT/lammps-ucg-dev_amd/csrc"
 F="-O1 -g -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -fsanitize=address,undefined -fno-gpu-sanitize -fno-omit-frame-pointer -Wno-unused-result"
-for f in ucg_model.cpp ucg_io.cpp ucg_pair.hip ucg_density.hip ucg_fix.hip ucg_ranmars.hip ucg_neigh.hip ucg_cluster.hip ucg_capi.hip ucg_comm.hip ucg_host.hip; do
+for f in ucg_model.cpp ucg_io.cpp ucg_pair.hip ucg_pair_hot.hip ucg_pair_vrow.hip ucg_density.hip ucg_fix.hip ucg_ranmars.hip ucg_neigh.hip ucg_cluster.hip ucg_capi.hip ucg_comm.hip ucg_host.hip; do
   /opt/rocm/bin/hipcc $F -c "$f" -o "$OUT/${f%.*}.o" &
 done
 /opt/rocm/bin/hipcc $F -ffp-contract=fast -DUCG_FUSED -c ucg_pair.hip -o "$OUT/ucg_pair_fused.o" &
+/opt/rocm/bin/hipcc $F -ffp-contract=fast -DUCG_FUSED -c ucg_pair_hot.hip -o "$OUT/ucg_pair_hot_fused.o" &
 wait
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -fsanitize=address,undefined -fno-gpu-sanitize -shared-libsan \
   -o "$OUT/libucg_hip_asan.so" "$OUT"/*.o -ldl
