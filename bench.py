@@ -536,6 +536,8 @@ def main():
             "ghosts": int(result["nghost"]),
             "parallelism": par,
         },
+        # N > 1 (and UCG_FORCE_MULTI=1): what moved the halo, asked of RCCL itself -- a host-staged rehearsal says false / 0
+        **({"rccl": bool(result["rccl"]), "rccl_nranks": int(result["rccl_nranks"])} if "rccl" in result else {}),
         "roofline": {
             "bound": "hbm",
             "kernel": ("k_density_pass1+2+3" if args.style == "table_ucg_bethe_density"

@@ -687,6 +687,12 @@ class Context:
         self.chk(self.L.ucg_comm_info(self.h, C.byref(r), C.byref(w), C.byref(k), C.byref(n)))
         return dict(rank=r.value, world=w.value, rccl=bool(k.value), nrebuild=n.value)
 
+    def comm_transport(self):
+        """what the attached communicator really is (asked of RCCL itself: ncclCommCount / ncclCommCuDevice)"""
+        out = np.zeros(4, np.int32)
+        self.chk(self.L.ucg_comm_transport(self.h, _ip(out)))
+        return dict(rccl=bool(out[0]), rccl_nranks=int(out[1]), rccl_device=int(out[2]), host_staged=bool(out[3]))
+
     def comm_allreduce_sum(self, values):
         a = _f64(values).copy()
         self.chk(self.L.ucg_comm_allreduce_f64(self.h, _dp(a), len(a), 0))

@@ -208,6 +208,33 @@ void alltoallv(ucg_ctx *ctx, const void *send, const long long *sendbytes, void 
   nccl_check(g_rccl.GroupEnd(), "ncclGroupEnd");
 }
 
+// the RCCL all-to-all with the block of rank `gap_rank` (this rank's own) left out of the transfer but kept as a hole of
+// `gap_bytes` in both buffers, so that every other block stays where the ghost permutation expects it
+void alltoallv_gap(ucg_ctx *ctx, const void *send, const long long *sendbytes, void *recv, const long long *recvbytes, int gap_rank,
+                   long long gap_bytes)
+{
+  CommState &C = *ctx->comm;
+  long long so = 0, ro = 0;
+  bool peers = false;
+  for (int r = 0; r < C.world; r++) peers = peers || (r != gap_rank && (sendbytes[r] > 0 || recvbytes[r] > 0));
+  if (!peers) return;
+  nccl_check(g_rccl.GroupStart(), "ncclGroupStart");
+  for (int r = 0; r < C.world; r++) {
+    if (r == gap_rank) {
+      so += gap_bytes;
+      ro += gap_bytes;
+      continue;
+    }
+    if (sendbytes[r] > 0)
+      nccl_check(g_rccl.Send((const char *) send + so, (size_t) sendbytes[r], NCCL_CHAR, r, C.nccl, ctx->stream), "ncclSend");
+    if (recvbytes[r] > 0)
+      nccl_check(g_rccl.Recv((char *) recv + ro, (size_t) recvbytes[r], NCCL_CHAR, r, C.nccl, ctx->stream), "ncclRecv");
+    so += sendbytes[r];
+    ro += recvbytes[r];
+  }
+  nccl_check(g_rccl.GroupEnd(), "ncclGroupEnd");
+}
+
 // one long long per peer, host arrays, blocking
 void alltoall_counts(ucg_ctx *ctx, const long long *send, long long *recv)
 {
@@ -329,7 +356,10 @@ struct LocalStatus {
 
 // CommBrick::exchange + borders: every bead to the rank that owns its wrapped position, then the images every
 // rank's extended brick needs; afterwards bins and rows are rebuilt (ucg_border_unpack).  Ends with a status agreement.
-int multi_rebuild(ucg_ctx *ctx, const LocalStatus *held = nullptr)
+// `agree` = false (the step loop): no all-reduce of its own at the end -- a local failure is handed back in *deferred and
+// the ranks agree on it at the next re-neighbour decision, whose all-reduce carries every rank's status anyway (at most
+// `every` steps later; until then the failing rank keeps taking part in the halos with stale data and runs nothing local)
+int multi_rebuild(ucg_ctx *ctx, const LocalStatus *held = nullptr, bool agree = true, LocalStatus *deferred = nullptr)
 {
   CommState &C = *ctx->comm;
   const size_t w = (size_t) C.world;
@@ -381,6 +411,10 @@ int multi_rebuild(ucg_ctx *ctx, const LocalStatus *held = nullptr)
     st.run(ctx, [&] { return ucg_halo_molmask_unpack(ctx, C.auxrecv.get()); });
   }
   C.nrebuild++;
+  if (!agree) {
+    if (deferred && st.bad != UCG_OK) deferred->fail(st.bad, st.msg);
+    return UCG_OK;
+  }
   return st.agree(ctx, "during the re-neighbouring");
 }
 
@@ -401,9 +435,26 @@ int multi_halo_forward(ucg_ctx *ctx, LocalStatus *ls = nullptr)
   // a rank with a pending local failure (ls->bad) still moves its (stale) buffers: the peers' receives complete
   LocalStatus own;
   LocalStatus &st = ls ? *ls : own;
-  st.run(ctx, [&] { return ucg_halo_pack(ctx, C.send.get()); });
-  alltoallv(ctx, C.send.get(), sb.data(), C.recv.get(), rb.data());
-  st.run(ctx, [&] { return ucg_halo_unpack(ctx, C.recv.get()); });
+  if (C.rccl && C.self_copy && C.halo_send[(size_t) C.rank] > 0 && C.halo_send[(size_t) C.rank] == C.halo_recv[(size_t) C.rank]) {
+    // the rank's own periodic images (a grid dimension of one rank): made straight from their owner beads by the unpack
+    // kernel; only the peers' records are packed and moved -- with one rank the whole halo is one launch
+    long long so_self = 0, ro_self = 0;
+    for (int r = 0; r < C.rank; r++) {
+      so_self += C.halo_send[(size_t) r];
+      ro_self += C.halo_recv[(size_t) r];
+    }
+    const long long nself = C.halo_send[(size_t) C.rank];
+    st.run(ctx, [&] { return halo_pack_peers(ctx, C.send.get(), so_self, nself); });
+    sb[(size_t) C.rank] = rb[(size_t) C.rank] = 0;
+    // (the offsets of the peers' blocks inside the buffers must stay what the permutation expects: the self block's
+    // bytes are skipped, not closed up)
+    alltoallv_gap(ctx, C.send.get(), sb.data(), C.recv.get(), rb.data(), C.rank, nself * hrec);
+    st.run(ctx, [&] { return halo_unpack_self(ctx, C.recv.get(), ro_self, so_self, nself); });
+  } else {
+    st.run(ctx, [&] { return ucg_halo_pack(ctx, C.send.get()); });
+    alltoallv(ctx, C.send.get(), sb.data(), C.recv.get(), rb.data());
+    st.run(ctx, [&] { return ucg_halo_unpack(ctx, C.recv.get()); });
+  }
   if (!ls && own.bad != UCG_OK) {
     ctx->err = own.msg;
     return own.bad;
@@ -597,22 +648,25 @@ int md_run_multi(ucg_ctx *ctx, long long nsteps, int thermo_every, int ev_on_las
       const int ev = ((thermo_every > 0 && (ctx->ntimestep % thermo_every == 0)) || (ev_on_last && s + 1 == nsteps)) ? 1 : 0;
       if (ctx->md_nve && !initial_done)
         ls.run(ctx, [&] { return ctx->md_nve == 2 ? ucg_fix_nve_wall_hard_initial(ctx, ctx->groupbit) : ucg_fix_nve_initial(ctx, ctx->groupbit); });
-      int due = 0, flag = 0;
-      UCG_RC(ucg_decide_local(ctx, &due, &flag));  // (the schedule must stay in step on every rank: a failure here is fatal)
+      int due = 0, flag = 0, pair_flag = -1;
+      UCG_RC(decide_local_impl(ctx, &due, &flag, &pair_flag));  // (the schedule must stay in step on every rank: a failure here is fatal)
       const bool fuse_next = ctx->md_nve && !ev && (s + 1 < nsteps) && !ctx->md_no_fuse;
       bool rebuilt = false;
-      if (due) {  // Neighbor::decide(): MPI_Allreduce of the flag -- and of the ranks' status since the last agreement
-        long long f[2] = {flag, ls.bad};
-        allreduce_ll(ctx, f, 2, 1);
+      if (due) {
+        // Neighbor::decide(): MPI_Allreduce of the flag -- and, in the same message, of the ranks' status since the last
+        // agreement and of the pair kernels' sticky table-range flag (read by the decision's own download: -1 = the
+        // distance check did not run, so the poll below has to)
+        long long f[3] = {flag, ls.bad, pair_flag != 0};
+        allreduce_ll(ctx, f, 3, 1);
         if (f[1] != UCG_OK) {
           ctx->err = ls.bad != UCG_OK ? ls.msg : std::string("another rank failed in the step loop (every rank stops; the job must be aborted)");
           return (int) f[1];
         }
+        if (f[2] != 0) UCG_RC(poll_pair_errors(ctx, &ls));  // some rank's flag is up (or unknown): every rank takes part in the poll
         rebuilt = f[0] != 0;
       }
       if (rebuilt) {
-        UCG_RC(poll_pair_errors(ctx, &ls));  // the stream is drained here anyway: check the steps since the last rebuild
-        UCG_RC(multi_rebuild(ctx));
+        UCG_RC(multi_rebuild(ctx, nullptr, false, &ls));
         if (ctx->cs) {
           int forced = 0, switching = 0;
           UCG_RC(ucg_fix_cluster_switch_due(ctx, &forced, &switching));  // (a function of the timestep alone: in step on every rank)

@@ -258,6 +258,9 @@ void cluster_destroy(ucg_ctx *ctx);
 void comm_destroy(ucg_ctx *ctx);
 int md_setup_multi(ucg_ctx *ctx);
 int md_run_multi(ucg_ctx *ctx, long long nsteps, int thermo_every, int ev_on_last);
+int halo_pack_peers(ucg_ctx *ctx, void *sendbuf, long long so_self, long long nself);
+int halo_unpack_self(ucg_ctx *ctx, const void *recvbuf, long long ro_self, long long so_self, long long nself);
+int decide_local_impl(ucg_ctx *ctx, int *due, int *flag, int *pair_flag);
 bool cluster_forces_rebuild(const ucg_ctx *ctx);
 void cluster_pre_exchange(ucg_ctx *ctx);
 }

@@ -51,6 +51,19 @@ struct Domain {
   DevBuf<int> scratch;                 // discovery-order rows before the class partition
   DevBuf<unsigned long long> rowstat;  // [0] max row length, [1] total entries
   int row_capacity = 0, skin_capacity = 0;
+  // second scratch set of the one-launch permutation of all per-bead arrays (k_permute_all)
+  DevBuf<double4> tmp4b;
+  DevBuf<int> tmpi2, tmpi3, tmpi4, tmpi5;
+  DevBuf<double> tmpd2;
+  // pinned staging of the per-destination offsets (two alternating slots: a rebuild uploads them twice, with stream
+  // synchronisations of its own in between, so a slot is never rewritten before its copy has run)
+  int *h_off[2] = {nullptr, nullptr};
+  int h_off_cap = 0, h_off_next = 0;
+  ~Domain()
+  {
+    for (int *p : h_off)
+      if (p) (void) hipHostFree(p);
+  }
 };
 
 struct DomainDev {
@@ -155,6 +168,34 @@ __global__ __launch_bounds__(NB) void k_gather(int n, const int *perm, const T *
 {
   const int i = blockIdx.x * NB + threadIdx.x;
   if (i < n) dst[i] = src[perm[i]];
+}
+
+// every per-bead array of the owned beads through the sort permutation, and the beads' bins, in ONE launch (nine
+// k_gather launches and k_bins_from_pos before: at 125 k beads per rank each was 2-3 us of work behind a 4-5 us dispatch)
+struct PermuteArgs {
+  const double4 *pos_s, *vel_s;
+  double4 *pos_d, *vel_d;
+  const int *meta_s, *tag_s, *mask_s, *nst_s, *mol_s;
+  int *meta_d, *tag_d, *mask_d, *nst_d, *mol_d;
+  const double *ml_s, *up_s;
+  double *ml_d, *up_d;
+};
+__global__ __launch_bounds__(NB) void k_permute_all(const DomainDev D, int n, const int *perm, const PermuteArgs a, int *bin_of)
+{
+  const int i = blockIdx.x * NB + threadIdx.x;
+  if (i >= n) return;
+  const int j = perm[i];
+  const double4 p = a.pos_s[j];
+  a.pos_d[i] = p;
+  a.vel_d[i] = a.vel_s[j];
+  a.meta_d[i] = a.meta_s[j];
+  a.tag_d[i] = a.tag_s[j];
+  a.mask_d[i] = a.mask_s[j];
+  a.nst_d[i] = a.nst_s[j];
+  a.ml_d[i] = a.ml_s[j];
+  a.up_d[i] = a.up_s[j];
+  if (a.mol_s) a.mol_d[i] = a.mol_s[j];
+  bin_of[i] = coord2bin(D, p.x, p.y, p.z);
 }
 
 __global__ __launch_bounds__(NB) void k_bins_from_pos(const DomainDev D, int n, int offset, const double4 *pos4, int *bin_of)
@@ -706,7 +747,9 @@ __global__ __launch_bounds__(NB) void k_check_distance(const DomainDev D, int n,
   if (threadIdx.x == 0) blockflags[blockIdx.x] = s_any;
 }
 
-__global__ __launch_bounds__(1024) void k_flags_any(int nflags, const int *blockflags, int *flag)
+// flag[0] = any workgroup flag set; flag[1] = the pair kernels' sticky table-range flag (read here so that the one small
+// download of the re-neighbour decision also tells whether an error poll is due)
+__global__ __launch_bounds__(1024) void k_flags_any(int nflags, const int *blockflags, int *flag, const int *pair_err)
 {
   __shared__ int s_any;
   if (threadIdx.x == 0) s_any = 0;
@@ -715,7 +758,10 @@ __global__ __launch_bounds__(1024) void k_flags_any(int nflags, const int *block
   for (int b = threadIdx.x; b < nflags; b += 1024) any |= blockflags[b];
   if (__any(any != 0) && (threadIdx.x & 63) == 0) s_any = 1;
   __syncthreads();
-  if (threadIdx.x == 0) *flag = s_any;
+  if (threadIdx.x == 0) {
+    flag[0] = s_any;
+    flag[1] = pair_err ? *pair_err : 0;
+  }
 }
 
 void setup_bins(Domain &D)
@@ -782,18 +828,45 @@ void sort_owned(ucg_ctx *ctx, bool wrap)
                      D.keys_in.get(), D.vals_in.get());
   sort_pairs(ctx, D, n);
   const int *perm = D.vals_out.get();
-  permute(ctx, n, perm, ctx->pos4, D.tmp4);
-  permute(ctx, n, perm, ctx->vel4, D.tmp4);
-  permute(ctx, n, perm, ctx->meta, D.tmpi);
-  permute(ctx, n, perm, ctx->tag, D.tmpi);
-  permute(ctx, n, perm, ctx->mask, D.tmpi);
-  permute(ctx, n, perm, ctx->num_ucgstates, D.tmpi);
-  permute(ctx, n, perm, ctx->ucgml, D.tmpd);
-  permute(ctx, n, perm, ctx->ucgp, D.tmpd);
-  if (ctx->has_mol) permute(ctx, n, perm, ctx->mol, D.tmpi);
+  // every per-bead array through the permutation in one launch: gather into scratch buffers, which then trade places with
+  // the arrays (no copy back).  A scratch buffer is made at least as large as the array it replaces, so the arrays of one
+  // family converge to one capacity and nothing is reallocated afterwards; entries beyond n (ghosts) are rebuilt by the caller.
+  auto scratch = [&](auto &arr, auto &tmp) {
+    if (tmp.capacity() < arr.capacity()) tmp.reserve_exact(arr.capacity());  // exact: the family's capacity must not creep
+    tmp.reserve((size_t) n);
+  };
+  scratch(ctx->pos4, D.tmp4);
+  scratch(ctx->vel4, D.tmp4b);
+  scratch(ctx->meta, D.tmpi);
+  scratch(ctx->tag, D.tmpi2);
+  scratch(ctx->mask, D.tmpi3);
+  scratch(ctx->num_ucgstates, D.tmpi4);
+  scratch(ctx->ucgml, D.tmpd);
+  scratch(ctx->ucgp, D.tmpd2);
+  if (ctx->has_mol) scratch(ctx->mol, D.tmpi5);
   D.bin_of.reserve((size_t) n);
-  hipLaunchKernelGGL(k_bins_from_pos, dim3(nblk(n)), dim3(NB), 0, st, dd, n, 0, ctx->pos4.get(), D.bin_of.get());
-
+  PermuteArgs pa;
+  pa.pos_s = ctx->pos4.get(); pa.pos_d = D.tmp4.get();
+  pa.vel_s = ctx->vel4.get(); pa.vel_d = D.tmp4b.get();
+  pa.meta_s = ctx->meta.get(); pa.meta_d = D.tmpi.get();
+  pa.tag_s = ctx->tag.get(); pa.tag_d = D.tmpi2.get();
+  pa.mask_s = ctx->mask.get(); pa.mask_d = D.tmpi3.get();
+  pa.nst_s = ctx->num_ucgstates.get(); pa.nst_d = D.tmpi4.get();
+  pa.ml_s = ctx->ucgml.get(); pa.ml_d = D.tmpd.get();
+  pa.up_s = ctx->ucgp.get(); pa.up_d = D.tmpd2.get();
+  pa.mol_s = ctx->has_mol ? ctx->mol.get() : nullptr;
+  pa.mol_d = ctx->has_mol ? D.tmpi5.get() : nullptr;
+  hipLaunchKernelGGL(k_permute_all, dim3(nblk(n)), dim3(NB), 0, st, dd, n, perm, pa, D.bin_of.get());
+  UCG_HIP(hipGetLastError());
+  ctx->pos4.swap(D.tmp4);
+  ctx->vel4.swap(D.tmp4b);
+  ctx->meta.swap(D.tmpi);
+  ctx->tag.swap(D.tmpi2);
+  ctx->mask.swap(D.tmpi3);
+  ctx->num_ucgstates.swap(D.tmpi4);
+  ctx->ucgml.swap(D.tmpd);
+  ctx->ucgp.swap(D.tmpd2);
+  if (ctx->has_mol) ctx->mol.swap(D.tmpi5);
 }
 
 void build_bins_and_rows(ucg_ctx *ctx);
@@ -992,7 +1065,7 @@ bool decide(ucg_ctx *ctx)
     hipLaunchKernelGGL(k_check_distance, dim3(nblk(ctx->nlocal)), dim3(NB), 0, ctx->stream, dd, ctx->nlocal,
                        ctx->pos4.get(), D.xhold.get(), D.blockflags.get());
     hipLaunchKernelGGL(k_flags_any, dim3(1), dim3(1024), 0, ctx->stream, nblk(ctx->nlocal), D.blockflags.get(),
-                       D.counter.get());
+                       D.counter.get(), (const int *) nullptr);
     int flag = 0;
     UCG_HIP(hipMemcpyAsync(&flag, D.counter.get(), sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     UCG_HIP(hipStreamSynchronize(ctx->stream));
@@ -1211,6 +1284,56 @@ __global__ __launch_bounds__(NB) void k_halo_unpack(int ng, int nlocal, const in
   if (with_tag) tag[nlocal + g] = r.tag;
 }
 
+// The forward halo of a rank whose own periodic images are among its ghosts (every grid with a dimension of one rank):
+// the self block never travels, so it needs neither the send nor the receive buffer.  k_halo_pack_peers packs only the
+// records bound for other ranks (send-list positions outside [so_self, so_self + nself)); k_halo_unpack_self makes a ghost
+// of the self block straight from its owner bead -- the statements of k_halo_pack followed by those of k_halo_unpack, so
+// the same bits -- and takes every other ghost from the receive buffer.  pack + device copy + unpack become one launch
+// when the whole halo is the rank's own (one rank), and stay pack / transfer / unpack for the peers' blocks.
+__global__ __launch_bounds__(NB) void k_halo_pack_peers(const DomainDev D, int nsend, int so_self, int nself, const int *send_src,
+                                                       const int *send_code, const double4 *pos4, const double *ucgp,
+                                                       const int *meta, const int *tag, HaloRec *out)
+{
+  int j = blockIdx.x * NB + threadIdx.x;
+  if (j >= nsend - nself) return;
+  if (j >= so_self) j += nself;
+  const int src = send_src[j], code = send_code[j];
+  const int sx = code % 3 - 1, sy = (code / 3) % 3 - 1, sz = code / 9 - 1;
+  const double4 p = pos4[src];
+  HaloRec r;
+  r.x = p.x + sx * D.prd[0];
+  r.y = p.y + sy * D.prd[1];
+  r.z = p.z + sz * D.prd[2];
+  r.w = p.w;
+  r.ucgp = ucgp[src];
+  r.meta = meta[src] & 0xFFFFFF;
+  r.tag = tag[src];
+  out[j] = r;
+}
+
+__global__ __launch_bounds__(NB) void k_halo_unpack_self(const DomainDev D, int ng, int nlocal, const int *perm, int ro_self,
+                                                        int so_self, int nself, const int *send_src, const int *send_code,
+                                                        const HaloRec *in, double4 *pos4, int *meta, double *ucgp)
+{
+  const int g = blockIdx.x * NB + threadIdx.x;
+  if (g >= ng) return;
+  const int j = perm[g];
+  const unsigned js = (unsigned) (j - ro_self);
+  if (js < (unsigned) nself) {
+    const int src = send_src[so_self + (int) js], code = send_code[so_self + (int) js];
+    const int sx = code % 3 - 1, sy = (code / 3) % 3 - 1, sz = code / 9 - 1;
+    const double4 p = pos4[src];
+    pos4[nlocal + g] = make_double4(p.x + sx * D.prd[0], p.y + sy * D.prd[1], p.z + sz * D.prd[2], p.w);
+    meta[nlocal + g] = meta[src] & 0xFFFFFF;
+    ucgp[nlocal + g] = ucgp[src];
+  } else {
+    const HaloRec r = in[j];
+    pos4[nlocal + g] = make_double4(r.x, r.y, r.z, r.w);
+    meta[nlocal + g] = r.meta & 0xFFFFFF;
+    ucgp[nlocal + g] = r.ucgp;
+  }
+}
+
 // auxiliary forward halo of one double2 per bead (the density style's priors / CV forces)
 __global__ __launch_bounds__(NB) void k_halo_aux_pack(int nsend, const int *send_src, const double2 *src, double2 *out)
 {
@@ -1251,11 +1374,20 @@ void counts_to_host(ucg_ctx *ctx, Domain &D, long long *out)
 
 void offsets_to_device(ucg_ctx *ctx, Domain &D, const std::vector<long long> &counts, DevBuf<int> &dst)
 {
-  std::vector<int> off((size_t) D.world + 1, 0);
-  for (int r = 0; r < D.world; r++) off[(size_t) r + 1] = off[(size_t) r] + (int) counts[(size_t) r];
+  if (D.h_off_cap < D.world + 1) {
+    for (int k = 0; k < 2; k++) {
+      if (D.h_off[k]) (void) hipHostFree(D.h_off[k]);
+      D.h_off[k] = nullptr;
+      UCG_HIP(hipHostMalloc((void **) &D.h_off[k], (size_t) (D.world + 1) * sizeof(int), hipHostMallocDefault));
+    }
+    D.h_off_cap = D.world + 1;
+  }
+  int *off = D.h_off[D.h_off_next];
+  D.h_off_next ^= 1;
+  off[0] = 0;
+  for (int r = 0; r < D.world; r++) off[r + 1] = off[r] + (int) counts[(size_t) r];
   dst.reserve((size_t) D.world + 1);
-  UCG_HIP(hipMemcpyAsync(dst.get(), off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-  UCG_HIP(hipStreamSynchronize(ctx->stream));
+  UCG_HIP(hipMemcpyAsync(dst.get(), off, (size_t) (D.world + 1) * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
 }
 
 template <typename F>
@@ -1302,6 +1434,42 @@ int forces_and_post_force(ucg_ctx *ctx, int ev)
 }
 
 }  // namespace
+
+// per-step forward halo with the rank's self block kept off the buffers (csrc/ucg_comm.hip: multi_halo_forward)
+int halo_pack_peers(ucg_ctx *ctx, void *sendbuf, long long so_self, long long nself)
+{
+  if (int rc = need_domain(ctx)) return rc;
+  return guarded(ctx, [&]() -> int {
+    Domain &D = *ctx->dom;
+    const long long npeer = D.nsend - nself;
+    if (npeer <= 0) return UCG_OK;
+    if (!sendbuf) return UCG_ERR_INVALID;
+    const DomainDev dd = make_dev(D);
+    hipLaunchKernelGGL(k_halo_pack_peers, dim3(nblk(npeer)), dim3(NB), 0, ctx->stream, dd, (int) D.nsend, (int) so_self, (int) nself,
+                       D.send_src.get(), D.send_code.get(), ctx->pos4.get(), ctx->ucgp.get(), ctx->meta.get(), ctx->tag.get(),
+                       (HaloRec *) sendbuf);
+    UCG_HIP(hipGetLastError());
+    return UCG_OK;
+  });
+}
+
+int halo_unpack_self(ucg_ctx *ctx, const void *recvbuf, long long ro_self, long long so_self, long long nself)
+{
+  if (int rc = need_domain(ctx)) return rc;
+  return guarded(ctx, [&]() -> int {
+    Domain &D = *ctx->dom;
+    const int ng = ctx->nghost;
+    if (ng == 0) return UCG_OK;
+    if (!recvbuf && nself < ng) return UCG_ERR_INVALID;
+    const DomainDev dd = make_dev(D);
+    hipLaunchKernelGGL(k_halo_unpack_self, dim3(nblk(ng)), dim3(NB), 0, ctx->stream, dd, ng, ctx->nlocal, D.ghost_perm.get(),
+                       (int) ro_self, (int) so_self, (int) nself, D.send_src.get(), D.send_code.get(), (const HaloRec *) recvbuf,
+                       ctx->pos4.get(), ctx->meta.get(), ctx->ucgp.get());
+    UCG_HIP(hipGetLastError());
+    return UCG_OK;
+  });
+}
+
 }  // namespace ucg
 
 using namespace ucg;
@@ -1898,9 +2066,14 @@ int ucg_md_set_timestep(ucg_ctx *ctx, long long ntimestep)
   return UCG_OK;
 }
 
-int ucg_decide_local(ucg_ctx *ctx, int *due, int *flag)
+}  // extern "C"
+
+namespace ucg {
+// ucg_decide_local, and -- when the distance check ran -- the pair kernels' sticky error flag in *pair_flag (-1: not read)
+int decide_local_impl(ucg_ctx *ctx, int *due, int *flag, int *pair_flag)
 {
   if (!ctx || !due || !flag) return UCG_ERR_INVALID;
+  if (pair_flag) *pair_flag = -1;
   if (int rc = need_domain(ctx)) return rc;
   return guarded(ctx, [&]() -> int {
     // Neighbor::decide(): the caller combines `flag` over ranks (MPI_Allreduce in upstream)
@@ -1925,16 +2098,24 @@ int ucg_decide_local(ucg_ctx *ctx, int *due, int *flag)
       if (ctx->nlocal > 0)
         hipLaunchKernelGGL(k_check_distance, dim3(nblk(ctx->nlocal)), dim3(NB), 0, ctx->stream, dd, ctx->nlocal,
                            ctx->pos4.get(), D.xhold.get(), D.blockflags.get());
+      const int *perr = (pair_flag && ctx->md_pair && ctx->md_pair->uploaded) ? ctx->md_pair->d_err.get() : nullptr;
+      D.counter.reserve(4);
       hipLaunchKernelGGL(k_flags_any, dim3(1), dim3(1024), 0, ctx->stream, nblk(ctx->nlocal), D.blockflags.get(),
-                         D.counter.get());
-      int f = 0;
-      UCG_HIP(hipMemcpyAsync(&f, D.counter.get(), sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+                         D.counter.get(), perr);
+      int f[2] = {0, 0};
+      UCG_HIP(hipMemcpyAsync(f, D.counter.get(), 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
       UCG_HIP(hipStreamSynchronize(ctx->stream));
-      *flag = f != 0;
+      *flag = f[0] != 0;
+      if (perr) *pair_flag = f[1];
     }
     return UCG_OK;
   });
 }
+}  // namespace ucg
+
+extern "C" {
+
+int ucg_decide_local(ucg_ctx *ctx, int *due, int *flag) { return decide_local_impl(ctx, due, flag, nullptr); }
 
 int ucg_record_bytes(int *atom_rec, int *halo_rec)
 {

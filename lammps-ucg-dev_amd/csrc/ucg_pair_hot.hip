@@ -18,12 +18,16 @@ hipError_t launch_hot_ts(const PairDev &P, const AtomsDev &A, const ListDev &L, 
 #define UCG_LAUNCH(EVF)                                                                                 \
   do {                                                                                                  \
     auto kern = k_pair_gather<STYLE, TS, EVF, true, true, SLOTS>;                                       \
+    const bool p2 = P.kT_pow2 != 0;                                                                     \
     if constexpr (STYLE == 1) {                                                                         \
       if (P.onetype_same10)                                                                             \
-        kern = P.pseudo_flag ? k_pair_gather<STYLE, TS, EVF, true, true, SLOTS, true, 1>                \
-                             : k_pair_gather<STYLE, TS, EVF, true, true, SLOTS, true, 0>;               \
+        kern = P.pseudo_flag ? (p2 ? k_pair_gather<STYLE, TS, EVF, true, true, SLOTS, true, 1, 1>       \
+                                   : k_pair_gather<STYLE, TS, EVF, true, true, SLOTS, true, 1>)         \
+                             : (p2 ? k_pair_gather<STYLE, TS, EVF, true, true, SLOTS, true, 0, 1>       \
+                                   : k_pair_gather<STYLE, TS, EVF, true, true, SLOTS, true, 0>);        \
     } else if (P.onetype_same10) {                                                                      \
-      kern = k_pair_gather<STYLE, TS, EVF, true, true, SLOTS, true>;                                    \
+      kern = p2 ? k_pair_gather<STYLE, TS, EVF, true, true, SLOTS, true, -1, 1>                         \
+                : k_pair_gather<STYLE, TS, EVF, true, true, SLOTS, true>;                               \
     }                                                                                                   \
     if (ldsbytes > 48 * 1024) {                                                                         \
       hipError_t e = hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, \

@@ -30,6 +30,10 @@
 // where the reference's scalar x86-64 code rounds.
 #pragma once
 
+#ifndef UCG_VARIANT
+#define UCG_VARIANT 0
+#endif
+
 #include "ucg_pair_dev.h"
 
 namespace ucg {
@@ -58,8 +62,10 @@ __device__ __forceinline__ void gather_bead_split(const AtomsDev &A, const doubl
 
 // SCE (table_ucg_bethe): -1 = P.pseudo_flag decides at run time; 0 = pseudo-likelihood scores only (`pseudo yes`), the
 // full-SCE code and the per-row reciprocals it keeps in registers are compiled out; 1 = full SCE (`pseudo no`)
-template <int STYLE, int TS, bool EV, bool LDS_TAB, bool FAST, int SLOTS, bool ONETYPE = false, int SCE = -1>
-__global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, const AtomsDev A,
+// KTP2: 1 = kT is a power of two (known on the host): u / kT is the exact product u * (1 / kT) and the general quotient's
+// code (a uniform branch and a range test per division) is compiled out; -1 = P.kT_pow2 decides at run time
+template <int STYLE, int TS, bool EV, bool LDS_TAB, bool FAST, int SLOTS, bool ONETYPE = false, int SCE = -1, int KTP2 = -1>
+__global__ __launch_bounds__(PAIR_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_pair_gather(const PairDev P, const AtomsDev A,
                                                            const ListDev Lst, double *evpart,
                                                            int *errflag)
 {
@@ -116,7 +122,7 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
   const int nlocal = A.nlocal;
   const int na1 = P.n_actual + 1;
   const double kT = P.kT, rkT = P.rkT;
-  const int kTp2 = P.kT_pow2;
+  const int kTp2 = KTP2 >= 0 ? KTP2 : P.kT_pow2;
   const int pseudo_flag = SCE < 0 ? P.pseudo_flag : SCE;
   double ev[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int err = 0;
@@ -215,12 +221,34 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
     int mm;
     gather_bead_split(A, s_ownpos, s_ownmeta, k0, nown, ent & 0x1FFFFFFF, pm, mm);
     rp += rstep;
+#if UCG_VARIANT == 4
+    // (experiment) three-stage pipeline: the gather of entry e+2 is issued while entry e is evaluated
+    int ent_n2 = (slot + 2 * SLOTS < n) ? rp[rstep] : ent_n;
+    double4 pm_n;
+    int mm_n;
+    gather_bead_split(A, s_ownpos, s_ownmeta, k0, nown, ent_n & 0x1FFFFFFF, pm_n, mm_n);
+    rp += rstep;
+#endif
     for (int e = slot; e < n; e += SLOTS) {
       rp += rstep;
+#if UCG_VARIANT == 4
+      const int ent_n3 = (e + 3 * SLOTS < n) ? rp[0] : ent_n2;
+      double4 pm_n2;
+      int mm_n2;
+      gather_bead_split(A, s_ownpos, s_ownmeta, k0, nown, ent_n2 & 0x1FFFFFFF, pm_n2, mm_n2);
+#else
       const int ent_nn = (e + 2 * SLOTS < n) ? rp[0] : ent_n;
       double4 pm_n;
       int mm_n;
+#endif
+#if UCG_VARIANT == 4
+#elif UCG_VARIANT == 2 || UCG_VARIANT == 3
+      // (experiment) the next entry's flat loads are issued only after this entry's knot reads have been issued, so that
+      // the knot reads' waits can count (a flat load in flight forces every LDS wait to lgkmcnt(0))
+      bool gathered = false;
+#else
       gather_bead_split(A, s_ownpos, s_ownmeta, k0, nown, ent_n & 0x1FFFFFFF, pm_n, mm_n);
+#endif
 
       const int m = ent & 0x1FFFFFFF;
       const bool k_is_i = (ent >> 29) & 1;
@@ -250,6 +278,12 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
                                                   nullptr, false, -1, FAST ? &parF : nullptr);
         else eval_quad<TS, FAST>(FAST ? P.tab_fast : P.tab, s_par, pt, P.tablength, P.tlm1, P.fast_stride, rsq, factor_lj, q, err, rtrack,
                                  hot_ent ? reinterpret_cast<const double2 *>(s_tab) : nullptr, tk == P.hot_type && tm == P.hot_type, P.hot_k0);
+#if UCG_VARIANT == 2 || UCG_VARIANT == 3
+        __builtin_amdgcn_sched_barrier(0);
+        gather_bead_split(A, s_ownpos, s_ownmeta, k0, nown, ent_n & 0x1FFFFFFF, pm_n, mm_n);
+        gathered = true;
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 
         double evdwl = 0.0, fpair;
         if (STYLE == 0 || pseudo_flag == 0) {
@@ -376,10 +410,23 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_pair_gather(const PairDev P, con
           ev[6] += 0.5 * (dy * dz * fpair);
         }
       }
+#if UCG_VARIANT == 2 || UCG_VARIANT == 3
+      if (!gathered) gather_bead_split(A, s_ownpos, s_ownmeta, k0, nown, ent_n & 0x1FFFFFFF, pm_n, mm_n);
+#endif
+#if UCG_VARIANT == 4
+      ent = ent_n;
+      ent_n = ent_n2;
+      ent_n2 = ent_n3;
+      pm = pm_n;
+      mm = mm_n;
+      pm_n = pm_n2;
+      mm_n = mm_n2;
+#else
       ent = ent_n;
       ent_n = ent_nn;
       pm = pm_n;
       mm = mm_n;
+#endif
     }
   }
   if (active) {

@@ -404,8 +404,18 @@ def run_bench(args, deck, beads, cs, rank, world, device_index, dist, shared, ma
                nlocal_sum=int(tot[2]), rank0_list_entries=info["list_entries"], rank0_nlocal=info["nlocal"],
                transport=(f"gloo callbacks, host-staged: {world} ranks share {torch.cuda.device_count()} GPU(s) (rehearsal of the N > 1 path)"
                           if shared else "RCCL called from the library's C++ step loop (grouped ncclSend / ncclRecv over xGMI)"))
-    if not shared and not ctx.comm_info()["rccl"]:
+    tinfo = ctx.comm_transport()
+    out["rccl"] = tinfo["rccl"]
+    out["rccl_nranks"] = tinfo["rccl_nranks"]  # ncclCommCount of the attached communicator (0: no RCCL)
+    if not shared and not tinfo["rccl"]:
         out["transport"] = sim.transport_note or f"RCCL transport unavailable ({rccl_why}): host-staged gloo callbacks used instead"
+        # every rank has a GPU of its own and RCCL still did not attach: a scaling number measured over host-staged gloo
+        # must not pass for an xGMI one.  UCG_BENCH_ALLOW_HOST_STAGED=1 lets the run stand (its JSON says "rccl": false).
+        if os.environ.get("UCG_BENCH_ALLOW_HOST_STAGED") != "1":
+            raise SystemExit("bench.py: --gpus %d found a GPU per rank but RCCL did not attach (%s); refusing to report a "
+                             "host-staged number as the scaling result (UCG_BENCH_ALLOW_HOST_STAGED=1 overrides)" % (world, out["transport"]))
+    if tinfo["rccl"] and tinfo["rccl_nranks"] != world:
+        raise SystemExit(f"bench.py: RCCL reports {tinfo['rccl_nranks']} ranks for a world of {world}")
     if cs:
         out["cluster_switch_vector"] = [float(v) for v in ctx.fix_cluster_switch_vector()]
     return out

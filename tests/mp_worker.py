@@ -79,6 +79,33 @@ def main():
                       nrebuild=sim.nrebuild)
         pair.close()
         ctx.close()
+    elif mode == "gpu_rccl":
+        # one GPU per rank, the library's RCCL transport between DISTINCT devices (tests/test_multi_rank.py skips this
+        # where the box has fewer GPUs than ranks)
+        capi = pkg.capi
+        beads = synth.make_beads(12, seed=5)
+        deck = util.make_deck("spline", 1024)
+        ctx = capi.Context(rank, dt=0.004)
+        sl = slice(rank * beads.n // world, (rank + 1) * beads.n // world)
+        n = sl.stop - sl.start
+        ctx.atoms_upload(n, 0, beads.ntypes, beads.x[sl], beads.v[sl], beads.type[sl], beads.tag[sl], beads.mask[sl],
+                         beads.ucgstate[sl], beads.ucgl[sl], beads.ucgvl[sl], beads.ucgml[sl], beads.ucgp[sl], beads.mass)
+        ctx.domain_set(beads.boxlo, beads.boxhi, 2.5, 0.3, every=2, delay=0, check=1)
+        pair = util.gpu_pair(ctx, "table_ucgld", deck)
+        box = [capi.Context.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        tr = multi.Transport(dist, torch.device("cuda", rank), staged=True)
+        sim = multi.RankSim(ctx, pair, tr, grid, use_langevin=False, use_ucgstate=False, rccl_id=box[0])
+        assert sim.transport_note is None, sim.transport_note
+        sim.setup(40)
+        A0 = ctx.atoms_download()
+        sim.run(40)
+        pair.check_errors()
+        A1 = ctx.atoms_download()
+        result = dict(transport=ctx.comm_transport(), tag0=A0["tag"], f0=A0["f"], uf0=A0["ucgforce"], s0=A0["scores"],
+                      tag1=A1["tag"], x1=A1["x"], l1=A1["ucgl"], nrebuild=sim.nrebuild)
+        pair.close()
+        ctx.close()
     elif mode == "gpu_fault":
         # a rank-local failure in the step loop (injected on rank 1 at step 7): BOTH ranks must come back from ucg_md_run
         # with an error -- the failing one with its own message, the other told that a peer failed -- instead of one of
