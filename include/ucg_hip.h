@@ -100,6 +100,10 @@ int ucg_ctx_set_option(ucg_ctx *ctx, const char *name, int value);
 int ucg_selftest_stream(ucg_ctx *ctx, long long nbytes, int wide, int repeats);
 /* device self-test: n random operands, counts a / b != div_by_const(a, b) (must be 0) */
 int ucg_selftest_div(ucg_ctx *ctx, double b, long long seed, int n, long long *mismatches);
+/* the same for the bare Newton-Raphson core the math kernels use where the operand scaling of the hardware division is the
+ * identity (csrc/ucg_math.h: ucg_div_core): n random numerators (exponents -112 ... 2, and zeros) over denominators in
+ * [1.25, 2.75] and [5.25, 6.75]; counts the quotients that differ from a / b (must be 0) */
+int ucg_selftest_div_core(ucg_ctx *ctx, long long seed, int n, long long *mismatches);
 
 /* --------------------------------------------------------------- pair styles
  * replaces PairTable_UCGLD / PairTable_UCG_Bethe / PairTable_UCG_Bethe_Density

@@ -498,7 +498,7 @@ int ucg_pair_init(ucg_pair *p, int ntypes, double T)
         // one actual type, tables too long for the LDS: the knots of the far end of the r^2 grid -- as many as fit next
         // to 1024 staged beads -- are kept there (PairDev::hot_k0); the window starts at an even knot so that it is a
         // double4-aligned piece of the FAST layout
-        const size_t budget = 160 * 1024 - 6 * 1024 - (ctx->stage_own ? (size_t) 1024 * 36 : 0) - 1024;
+        const size_t budget = 160 * 1024 - 6 * 1024 - (ctx->stage_own ? (size_t) 1024 * (M.style == STYLE_BETHE ? 44 : 36) : 0) - 1024;
         int nk = (int) (budget / ((size_t) D.fast_stride * sizeof(double2)));
         int k0 = tl - nk;
         if (k0 < 0) k0 = 0;
@@ -511,8 +511,8 @@ int ucg_pair_init(ucg_pair *p, int ntypes, double T)
       }
       D.gather_slots = slots0;
       p->tab_lds_bytes = D.tab_in_lds ? bytes : (size_t) D.hot_ent * sizeof(double4);
-      const size_t own = (size_t) (1024 / slots0) * 36;
-      const size_t used = p->tab_lds_bytes + own + 6 * 1024;  // + the static model arrays
+      const size_t own = (size_t) (1024 / slots0) * (M.style == STYLE_BETHE ? 44 : 36);  // pair_own_bytes: + ucgp for table_ucg_bethe
+      const size_t used = p->tab_lds_bytes + own + 4 * 1024;  // + the static model arrays (3.5 KB at most)
       D.stage_own = (ctx->stage_own && used <= 160 * 1024) ? 1 : 0;
       D.stage_own_allowed = ctx->stage_own ? 1 : 0;
     }
@@ -706,16 +706,17 @@ static int pair_compute_impl(ucg_pair *p, int eflag, int vflag, double *eng_vdwl
         }
       }
       p->dev.gather_slots = slots;
-      const size_t own = (size_t) (1024 / slots) * 36;
-      p->dev.stage_own = (ctx->stage_own && p->tab_lds_bytes + own + 6 * 1024 <= 160 * 1024) ? 1 : 0;
+      const size_t own = (size_t) (1024 / slots) * (p->model.style == STYLE_BETHE ? 44 : 36);
+      p->dev.stage_own = (ctx->stage_own && p->tab_lds_bytes + own + 4 * 1024 <= 160 * 1024) ? 1 : 0;
     }
     if (!p->host_tab.empty()) {
       // density: its pass 2 stages 1024 beads; the gather kernels 1024 / lanes-per-bead
-      const size_t own = p->model.style == STYLE_BETHE_DENSITY ? (size_t) 1024 * 36 : (size_t) (1024 / p->dev.gather_slots) * 36;
+      const size_t own = p->model.style == STYLE_BETHE_DENSITY ? (size_t) 1024 * 36
+                                                               : (size_t) (1024 / p->dev.gather_slots) * (p->model.style == STYLE_BETHE ? 44 : 36);
       choose_hot_block(ctx, p, ctx->stage_own ? own : 0);
       const size_t hot = (size_t) p->dev.hot_ent * sizeof(double4);
       p->tab_lds_bytes = hot;
-      p->dev.stage_own = (ctx->stage_own && hot + (size_t) (1024 / p->dev.gather_slots) * 36 + 6 * 1024 <= 160 * 1024) ? 1 : 0;
+      p->dev.stage_own = (ctx->stage_own && hot + own + 4 * 1024 <= 160 * 1024) ? 1 : 0;
     }
     const int nb = p->vrow ? vrow_blocks(ctx->nlocal) : pair_gather_blocks(ctx->nlocal, p->dev.gather_slots);
     if (ev) p->d_evpart.reserve((size_t) nb * 8 + 8);
@@ -773,6 +774,8 @@ static int pair_compute_impl(ucg_pair *p, int eflag, int vflag, double *eng_vdwl
         L.blockwant = part == 1 ? 0 : 1;
       }
       if (post) L.post = *post;
+      // (a mirror upload in mirror_need above may just have raised it)
+      p->dev.first_possible = ctx->ucgp_first_possible ? 1 : 0;
       if (p->vrow)
         UCG_HIP(launch_pair_vrow(p->dev, ctx->atoms_dev(), L, p->d_vr_ent.get(), (size_t) p->vr_pitch * (size_t) p->vr_cap,
                                  p->d_vr_lanemeta.get(), p->vr_pitch, ev, p->d_evpart.get(), p->d_evout.get(), p->d_err.get(),
@@ -819,7 +822,7 @@ int ucg_pair_density_phase(ucg_pair *p, int phase, int eflag, int vflag, double 
       p->d_partial.reserve((size_t) ctx->nlocal + 1);
       p->d_evpart.reserve((size_t) density_evpart_doubles(ctx->nlocal));
     }
-    if (!p->host_tab.empty()) choose_hot_block(ctx, p, ctx->stage_own ? (size_t) 1024 * 36 : 0);
+    if (!p->host_tab.empty()) choose_hot_block(ctx, p, ctx->stage_own ? (size_t) 1024 * 36 : 0);  // (the density style: no ucgp staged)
     mirror_need(ctx, UCG_F_X | UCG_F_STATE | UCG_F_UCGL | UCG_F_UCGP);
     mirror_wrote(ctx, UCG_F_F | UCG_F_UCGFORCE | UCG_F_SCORES | UCG_F_NSTATES | UCG_F_UCGP);
     UCG_HIP(launch_density_phase(p->dev, ctx->atoms_dev(), ctx->list_dev(), phase, ev, p->d_prior.get(), p->d_partial.get(),
@@ -883,6 +886,9 @@ int ucg_pair_check_errors(ucg_pair *p)
     UCG_HIP(hipMemsetAsync(p->d_err.get(), 0, sizeof(int), ctx->stream));
     if (flag & 1) return fail(ctx, UCG_ERR_TABLE_INNER, "Pair distance < table inner cutoff");
     if (flag & 2) return fail(ctx, UCG_ERR_TABLE_OUTER, "Pair distance > table outer cutoff");
+    if (flag & 16)
+      return fail(ctx, UCG_ERR_INVALID, "internal error: the Bethe gather kernel met a first-call marker (ucgp < -0.999) although the "
+                                        "library held every bead's ucgp to be set");
     if (flag & 8) p->vr_gen = -1;  // the unusable virtual rows are made (and found wanting) again by the next compute: reported every time
     if (flag & 8)
       return fail(ctx, UCG_ERR_UNSUPPORTED, "the virtual rows of a block of 512 beads do not fit (a row of more than 128 entries, or "
@@ -925,6 +931,11 @@ int ucg_atoms_upload(ucg_ctx *ctx, int nlocal, int nghost, int ntypes, const dou
       meta[i] = (type[i] & 0xFFFF) | ((ucgstate[i] & 1) << 16);
       tg[i] = tag ? tag[i] : (int) i + 1;
       up[i] = ucgp ? ucgp[i] : -1.0;
+    }
+    {
+      bool first = false;
+      for (size_t i = 0; i < nall && !first; i++) first = !(up[i] >= 0.0);
+      ctx->ucgp_first_possible = first;
     }
     for (size_t i = 0; i < nl; i++) {
       v4[i] = make_double4(v ? v[3 * i] : 0.0, v ? v[3 * i + 1] : 0.0, v ? v[3 * i + 2] : 0.0, ucgvl ? ucgvl[i] : 0.0);
@@ -973,7 +984,12 @@ int ucg_atoms_upload_comm(ucg_ctx *ctx, const double *x, const int *ucgstate, co
     }
     h2d(ctx, ctx->pos4.get(), p4.data(), nall);
     h2d(ctx, ctx->meta.get(), meta.data(), nall);
-    if (ucgp) h2d(ctx, ctx->ucgp.get(), ucgp, nall);
+    if (ucgp) {
+      h2d(ctx, ctx->ucgp.get(), ucgp, nall);
+      bool first = false;
+      for (size_t i = 0; i < nall && !first; i++) first = !(ucgp[i] >= 0.0);
+      ctx->ucgp_first_possible = first;
+    }
     sync(ctx);
     return UCG_OK;
   });
@@ -1018,7 +1034,10 @@ int ucg_atoms_upload_owned(ucg_ctx *ctx, const double *x, const double *v, const
       h2d(ctx, ctx->meta.get(), meta.data(), nl);
     }
     if (num_ucgstates) h2d(ctx, ctx->num_ucgstates.get(), num_ucgstates, nl);
-    if (ucgp) h2d(ctx, ctx->ucgp.get(), ucgp, nl);
+    if (ucgp) {
+      h2d(ctx, ctx->ucgp.get(), ucgp, nl);
+      for (size_t i = 0; i < nl && !ctx->ucgp_first_possible; i++) ctx->ucgp_first_possible = !(ucgp[i] >= 0.0);
+    }
     if (ucgsoftmaxscores) h2d(ctx, (double *) ctx->scores.get(), ucgsoftmaxscores, 2 * nl);
     sync(ctx);
     return UCG_OK;
@@ -1492,6 +1511,7 @@ int ucg_fix_ucgstate_post_force(ucg_ctx *ctx)
     }
     mirror_need(ctx, UCG_F_SCORES | UCG_F_NSTATES | UCG_F_STATE | UCG_F_X | UCG_F_UCGL);
     UCG_HIP(launch_ucgstate(ctx->atoms_dev(), S.ld_flag, S.mc_flag, S.mc_rate, draws, ctx->stream));
+    ctx->ucgp_first_possible = false;  // every owned bead's ucgp now lies in [1e-6, 1 - 1e-6] (or is 1 for a one-state bead)
     mirror_wrote(ctx, UCG_F_UCGP | UCG_F_STATE | UCG_F_UCGL);
     return UCG_OK;
   });
@@ -1530,6 +1550,7 @@ int ucg_md_post_fused(ucg_ctx *ctx, int use_langevin, int use_ucgstate, int use_
     UCG_HIP(launch_post_fused(ctx->atoms_dev(), use_langevin != 0, Lg, use_ucgstate != 0, S.ld_flag, S.mc_flag, S.mc_rate,
                               mc_draws, use_nve != 0, fuse_next_initial != 0, ctx->dt, 0.5 * ctx->dt * ctx->ftm2v,
                               groupbit, use_nve >= 2 ? (ctx->wall_bias ? 3 : 2) : 0, ctx->wall_barrier, ctx->stream));
+    if (use_ucgstate) ctx->ucgp_first_possible = false;
     mirror_wrote(ctx, UCG_F_ALL);
     return UCG_OK;
   });
@@ -1594,7 +1615,10 @@ int ucg_md_pair_post(ucg_ctx *ctx, ucg_pair *p, int use_langevin, int use_ucgsta
   // the next step's positions / states become the current ones (ghost entries are refreshed by the halo)
   ctx->pos4.swap(ctx->pos4_alt);
   ctx->meta.swap(ctx->meta_alt);
-  if (Q.ucgst) ctx->ucgp.swap(ctx->ucgp_alt);
+  if (Q.ucgst) {
+    ctx->ucgp.swap(ctx->ucgp_alt);
+    ctx->ucgp_first_possible = false;
+  }
   mirror_wrote(ctx, UCG_F_ALL);
   return UCG_OK;
 }
@@ -1633,6 +1657,22 @@ int ucg_selftest_div(ucg_ctx *ctx, double b, long long seed, int n, long long *m
     d.reserve(2);
     UCG_HIP(hipMemsetAsync(d.get(), 0, sizeof(unsigned long long), ctx->stream));
     UCG_HIP(launch_selftest_div(b, (unsigned long long) seed, n, d.get(), ctx->stream));
+    unsigned long long h = 0;
+    d2h(ctx, &h, d.get(), 1);
+    sync(ctx);
+    *mismatches = (long long) h;
+    return UCG_OK;
+  });
+}
+
+int ucg_selftest_div_core(ucg_ctx *ctx, long long seed, int n, long long *mismatches)
+{
+  if (!ctx || !mismatches || n < 0) return UCG_ERR_INVALID;
+  return guarded(ctx, [&]() -> int {
+    DevBuf<unsigned long long> d;
+    d.reserve(2);
+    UCG_HIP(hipMemsetAsync(d.get(), 0, sizeof(unsigned long long), ctx->stream));
+    UCG_HIP(launch_selftest_div_core((unsigned long long) seed, n, d.get(), ctx->stream));
     unsigned long long h = 0;
     d2h(ctx, &h, d.get(), 1);
     sync(ctx);

@@ -235,6 +235,28 @@ void alltoallv_gap(ucg_ctx *ctx, const void *send, const long long *sendbytes, v
   nccl_check(g_rccl.GroupEnd(), "ncclGroupEnd");
 }
 
+// RCCL transport, host arrays, in the wire format of alltoall_counts_dev (4 bytes per peer each way): what a rank uses whose
+// counting kernel did not run (it holds a failure and sends zeros) while its peers exchange device counters
+void alltoall_counts32(ucg_ctx *ctx, const long long *send, long long *recv)
+{
+  CommState &C = *ctx->comm;
+  const size_t w = (size_t) C.world;
+  C.dsmall.reserve(w + 8);
+  int *d = reinterpret_cast<int *>(C.dsmall.get());
+  std::vector<int> h(2 * w, 0);
+  for (size_t r = 0; r < w; r++) h[r] = (int) send[r];
+  UCG_HIP(hipMemcpyAsync(d, h.data(), w * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  nccl_check(g_rccl.GroupStart(), "ncclGroupStart");
+  for (int r = 0; r < C.world; r++) {
+    nccl_check(g_rccl.Send(d + r, 4, NCCL_CHAR, r, C.nccl, ctx->stream), "ncclSend");
+    nccl_check(g_rccl.Recv(d + w + r, 4, NCCL_CHAR, r, C.nccl, ctx->stream), "ncclRecv");
+  }
+  nccl_check(g_rccl.GroupEnd(), "ncclGroupEnd");
+  UCG_HIP(hipMemcpyAsync(h.data() + w, d + w, w * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  UCG_HIP(hipStreamSynchronize(ctx->stream));
+  for (size_t r = 0; r < w; r++) recv[r] = h[w + r];
+}
+
 // one long long per peer, host arrays, blocking
 void alltoall_counts(ucg_ctx *ctx, const long long *send, long long *recv)
 {
@@ -254,6 +276,31 @@ void alltoall_counts(ucg_ctx *ctx, const long long *send, long long *recv)
   nccl_check(g_rccl.GroupEnd(), "ncclGroupEnd");
   UCG_HIP(hipMemcpyAsync(recv, C.dsmall.get() + w, w * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
   UCG_HIP(hipStreamSynchronize(ctx->stream));
+}
+
+// RCCL transport: the per-destination counters (world ints on the device, fresh from the counting kernel) go straight into
+// a grouped 4-byte send / receive per peer; the host gets its send AND receive counts with one synchronisation (the
+// host-array form above costs two: the counters' download, then the exchanged counts')
+void alltoall_counts_dev(ucg_ctx *ctx, const int *dev_send, long long *send, long long *recv)
+{
+  CommState &C = *ctx->comm;
+  const size_t w = (size_t) C.world;
+  C.dsmall.reserve(w + 8);
+  int *drecv = reinterpret_cast<int *>(C.dsmall.get());
+  nccl_check(g_rccl.GroupStart(), "ncclGroupStart");
+  for (int r = 0; r < C.world; r++) {
+    nccl_check(g_rccl.Send(dev_send + r, 4, NCCL_CHAR, r, C.nccl, ctx->stream), "ncclSend");
+    nccl_check(g_rccl.Recv(drecv + r, 4, NCCL_CHAR, r, C.nccl, ctx->stream), "ncclRecv");
+  }
+  nccl_check(g_rccl.GroupEnd(), "ncclGroupEnd");
+  std::vector<int> h(2 * w);
+  UCG_HIP(hipMemcpyAsync(h.data(), dev_send, w * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  UCG_HIP(hipMemcpyAsync(h.data() + w, drecv, w * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  UCG_HIP(hipStreamSynchronize(ctx->stream));
+  for (size_t r = 0; r < w; r++) {
+    send[r] = h[r];
+    recv[r] = h[w + r];
+  }
 }
 
 // op: 0 sum, 1 max, 2 min
@@ -371,9 +418,25 @@ int multi_rebuild(ucg_ctx *ctx, const LocalStatus *held = nullptr, bool agree = 
   auto zero = [&]() {
     if (st.bad != UCG_OK) std::fill(sc.begin(), sc.end(), 0LL);
   };
-  st.run(ctx, [&] { return ucg_exchange_count(ctx, sc.data()); });
-  zero();
-  alltoall_counts(ctx, sc.data(), rc.data());
+  // counts: on the RCCL transport exchanged on the device (one synchronisation); a rank that has already failed takes
+  // the host form with zeros, which its peers' device form matches message by message (4 bytes each way per peer)
+  const int *dcounts = nullptr;
+  auto exchange_counts = [&](int which) {
+    if (C.rccl && st.bad == UCG_OK) {
+      st.run(ctx, [&] { return which == 0 ? exchange_count_launch(ctx, &dcounts) : border_count_launch(ctx, &dcounts); });
+      if (st.bad == UCG_OK) {
+        alltoall_counts_dev(ctx, dcounts, sc.data(), rc.data());
+        st.run(ctx, [&] { return counts_adopt(ctx, which, sc.data()); });
+        return;
+      }
+    } else {
+      st.run(ctx, [&] { return which == 0 ? ucg_exchange_count(ctx, sc.data()) : ucg_border_count(ctx, sc.data()); });
+    }
+    zero();
+    if (C.rccl) alltoall_counts32(ctx, sc.data(), rc.data());
+    else alltoall_counts(ctx, sc.data(), rc.data());
+  };
+  exchange_counts(0);
   for (size_t r = 0; r < w; r++) {
     sb[r] = sc[r] * arec;
     rb[r] = rc[r] * arec;
@@ -383,9 +446,7 @@ int multi_rebuild(ucg_ctx *ctx, const LocalStatus *held = nullptr, bool agree = 
   st.run(ctx, [&] { return ucg_exchange_pack(ctx, C.send.get()); });
   alltoallv(ctx, C.send.get(), sb.data(), C.recv.get(), rb.data());
   st.run(ctx, [&] { return ucg_exchange_unpack(ctx, C.recv.get(), sum(rc)); });
-  st.run(ctx, [&] { return ucg_border_count(ctx, sc.data()); });
-  zero();
-  alltoall_counts(ctx, sc.data(), rc.data());
+  exchange_counts(1);
   for (size_t r = 0; r < w; r++) {
     sb[r] = sc[r] * hrec;
     rb[r] = rc[r] * hrec;
@@ -610,6 +671,13 @@ int md_setup_multi(ucg_ctx *ctx)
       multi_cluster_sync_after_create(ctx, ls);
       UCG_RC(ls.agree(ctx, "in the survey of fix cluster_switch"));
     }
+    {
+      // table_ucg_bethe: beads arrive from other ranks in the exchange below; one rank's "a first-call marker may be around"
+      // is every rank's (uploads differ per rank; the fixes that lower the flag run in lockstep)
+      long long fp = ctx->ucgp_first_possible ? 1 : 0;
+      allreduce_ll(ctx, &fp, 1, 1);
+      ctx->ucgp_first_possible = fp != 0;
+    }
     UCG_RC(multi_rebuild(ctx, &ls));  // (ends with an agreement of its own)
     if (ctx->md_lang && !ctx->lang.inited) {
       // Fix_UCGLD_Langevin::init(): reads atom->ucgml[1..ntypes] of the LOCAL bead order (App. B #5)
@@ -649,9 +717,40 @@ int md_run_multi(ucg_ctx *ctx, long long nsteps, int thermo_every, int ev_on_las
       if (ctx->md_nve && !initial_done)
         ls.run(ctx, [&] { return ctx->md_nve == 2 ? ucg_fix_nve_wall_hard_initial(ctx, ctx->groupbit) : ucg_fix_nve_initial(ctx, ctx->groupbit); });
       int due = 0, flag = 0, pair_flag = -1;
-      UCG_RC(decide_local_impl(ctx, &due, &flag, &pair_flag));  // (the schedule must stay in step on every rank: a failure here is fatal)
       const bool fuse_next = ctx->md_nve && !ev && (s + 1 < nsteps) && !ctx->md_no_fuse;
       bool rebuilt = false;
+      if (ctx->comm->rccl) {
+        // RCCL transport: {a bead moved too far, this rank's status, the pair kernels' error flag} are all-reduced where the
+        // decision's kernels leave them -- on the device -- and come back with ONE download (the host-array form below
+        // costs two synchronisations: the flags' download, then the all-reduce's)
+        CommState &C = *ctx->comm;
+        C.dsmall.reserve(16);
+        int checked = 0;
+        UCG_RC(decide_launch(ctx, &due, &checked, C.dsmall.get()));  // (the schedule must stay in step on every rank: a failure here is fatal)
+        if (due) {
+          long long h[3] = {1, ls.bad, 1};  // no distance check: the step re-neighbours; the flag is unknown: poll
+          if (checked) UCG_HIP(hipMemcpyAsync(C.dsmall.get() + 2, &h[1], sizeof(long long), hipMemcpyHostToDevice, ctx->stream));
+          else UCG_HIP(hipMemcpyAsync(C.dsmall.get(), h, sizeof h, hipMemcpyHostToDevice, ctx->stream));
+          if (checked) {
+            // the kernel wrote {moved, pair flag}; the wire order is {moved, status, pair flag}: status goes to slot 2 and the
+            // two are swapped on the host after the download
+          }
+          nccl_check(g_rccl.AllReduce(C.dsmall.get(), C.dsmall.get(), 3, NCCL_INT64, NCCL_MAX, C.nccl, ctx->stream), "ncclAllReduce");
+          long long f[3];
+          UCG_HIP(hipMemcpyAsync(f, C.dsmall.get(), sizeof f, hipMemcpyDeviceToHost, ctx->stream));
+          UCG_HIP(hipStreamSynchronize(ctx->stream));
+          const long long moved = f[0], status = checked ? f[2] : f[1], pairf = checked ? f[1] : f[2];
+          if (status != UCG_OK) {
+            ctx->err = ls.bad != UCG_OK ? ls.msg : std::string("another rank failed in the step loop (every rank stops; the job must be aborted)");
+            return (int) status;
+          }
+          if (pairf != 0) UCG_RC(poll_pair_errors(ctx, &ls));
+          rebuilt = moved != 0;
+        }
+        due = 0;  // handled
+      } else {
+        UCG_RC(decide_local_impl(ctx, &due, &flag, &pair_flag));
+      }
       if (due) {
         // Neighbor::decide(): MPI_Allreduce of the flag -- and, in the same message, of the ranks' status since the last
         // agreement and of the pair kernels' sticky table-range flag (read by the decision's own download: -1 = the

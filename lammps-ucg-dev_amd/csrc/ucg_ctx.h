@@ -162,6 +162,11 @@ struct ucg_ctx {
   ucg::DevBuf<int> mol;  // atom->molecule of the owned beads (optional: ucg_atoms_upload_molecule)
   bool has_mol = false;
   ucg::DevBuf<double> ucgp, ucgml, mass;
+  // "some resident bead may still carry ucgp < -0.999" (the first-call marker of table_ucg_bethe, UCG/pair_table_ucg_bethe.cpp:
+  // 179-205): raised by every upload whose ucgp holds such a value (or whose ucgp the library cannot see), lowered when a fix
+  // ucgstate pass has written ucgp of ALL owned beads; in decomposed runs agreed over the ranks with the re-neighbour
+  // decision.  While it is down the Bethe gather kernel skips the first-call rules (and reports a marker it meets anyway).
+  bool ucgp_first_possible = true;
   // neighbour list
   ucg::DevBuf<int> neigh, numneigh;
   ucg::DevBuf<int> ghost_src;  // owned bead each ghost images (single-rank periodic images)
@@ -261,6 +266,10 @@ int md_run_multi(ucg_ctx *ctx, long long nsteps, int thermo_every, int ev_on_las
 int halo_pack_peers(ucg_ctx *ctx, void *sendbuf, long long so_self, long long nself);
 int halo_unpack_self(ucg_ctx *ctx, const void *recvbuf, long long ro_self, long long so_self, long long nself);
 int decide_local_impl(ucg_ctx *ctx, int *due, int *flag, int *pair_flag);
+int decide_launch(ucg_ctx *ctx, int *due, int *checked, long long *dev_out3);
+int exchange_count_launch(ucg_ctx *ctx, const int **dev_counts);
+int border_count_launch(ucg_ctx *ctx, const int **dev_counts);
+int counts_adopt(ucg_ctx *ctx, int which, const long long *sendcounts);
 bool cluster_forces_rebuild(const ucg_ctx *ctx);
 void cluster_pre_exchange(ucg_ctx *ctx);
 }

@@ -28,6 +28,7 @@ struct PairDev {
   int ntab;            // tables resident on the device (those reachable through tabindex)
   int tab_in_lds;      // 1: the kernels stage all tables in LDS
   int pseudo_flag, prior_flag, method_flag;
+  int first_possible;  // table_ucg_bethe: some bead may still carry the first-call marker ucgp < -0.999 (ucg_ctx::ucgp_first_possible)
   const double4 *tab;     // [ntab * tablength]
   const double4 *tab_fast;  // FAST layout: [tablength][2*ntab+1] 16-byte slots (see ucg_pair.hip)
   int fast_stride;        // 2*ntab+1

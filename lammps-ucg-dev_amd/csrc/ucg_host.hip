@@ -134,7 +134,10 @@ void mirror_need(ucg_ctx *ctx, unsigned reads)
     UCG_HIP(hipGetLastError());
   }
   if (up & UCG_F_NSTATES) UCG_HIP(hipMemcpyAsync(ctx->num_ucgstates.get(), M.nstates, n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-  if (up & UCG_F_UCGP) UCG_HIP(hipMemcpyAsync(ctx->ucgp.get(), M.ucgp, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  if (up & UCG_F_UCGP) {
+    UCG_HIP(hipMemcpyAsync(ctx->ucgp.get(), M.ucgp, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    for (size_t i = 0; i < n && !ctx->ucgp_first_possible; i++) ctx->ucgp_first_possible = !(M.ucgp[i] >= 0.0);
+  }
   if (up & UCG_F_SCORES) UCG_HIP(hipMemcpyAsync(ctx->scores.get(), M.scores, 2 * n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   // pageable sources are staged by the runtime before the call returns; pinned ones must not change until the stream
   // has consumed them: drain (uploads happen on re-neighbouring / after host-side edits only)

@@ -179,6 +179,28 @@ UCG_HD double ucg_exp_nb(double x0)
   return UCG_BITS_U2D(UCG_BITS_D2U(y) + ((uint64_t)(int64_t)k << 52));
 }
 
+/* a / b for operands the caller knows to lie where the hardware division's operand scaling (v_div_scale_f64) is the
+ * identity: b normal with an exponent far from both ends, |a| >= 2^-900 or a == 0, a / b normal.  On gfx950 `a / b` is
+ * rcp + two Newton-Raphson steps on the reciprocal + one on the quotient, wrapped in two v_div_scale_f64, v_div_fmas_f64 and
+ * v_div_fixup_f64 that rescale extreme operands and patch the special cases; for operands in the range above those four are
+ * no-ops, so the bare core returns the same bits (the correctly rounded quotient) with four instructions less.  On the host
+ * it IS a / b.  tests/c_math/math_equiv.c and ucg_selftest_div compare the two on the ranges used. */
+#if defined(__HIP_DEVICE_COMPILE__)
+UCG_HD double ucg_div_core(double a, double b)
+{
+  double y = __builtin_amdgcn_rcp(b);
+  double e = __builtin_fma(-b, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-b, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  const double q = a * y;
+  const double r = __builtin_fma(-b, q, a);
+  return __builtin_fma(r, y, q);
+}
+#else
+UCG_HD double ucg_div_core(double a, double b) { return a / b; }
+#endif
+
 /* exp(x) and expm1(x) of the SAME argument (the Bethe closure needs both, UCG/pair_table_ucg_bethe.cpp:550-551), with
  * one shared argument reduction and almost no control flow -- on a GPU the two functions' many early exits and
  * k-dependent formulas make a wavefront run every path one of its 64 lanes takes.  Every result is bit for bit that of
@@ -220,7 +242,9 @@ UCG_HD void ucg_exp_expm1(double x0, double *ex, double *em1)
   /* exp */
   const double tt = x * x;
   const double c = x - tt * (P1 + tt * (P2 + tt * (P3 + tt * (P4 + tt * P5))));
-  const double y = 1.0 - ((lo - (x * c) / (2.0 - c)) - hi);
+  /* the two quotients below: denominators in [1.3, 2.7] and [5.4, 6.6]; numerators x c ~ x^2 >= 2^-109 and r1 - t3 ~ x / 2
+     (or exactly 0): inside ucg_div_core's range for every argument of the common path */
+  const double y = 1.0 - ((lo - ucg_div_core(x * c, 2.0 - c)) - hi);
   /* y * 2^k, k in {-1, 0}: exponent arithmetic as ucg_scalbn_ does for k >= -1021 */
   *ex = km1 ? UCG_BITS_U2D(UCG_BITS_D2U(y) - ((uint64_t)1 << 52)) : y;
   /* expm1 */
@@ -228,7 +252,7 @@ UCG_HD void ucg_exp_expm1(double x0, double *ex, double *em1)
   const double hxs = x * hfx;
   const double r1 = 1.0 + hxs * (Q1 + hxs * (Q2 + hxs * (Q3 + hxs * (Q4 + hxs * Q5))));
   const double t3 = 3.0 - r1 * hfx;
-  double e = hxs * ((r1 - t3) / (6.0 - x * t3));
+  double e = hxs * ucg_div_core(r1 - t3, 6.0 - x * t3);
   /* k = 0: x - (x e - hxs);  k = -1: e = x (e - c) - c; e -= hxs; 0.5 (x - e) - 0.5.  With c = 0 the k = -1 chain
      gives e = x e - hxs as well, so both cases share it */
   e = (x * (e - c2) - c2);

@@ -1780,9 +1780,15 @@ int ucg_decomp_set(ucg_ctx *ctx, const int *procgrid, int me)
   });
 }
 
-int ucg_exchange_count(ucg_ctx *ctx, long long *sendcounts)
+}  // extern "C"
+
+namespace ucg {
+// The two halves of ucg_exchange_count / ucg_border_count for a communicator that exchanges the counts ON THE DEVICE
+// (csrc/ucg_comm.hip, RCCL transport: the per-destination counters go from the kernel that made them straight into the
+// all-to-all, and the host reads its send and receive counts with one download): *_launch queues the counting kernels
+// and returns the device counters (world ints), counts_adopt installs the host copy afterwards.
+int exchange_count_launch(ucg_ctx *ctx, const int **dev_counts)
 {
-  if (!ctx || !sendcounts) return UCG_ERR_INVALID;
   if (int rc = need_domain(ctx)) return rc;
   return guarded(ctx, [&]() -> int {
     Domain &D = *ctx->dom;
@@ -1795,9 +1801,55 @@ int ucg_exchange_count(ucg_ctx *ctx, long long *sendcounts)
     if (n > 0)
       hipLaunchKernelGGL(k_exchange_dest, dim3(nblk(n)), dim3(NB), 0, ctx->stream, dd, n, ctx->pos4.get(),
                          D.counter.get(), D.dest_of.get(), D.slot_of.get());
-    counts_to_host(ctx, D, sendcounts);  // leavers only: sendcounts[me] == 0
-    for (int r = 0; r < D.world; r++) D.send_counts[(size_t) r] = sendcounts[r];
+    UCG_HIP(hipGetLastError());
+    if (dev_counts) *dev_counts = D.counter.get();
     return UCG_OK;
+  });
+}
+
+int border_count_launch(ucg_ctx *ctx, const int **dev_counts)
+{
+  if (int rc = need_domain(ctx)) return rc;
+  return guarded(ctx, [&]() -> int {
+    Domain &D = *ctx->dom;
+    const int n = ctx->nlocal;
+    setup_bins(D);
+    if (D.nbin[0] > 512 || D.nbin[1] > 512 || D.nbin[2] > 512) throw InputError{"more than 512 bins per dimension: too many for the sort key"};
+    if (n > 0) sort_owned(ctx, true);
+    const DomainDev dd = make_dev(D);
+    UCG_HIP(hipMemsetAsync(D.counter.get(), 0, (size_t) D.world * sizeof(int), ctx->stream));
+    if (n > 0)
+      hipLaunchKernelGGL(k_border_candidates<false>, dim3(nblk(n)), dim3(NB), 0, ctx->stream, dd, D.cutneigh, n, D.world,
+                         ctx->pos4.get(), D.counter.get(), nullptr, nullptr, nullptr);
+    UCG_HIP(hipGetLastError());
+    if (dev_counts) *dev_counts = D.counter.get();
+    return UCG_OK;
+  });
+}
+
+// which: 0 = the leavers' counts of exchange_count_launch, 1 = the ghosts' counts of border_count_launch
+int counts_adopt(ucg_ctx *ctx, int which, const long long *sendcounts)
+{
+  if (int rc = need_domain(ctx)) return rc;
+  Domain &D = *ctx->dom;
+  if (which == 1) D.nsend = 0;
+  for (int r = 0; r < D.world; r++) {
+    D.send_counts[(size_t) r] = sendcounts[r];
+    if (which == 1) D.nsend += sendcounts[r];
+  }
+  return UCG_OK;
+}
+}  // namespace ucg
+
+extern "C" {
+
+int ucg_exchange_count(ucg_ctx *ctx, long long *sendcounts)
+{
+  if (!ctx || !sendcounts) return UCG_ERR_INVALID;
+  if (int rc = exchange_count_launch(ctx, nullptr)) return rc;
+  return guarded(ctx, [&]() -> int {
+    counts_to_host(ctx, *ctx->dom, sendcounts);  // leavers only: sendcounts[me] == 0
+    return counts_adopt(ctx, 0, sendcounts);
   });
 }
 
@@ -1875,25 +1927,10 @@ int ucg_exchange_unpack(ucg_ctx *ctx, const void *recvbuf, long long nrecv)
 int ucg_border_count(ucg_ctx *ctx, long long *sendcounts)
 {
   if (!ctx || !sendcounts) return UCG_ERR_INVALID;
-  if (int rc = need_domain(ctx)) return rc;
+  if (int rc = border_count_launch(ctx, nullptr)) return rc;
   return guarded(ctx, [&]() -> int {
-    Domain &D = *ctx->dom;
-    const int n = ctx->nlocal;
-    setup_bins(D);
-    if (D.nbin[0] > 512 || D.nbin[1] > 512 || D.nbin[2] > 512) throw InputError{"more than 512 bins per dimension: too many for the sort key"};
-    if (n > 0) sort_owned(ctx, true);
-    const DomainDev dd = make_dev(D);
-    UCG_HIP(hipMemsetAsync(D.counter.get(), 0, (size_t) D.world * sizeof(int), ctx->stream));
-    if (n > 0)
-      hipLaunchKernelGGL(k_border_candidates<false>, dim3(nblk(n)), dim3(NB), 0, ctx->stream, dd, D.cutneigh, n, D.world,
-                         ctx->pos4.get(), D.counter.get(), nullptr, nullptr, nullptr);
-    counts_to_host(ctx, D, sendcounts);
-    D.nsend = 0;
-    for (int r = 0; r < D.world; r++) {
-      D.send_counts[(size_t) r] = sendcounts[r];
-      D.nsend += sendcounts[r];
-    }
-    return UCG_OK;
+    counts_to_host(ctx, *ctx->dom, sendcounts);
+    return counts_adopt(ctx, 1, sendcounts);
   });
 }
 
@@ -2069,6 +2106,56 @@ int ucg_md_set_timestep(ucg_ctx *ctx, long long ntimestep)
 }  // extern "C"
 
 namespace ucg {
+// The re-neighbour decision without its download (RCCL transport: the all-reduce runs on the device values).  *due as
+// ucg_decide_local; *checked = 1: the distance check was queued and dev_out3[0] = "a local bead moved > skin / 2",
+// dev_out3[1] = "the pair kernels' sticky error flag is up" will be on the stream (dev_out3[2] is the caller's);
+// *checked = 0 with *due = 1: no check is made (neigh_modify check no, or fix cluster_switch forces the step): flag = 1.
+__global__ void k_flags_any64(int nflags, const int *blockflags, const int *pair_err, long long *out)
+{
+  __shared__ int s_any;
+  if (threadIdx.x == 0) s_any = 0;
+  __syncthreads();
+  int any = 0;
+  for (int b = threadIdx.x; b < nflags; b += blockDim.x) any |= blockflags[b];
+  if (__any(any != 0) && (threadIdx.x & 63) == 0) s_any = 1;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[0] = s_any;
+    out[1] = (pair_err && *pair_err) ? 1 : 0;
+  }
+}
+
+int decide_launch(ucg_ctx *ctx, int *due, int *checked, long long *dev_out3)
+{
+  if (!ctx || !due || !checked || !dev_out3) return UCG_ERR_INVALID;
+  if (int rc = need_domain(ctx)) return rc;
+  return guarded(ctx, [&]() -> int {
+    Domain &D = *ctx->dom;
+    *checked = 0;
+    if (cluster_forces_rebuild(ctx)) {
+      *due = 1;
+      return UCG_OK;
+    }
+    D.ago++;
+    *due = 0;
+    if (D.ago >= D.delay && D.ago % D.every == 0) {
+      *due = 1;
+      if (D.check == 0) return UCG_OK;
+      const DomainDev dd = make_dev(D);
+      D.blockflags.reserve((size_t) nblk(ctx->nlocal) + 1);
+      mirror_need(ctx, UCG_F_X);
+      if (ctx->nlocal > 0)
+        hipLaunchKernelGGL(k_check_distance, dim3(nblk(ctx->nlocal)), dim3(NB), 0, ctx->stream, dd, ctx->nlocal,
+                           ctx->pos4.get(), D.xhold.get(), D.blockflags.get());
+      const int *perr = (ctx->md_pair && ctx->md_pair->uploaded) ? ctx->md_pair->d_err.get() : nullptr;
+      hipLaunchKernelGGL(k_flags_any64, dim3(1), dim3(1024), 0, ctx->stream, nblk(ctx->nlocal), D.blockflags.get(), perr, dev_out3);
+      UCG_HIP(hipGetLastError());
+      *checked = 1;
+    }
+    return UCG_OK;
+  });
+}
+
 // ucg_decide_local, and -- when the distance check ran -- the pair kernels' sticky error flag in *pair_flag (-1: not read)
 int decide_local_impl(ucg_ctx *ctx, int *due, int *flag, int *pair_flag)
 {

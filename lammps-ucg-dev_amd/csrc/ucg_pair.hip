@@ -62,13 +62,38 @@ __global__ void k_selftest_div(const double b, const double y, const unsigned lo
   if (__builtin_bit_cast(unsigned long long, q1) != __builtin_bit_cast(unsigned long long, q2)) atomicAdd(mismatches, 1ull);
 }
 
+// exactness check of ucg_div_core (ucg_math.h) against the IEEE division on the operand ranges it is used on: denominators
+// in [1.25, 2.75] and [5.25, 6.75], numerators with a random sign, significand and exponent in [-112, 2], and zero
+__global__ void k_selftest_div_core(const unsigned long long seed, const int n, unsigned long long *mismatches)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long) (i + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  unsigned long long w = z * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+  w = (w ^ (w >> 29)) * 0xBF58476D1CE4E5B9ull;
+  w ^= w >> 32;
+  const unsigned long long mant = z & 0xFFFFFFFFFFFFFull;
+  const unsigned long long ex = 1023ull - 112ull + ((z >> 52) % 115ull);
+  const unsigned long long sg = (z >> 63) << 63;
+  double a = __builtin_bit_cast(double, sg | (ex << 52) | mant);
+  if ((w & 0xFFFull) == 0) a = 0.0;
+  const double u = (double) (w >> 11) * 1.1102230246251565e-16;  // [0, 1)
+  const double b = ((w >> 3) & 1ull) ? 1.25 + 1.5 * u : 5.25 + 1.5 * u;
+  const double q1 = a / b;
+  const double q2 = ucg_div_core(a, b);
+  if (__builtin_bit_cast(unsigned long long, q1) != __builtin_bit_cast(unsigned long long, q2)) atomicAdd(mismatches, 1ull);
+}
+
 template <int STYLE, int TS, int SLOTS>
 hipError_t launch_style_ts(const PairDev &P, const AtomsDev &A, const ListDev &L, bool ev, double *evpart,
                            int *errflag, hipStream_t st, int nblocks)
 {
   const size_t tabbytes = P.fast ? ((size_t) (P.tablength * P.fast_stride + 1) / 2) * sizeof(double4)
                                  : (size_t) P.ntab * P.tablength * sizeof(double4);
-  const size_t ownbytes = P.stage_own ? (size_t) (PAIR_BLOCK / SLOTS) * (sizeof(double4) + sizeof(int)) : 0;
+  const size_t ownbytes = P.stage_own ? (size_t) (PAIR_BLOCK / SLOTS) * pair_own_bytes(STYLE) : 0;
   const size_t ldsbytes = (P.tab_in_lds ? tabbytes : (P.fast ? (size_t) P.hot_ent * sizeof(double4) : 0)) + ownbytes;
 #define UCG_LAUNCH(EVF, LDSF, FASTF)                                                                   \
   do {                                                                                                 \
@@ -105,7 +130,7 @@ hipError_t launch_style_bitmap(const PairDev &P, const AtomsDev &A, const ListDe
                                int *errflag, hipStream_t st, int nblocks)
 {
   if (P.tab_in_lds || P.fast || P.gather_slots != 1) return hipErrorInvalidValue;
-  const size_t ldsbytes = P.stage_own ? (size_t) PAIR_BLOCK * (sizeof(double4) + sizeof(int)) : 0;
+  const size_t ldsbytes = P.stage_own ? (size_t) PAIR_BLOCK * pair_own_bytes(STYLE) : 0;
   if (ev) hipLaunchKernelGGL((k_pair_gather<STYLE, 3, true, false, false, 1>), dim3(nblocks), dim3(PAIR_BLOCK), ldsbytes, st, P, A, L, evpart, errflag);
   else hipLaunchKernelGGL((k_pair_gather<STYLE, 3, false, false, false, 1>), dim3(nblocks), dim3(PAIR_BLOCK), ldsbytes, st, P, A, L, evpart, errflag);
   return hipGetLastError();
@@ -181,6 +206,12 @@ hipError_t launch_block_classify(const AtomsDev &A, const ListDev &L, int slots,
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_block_classify, dim3((A.nlocal + 255) / 256), dim3(256), 0, st, A.nlocal, PAIR_BLOCK / slots, L.pitch,
                      L.numneigh, L.neigh, flags);
+  return hipGetLastError();
+}
+
+hipError_t launch_selftest_div_core(unsigned long long seed, int n, unsigned long long *d_mismatches, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_selftest_div_core, dim3((n + 255) / 256), dim3(256), 0, st, seed, n, d_mismatches);
   return hipGetLastError();
 }
 

@@ -11,6 +11,8 @@ namespace ucg {
 namespace {
 
 constexpr int PAIR_BLOCK = 1024;
+// LDS bytes per staged own bead of the gather kernels: {x, y, z, lambda} + meta word (+ ucgp for table_ucg_bethe)
+constexpr size_t pair_own_bytes(int style) { return sizeof(double4) + sizeof(int) + (style == 1 ? sizeof(double) : 0); }
 
 struct Quad {
   double u00, u01, u10, u11;
@@ -256,31 +258,6 @@ __device__ __forceinline__ void eval_quad(TabPtr tab, const double4 *s_par, cons
                            : reinterpret_cast<const double2 *>(tab) + it * fast_stride;
     const int st = hb ? 7 : fast_stride;
     const int o00 = hb ? 0 : 2 * t00, o01 = hb ? 2 : 2 * t01, o10 = hb ? 2 : 2 * t10, o11 = hb ? 4 : 2 * t11;
-#if defined(UCG_VARIANT) && UCG_VARIANT == 3
-    if (TS == 2 && SAME10) {
-      // (experiment) all twelve 16-byte slots of the pair's three splines are requested before any of them is used
-      double2 r[12];
-      const int off[3] = {o00, o01, o11};
-#pragma unroll
-      for (int t = 0; t < 3; t++) {
-        r[4 * t + 0] = rec[off[t]];
-        r[4 * t + 1] = rec[off[t] + 1];
-        r[4 * t + 2] = rec[off[t] + st];
-        r[4 * t + 3] = rec[off[t] + st + 1];
-      }
-      __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
-      double fv[3], ev[3];
-#pragma unroll
-      for (int t = 0; t < 3; t++) {
-        fv[t] = B.a * r[4 * t].y + B.b * r[4 * t + 2].y + (B.a3 * r[4 * t + 1].y + B.b3 * r[4 * t + 3].y) * par.w;
-        ev[t] = B.a * r[4 * t].x + B.b * r[4 * t + 2].x + (B.a3 * r[4 * t + 1].x + B.b3 * r[4 * t + 3].x) * par.w;
-      }
-      q.f00 = fv[0]; q.u00 = ev[0];
-      q.f01 = q.f10 = fv[1]; q.u01 = q.u10 = ev[1];
-      q.f11 = fv[2]; q.u11 = ev[2];
-      return;
-    }
-#endif
     knot_eval_fast<TS>(rec + o00, st, par.w, B, q.f00, q.u00);
     knot_eval_fast<TS>(rec + o01, st, par.w, B, q.f01, q.u01);
     if (SAME10 || t10 == t01) {

@@ -13,7 +13,7 @@ hipError_t launch_hot_ts(const PairDev &P, const AtomsDev &A, const ListDev &L, 
                          hipStream_t st, int nblocks)
 {
   const size_t tabbytes = ((size_t) (P.tablength * P.fast_stride + 1) / 2) * sizeof(double4);
-  const size_t ownbytes = P.stage_own ? (size_t) (PAIR_BLOCK / SLOTS) * (sizeof(double4) + sizeof(int)) : 0;
+  const size_t ownbytes = P.stage_own ? (size_t) (PAIR_BLOCK / SLOTS) * pair_own_bytes(STYLE) : 0;
   const size_t ldsbytes = tabbytes + ownbytes;
 #define UCG_LAUNCH(EVF)                                                                                 \
   do {                                                                                                  \

@@ -30,10 +30,6 @@
 // where the reference's scalar x86-64 code rounds.
 #pragma once
 
-#ifndef UCG_VARIANT
-#define UCG_VARIANT 0
-#endif
-
 #include "ucg_pair_dev.h"
 
 namespace ucg {
@@ -91,12 +87,15 @@ __global__ __launch_bounds__(PAIR_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4
   const int hot_ent = (!LDS_TAB && FAST && TS != 3) ? P.hot_ent : 0;
   double4 *s_ownpos = s_tab + (LDS_TAB ? ntabent : hot_ent);
   int *s_ownmeta = reinterpret_cast<int *>(s_ownpos + PAIR_BLOCK / SLOTS);
+  // table_ucg_bethe: ucgp of the workgroup's own beads as well (8 bytes per bead behind the meta words)
+  double *s_ownucgp = reinterpret_cast<double *>(s_ownmeta + PAIR_BLOCK / SLOTS);
   const int k0 = chunk_id * (PAIR_BLOCK / SLOTS);
   if (stage_own) {
     for (int t = threadIdx.x; t < PAIR_BLOCK / SLOTS; t += blockDim.x) {
       if (k0 + t < A.nlocal) {
         s_ownpos[t] = A.pos4[k0 + t];
         s_ownmeta[t] = A.meta[k0 + t];
+        if (STYLE == 1) s_ownucgp[t] = A.ucgp[k0 + t];
       }
     }
   }
@@ -156,9 +155,14 @@ __global__ __launch_bounds__(PAIR_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4
     // priors of k for the Bethe closure
     double pk_as_i1 = 0.0, pk_as_j1 = 0.0, pk_as_i0 = 0.0, pk_as_j0 = 0.0;
     bool k_first_chempot = false;
+    // first-call rules (:179-205, :227-253) only while the host says a marker may still be around (uniform): afterwards
+    // the per-pair test and the selects behind it are skipped, and a marker met anyway is reported (error bit 16)
+    const bool firstp = STYLE == 1 && P.first_possible != 0;
+    int upm_sign_or = 0;
     if (STYLE == 1) {
       const double upk = A.ucgp[k];
-      const bool first = upk < -0.999;
+      const bool first = firstp && upk < -0.999;
+      if (!firstp) upm_sign_or |= __double2hiint(upk);  // (a set ucgp lies in [1e-6, 1]: any sign bit is a marker)
       if (first && P.prior_flag == 0) {  // CHEMICAL_POTENTIAL
         pk_as_i0 = P.prior_type[tk * 2 + 0];
         pk_as_i1 = P.prior_type[tk * 2 + 1];
@@ -220,37 +224,24 @@ __global__ __launch_bounds__(PAIR_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4
     double4 pm;
     int mm;
     gather_bead_split(A, s_ownpos, s_ownmeta, k0, nown, ent & 0x1FFFFFFF, pm, mm);
+    // table_ucg_bethe: the neighbour's ucgp travels with its record through the software pipeline (read at its use, inside
+    // the cutoff branch, its latency was exposed: 709 -> 684 us at 1 M beads), from the LDS copy for an own bead
+    auto gather_ucgp = [&](const int mi) {
+      const unsigned mlu = (unsigned) (mi - k0);
+      const double *upp = (mlu < nown) ? s_ownucgp + mlu : A.ucgp + mi;
+      asm volatile("" : "+v"(upp));
+      return *upp;
+    };
+    double up_cur = STYLE == 1 ? gather_ucgp(ent & 0x1FFFFFFF) : 0.0;
     rp += rstep;
-#if UCG_VARIANT == 4
-    // (experiment) three-stage pipeline: the gather of entry e+2 is issued while entry e is evaluated
-    int ent_n2 = (slot + 2 * SLOTS < n) ? rp[rstep] : ent_n;
-    double4 pm_n;
-    int mm_n;
-    gather_bead_split(A, s_ownpos, s_ownmeta, k0, nown, ent_n & 0x1FFFFFFF, pm_n, mm_n);
-    rp += rstep;
-#endif
     for (int e = slot; e < n; e += SLOTS) {
       rp += rstep;
-#if UCG_VARIANT == 4
-      const int ent_n3 = (e + 3 * SLOTS < n) ? rp[0] : ent_n2;
-      double4 pm_n2;
-      int mm_n2;
-      gather_bead_split(A, s_ownpos, s_ownmeta, k0, nown, ent_n2 & 0x1FFFFFFF, pm_n2, mm_n2);
-#else
       const int ent_nn = (e + 2 * SLOTS < n) ? rp[0] : ent_n;
       double4 pm_n;
       int mm_n;
-#endif
-#if UCG_VARIANT == 4
-#elif UCG_VARIANT == 2 || UCG_VARIANT == 3
-      // (experiment) the next entry's flat loads are issued only after this entry's knot reads have been issued, so that
-      // the knot reads' waits can count (a flat load in flight forces every LDS wait to lgkmcnt(0))
-      bool gathered = false;
-#else
       gather_bead_split(A, s_ownpos, s_ownmeta, k0, nown, ent_n & 0x1FFFFFFF, pm_n, mm_n);
-#endif
+      const double up_n = STYLE == 1 ? gather_ucgp(ent_n & 0x1FFFFFFF) : 0.0;
 
-      const int m = ent & 0x1FFFFFFF;
       const bool k_is_i = (ent >> 29) & 1;
       double factor_lj = 1.0;
       if (!FAST) {
@@ -278,12 +269,6 @@ __global__ __launch_bounds__(PAIR_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4
                                                   nullptr, false, -1, FAST ? &parF : nullptr);
         else eval_quad<TS, FAST>(FAST ? P.tab_fast : P.tab, s_par, pt, P.tablength, P.tlm1, P.fast_stride, rsq, factor_lj, q, err, rtrack,
                                  hot_ent ? reinterpret_cast<const double2 *>(s_tab) : nullptr, tk == P.hot_type && tm == P.hot_type, P.hot_k0);
-#if UCG_VARIANT == 2 || UCG_VARIANT == 3
-        __builtin_amdgcn_sched_barrier(0);
-        gather_bead_split(A, s_ownpos, s_ownmeta, k0, nown, ent_n & 0x1FFFFFFF, pm_n, mm_n);
-        gathered = true;
-        __builtin_amdgcn_sched_barrier(0);
-#endif
 
         double evdwl = 0.0, fpair;
         if (STYLE == 0 || pseudo_flag == 0) {
@@ -321,12 +306,13 @@ __global__ __launch_bounds__(PAIR_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4
           {
             // the usual case first (every bead has been through fix ucgstate: ucgp is set), the first-call rules
             // (:179-205, :227-253) in ONE rarely taken branch behind it
-            const double upm = A.ucgp[m];
+            const double upm = up_cur;
             pm_as_i1 = lm;
             pm_as_i0 = 1.0 - lm;
             pm_as_j1 = upm;
             pm_as_j0 = 1.0 - upm;
-            if (upm < -0.999) {
+            if (!firstp) upm_sign_or |= __double2hiint(upm);
+            if (firstp && upm < -0.999) {
               if (P.prior_flag == 0) {
                 pm_as_i0 = P.prior_type[tm * 2 + 0];
                 pm_as_i1 = P.prior_type[tm * 2 + 1];
@@ -410,24 +396,13 @@ __global__ __launch_bounds__(PAIR_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4
           ev[6] += 0.5 * (dy * dz * fpair);
         }
       }
-#if UCG_VARIANT == 2 || UCG_VARIANT == 3
-      if (!gathered) gather_bead_split(A, s_ownpos, s_ownmeta, k0, nown, ent_n & 0x1FFFFFFF, pm_n, mm_n);
-#endif
-#if UCG_VARIANT == 4
-      ent = ent_n;
-      ent_n = ent_n2;
-      ent_n2 = ent_n3;
-      pm = pm_n;
-      mm = mm_n;
-      pm_n = pm_n2;
-      mm_n = mm_n2;
-#else
       ent = ent_n;
       ent_n = ent_nn;
       pm = pm_n;
       mm = mm_n;
-#endif
+      up_cur = up_n;
     }
+    if (STYLE == 1 && upm_sign_or < 0) err |= 16;
   }
   if (active) {
     if (SLOTS > 1) {

@@ -222,6 +222,14 @@ def test_exact_division_by_constant(gpu_ctx, kT):
     assert gpu_ctx.selftest_div(kT, 12345, 4_000_000) == 0
 
 
+def test_bare_division_core_equals_the_ieee_division_on_its_operand_ranges(gpu_ctx):
+    """csrc/ucg_math.h: ucg_div_core -- the hardware division's Newton-Raphson core without v_div_scale / v_div_fixup -- is
+    used for the two quotients of exp / expm1's common path, whose operands lie where the scaling is the identity: 8 M random
+    operand pairs of those ranges (and zero numerators), every quotient bit-equal to a / b"""
+    for seed in (1, 987654321):
+        assert gpu_ctx.selftest_div_core(seed, 4_000_000) == 0
+
+
 @pytest.mark.parametrize("style", ["table_ucgld", "table_ucg_bethe"])
 @pytest.mark.parametrize("tabstyle,tablength,T", [("spline", 1024, 0.7), ("linear", 2048, 1.3), ("lookup", 3000, 1.0), ("spline", 512, 0.25),
                                                   ("bitmap", 10, 0.7)])
