@@ -113,7 +113,13 @@ int ucg_selftest_div_core(ucg_ctx *ctx, long long seed, int n, long long *mismat
  *   init_style() + init_one()  UCG/pair_table_ucgld.cpp:867-895
  *   compute()    UCG/pair_table_ucgld.cpp:111-541, UCG/pair_table_ucg_bethe.cpp:88-630,
  *                UCG/pair_table_ucg_bethe_density.cpp:133-758
- * argv arrays are the words after the style name, exactly as LAMMPS passes them. */
+ * argv arrays are the words after the style name, exactly as LAMMPS passes them.
+ * NOT offered on the device: `prior chemical_potential noise L seed` of table_ucg_bethe (UCG/pair_table_ucg_bethe.cpp:187-188,
+ * 235-236, 844-856).  It is parsed (ucg_pair_settings accepts the words) and ucg_pair_init then returns UCG_ERR_UNSUPPORTED
+ * with a message: the reference draws one RanMars number per bead and one per HALF-list entry inside the neighbour sweep of
+ * the first force evaluation, before the cutoff test, so the result is a function of upstream's half-list order (undefined
+ * by the reference) and, across ranks, of which rank's sweep holds a pair -- there is no order-free statement of it to be
+ * bit-exact against.  `prior ucgl` and `prior chemical_potential` (without noise) are offered. */
 
 int ucg_pair_create(ucg_ctx *ctx, int style, ucg_pair **out);
 /* host-only pair: the setup half of the style (settings, coeff, init, single, table

@@ -1731,6 +1731,10 @@ int ucg_ctx_set_option(ucg_ctx *ctx, const char *name, int value)
     ctx->fault_setup = value != 0;
     return UCG_OK;
   }
+  if (std::strcmp(name, "rows_sort_r2") == 0) {
+    ctx->rows_sort_r2 = value != 0;
+    return UCG_OK;
+  }
   if (std::strcmp(name, "rows_untiled") == 0) {
     ctx->rows_untiled = value != 0;
     return UCG_OK;

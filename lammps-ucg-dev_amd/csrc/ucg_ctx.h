@@ -145,6 +145,7 @@ struct ucg_ctx {
   bool fma_contract = false;           // option "fma_contract": gather kernels compiled with FMA contraction (not bit-exact)
   int rng_batch = 10;                  // option "rng_batch": steps of per-bead draws generated per k_ranmars launch (1 = one launch per step)
   bool rows_untiled = false;           // option "rows_untiled": build rows with the one-lane-per-bead kernels
+  bool rows_sort_r2 = false;           // option "rows_sort_r2": EXPERIMENT, rows ordered by build-time r^2 (not the specification's bits)
   bool pair_vrow = false;              // option "pair_vrow" (default off: measured slower than the full-row kernels, DESIGN.md
                                        // 4.1): the gather styles run on virtual rows where they can (ucg_pair_vrow.hip:
                                        // own-block pairs once, fixed sums)

@@ -8,6 +8,6 @@ action () {
     cp $1 ../$1
   fi
 }
-for file in *.cpp *.h; do
+for file in *.cpp *.h; do   # atom_vec_ucg_gpu, pair_table_ucg_gpu, fix_ucg_gpu, verlet_ucg_gpu
   test -f ${file} && action $file
 done

@@ -276,3 +276,48 @@ def test_every_entry_point_uploads_host_edits_before_it_reads_or_overwrites_them
         ctx.close()
     for k in out[0]:
         assert util.bits_equal(out[0][k], out[1][k]), (entry, k)
+
+
+def test_two_runs_of_the_resident_protocol_keep_re_neighbouring(pkg):
+    """the glue's integrator replaced LAMMPS' neigh_modify delay by a sentinel for a resident run and
+    never put it back, so the pair style's next init_style() read the sentinel as the user's delay, handed it to
+    ucg_domain_set, and the device never re-neighboured again in a second `run`.  The glue now restores the settings in
+    post_run() (lammps/fix_ucg_gpu.cpp) and refuses the sentinel (lammps/pair_table_ucg_gpu.cpp).  At the ABI this is the
+    protocol of two `run` commands: [ucg_domain_set(user's every / delay / check) -> Verlet::setup -> hooks] twice -- the
+    second framing must re-neighbour like the first and land on the bits of the resident loop run through the same two
+    framings; with the
+    sentinel as delay (what the bug passed) the second run does not re-neighbour at all."""
+    deck = util.make_deck("spline", 1024)
+    beads = pkg.synth.make_beads(9, seed=31)
+    steps, dt = 40, 0.004
+    # the resident loop through the same two framings (a `run` re-neighbours in its setup, so two runs are not one long run)
+    ctx, gp = _setup(pkg, beads, deck, "table_ucgld", dt, 2, None, None, False)
+    for _ in range(2):
+        ctx.md_setup(steps)
+        ctx.md_run(steps, 0)
+    R = ctx.atoms_download()
+    gp.close()
+    ctx.close()
+    for delay2, expect_rebuilds in ((0, True), (2000000000, False)):
+        ctx, gp = _setup(pkg, beads, deck, "table_ucgld", dt, 2, None, None, False)
+        M = _mirror_arrays(beads.n)
+        ctx.host_bind(M)
+        ctx.md_setup(steps)
+        st1 = ctx.verlet_hooks_run(gp, steps, nve=True)
+        ctx.host_sync(pkg.capi.Context.F_ALL)  # Verlet::cleanup / post_run: LAMMPS' arrays are current between two runs
+        # second `run`: init_style() reads neigh_modify again and hands it to ucg_domain_set
+        ctx.domain_set(beads.boxlo, beads.boxhi, 2.5, 0.3, every=2, delay=delay2, check=1)
+        ctx.md_setup(steps)
+        st2 = ctx.verlet_hooks_run(gp, steps, nve=True)
+        gp.check_errors() if expect_rebuilds else None
+        assert st1["rebuilds"] >= 2
+        if expect_rebuilds:
+            assert st2["rebuilds"] >= 2
+            G = ctx.atoms_download()
+            assert np.array_equal(G["tag"], R["tag"])
+            for k in ("x", "v", "ucgl", "ucgvl"):
+                assert util.bits_equal(G[k], R[k]), k
+        else:
+            assert st2["rebuilds"] == 0  # what the unrestored sentinel did: beads drift inside the cutoff unlisted
+        gp.close()
+        ctx.close()

@@ -496,3 +496,43 @@ def test_rccl_ranks_on_separate_gpus_equal_the_decomposed_oracle_bit_for_bit(pkg
         O, G = w.rank_arrays(r), res[r]
         assert np.array_equal(G["tag1"], O["tag"])
         assert util.bits_equal(G["x1"], O["x"]) and util.bits_equal(G["l1"], O["ucgl"])
+
+
+@pytest.mark.gpu
+def test_fixed_sums_do_not_depend_on_the_decomposition_and_ordered_sums_do(fresh_ctx, pkg, monkeypatch):
+    """What option pair_vrow is FOR.  A bead's force / ucgforce / scores are sums over its
+    neighbours; the default kernels add them in row order -- the canonical order, a function of the bead order and hence of
+    the decomposition -- so the same bead gets different last bits on one rank and on two.  With pair_vrow every term is an
+    integer image (ucg_pair_sum_fixed) and the sums are order-free: the SAME beads on one rank and on two ranks of a
+    2 x 1 x 1 grid have bit-identical sums at setup, compared tag by tag.  (The price: 6 % / 3 % in the kernel)"""
+    deck = util.make_deck("spline", 1024)
+    beads = pkg.synth.make_beads(10, seed=5)
+    out = {}
+    for vrow in (1, 0):
+        monkeypatch.setenv("UCG_TEST_PAIR_VROW", str(vrow))
+        res = _launch("gpu", world=2)
+        tag2 = np.concatenate([r["tag0"] for r in res])
+        o2 = np.argsort(tag2)
+        two = {k: np.concatenate([r[k] for r in res])[o2] for k in ("f0", "uf0", "s0")}
+        ctx = pkg.capi.Context(-1, dt=0.004)
+        try:
+            ctx.set_option("pair_vrow", vrow)
+            ctx.upload_beads(beads)
+            ctx.domain_set(beads.boxlo, beads.boxhi, 2.5, 0.3, every=2, delay=0, check=1)
+            ctx.neigh_rebuild()
+            gp = util.gpu_pair(ctx, "table_ucgld", deck)
+            assert bool(gp.sum_fixed) == bool(vrow)
+            gp.compute(0, 0)
+            gp.check_errors()
+            A = ctx.atoms_download()
+            o1 = np.argsort(A["tag"])
+            one = {"f0": A["f"][o1], "uf0": A["ucgforce"][o1], "s0": A["scores"][o1]}
+            gp.close()
+        finally:
+            ctx.close()
+        assert np.array_equal(np.sort(tag2), A["tag"][o1])
+        out[vrow] = {k: util.bits_equal(one[k], two[k]) for k in one}
+        close = max(np.max(np.abs(one[k] - two[k])) / np.max(np.abs(one[k])) for k in one)
+        assert close < 1e-11  # the same physics either way
+    assert all(out[1].values()), out[1]        # fixed sums: bit for bit the same on 1 and on 2 ranks
+    assert not all(out[0].values()), out[0]    # ordered sums: the canonical order follows the decomposition
