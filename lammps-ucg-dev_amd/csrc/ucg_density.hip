@@ -241,6 +241,14 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass2(const PairDev P, c
       s1 -= mu1 / kT;
     }
 
+    // the shared grid's parameters (FAST) and, for one actual type, the cutoff as scalars instead of LDS reads per pair
+    const bool onetype = P.n_actual == 1;
+    const double cut11 = P.cutsq[na1 + 1];
+    double4 parF = make_double4(0, 0, 0, 0);
+    if (FAST) {
+      const double4 pg = P.tabpar[0];
+      parF = make_double4(uniform_f64(pg.x), uniform_f64(pg.y), uniform_f64(pg.z), uniform_f64(pg.w));
+    }
     // one-deep software pipeline: the next entry's bead is in flight while this one is evaluated
     int ent = n > 0 ? rp[0] : 0, ent_n = n > 1 ? rp[pitch] : ent;
     double4 pm;
@@ -263,10 +271,13 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass2(const PairDev P, c
       const int sm = UCG_META_STATE(mm);
       const double dx = pk.x - pm.x, dy = pk.y - pm.y, dz = pk.z - pm.z;
       const double rsq = dx * dx + dy * dy + dz * dz;
-      if (rsq < s_cutsq[tk * na1 + tm]) {
+      double cutv = cut11;
+      if (!onetype) cutv = s_cutsq[tk * na1 + tm];  // (uniform branch: a deck of several types keeps its per-pair LDS read)
+      if (rsq < cutv) {
         const int *pt = s_pairtab + (tk * na1 + tm) * 4;
         Quad q;
-        if (LDS_TAB) eval_quad<TS, FAST>(s_tab, s_par, pt, P.tablength, P.tlm1, P.fast_stride, rsq, factor_lj, q, err, rtrack);
+        if (LDS_TAB) eval_quad<TS, FAST>(s_tab, s_par, pt, P.tablength, P.tlm1, P.fast_stride, rsq, factor_lj, q, err, rtrack,
+                                         nullptr, false, -1, FAST ? &parF : nullptr);
         else eval_quad<TS, FAST>(FAST ? P.tab_fast : P.tab, s_par, pt, P.tablength, P.tlm1, P.fast_stride, rsq, factor_lj, q, err, rtrack,
                                  hot_ent ? reinterpret_cast<const double2 *>(s_tab) : nullptr, tk == P.hot_type && tm == P.hot_type, P.hot_k0);
         // scores: only the row owner's (:597-603)
