@@ -66,13 +66,32 @@ __device__ __forceinline__ void gather_bead(const AtomsDev &A, const OwnBlock &O
   }
 }
 
+// per-type constants of a deck of several actual types, in LDS: the squared cutoffs [tk][tm] and, per type, {threshold radius,
+// w = 0.1 * radius, 1 / w, flags as a small number: 1 = use_density, 2 = 1 / w qualifies for div_by_const} -- instead of loads through L1 per pair
+constexpr int NA1MAX = UCG_MAX_ACTUAL + 1;
+
+__device__ __forceinline__ void stage_type_pars(const PairDev &P, double *s_cutsq, double4 *s_tp)
+{
+  const int na1 = P.n_actual + 1;
+  for (int t = threadIdx.x; t < na1 * na1; t += blockDim.x) s_cutsq[t] = P.cutsq[t];
+  for (int t = threadIdx.x; t < na1; t += blockDim.x) {
+    const double rth = P.dens_par[t * 2 + 1];
+    const double w = 0.1 * rth;
+    const int bits = (P.dens_flags[t * 2 + 0] == 1 ? 1 : 0) | (recip_ok(w) ? 2 : 0);
+    s_tp[t] = make_double4(rth, w, 1.0 / w, (double) bits);
+  }
+}
+
 __global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass1(const PairDev P, const AtomsDev A, const ListDev Lst,
                                                              double2 *prior, double *partial0)
 {
   __shared__ double4 s_pos[PAIR_BLOCK];
   __shared__ int s_meta[PAIR_BLOCK];
+  __shared__ double s_cutsq[NA1MAX * NA1MAX];
+  __shared__ double4 s_tp[NA1MAX];
   const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
   const int k0 = chunk * PAIR_BLOCK;
+  stage_type_pars(P, s_cutsq, s_tp);
   stage_own_block(A, k0, s_pos, s_meta);
   OwnBlock O{s_pos, s_meta, k0, (unsigned) max(0, min(PAIR_BLOCK, A.nlocal - k0))};
   const int k = k0 + threadIdx.x;
@@ -105,7 +124,9 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass1(const PairDev P, c
       const int tm = UCG_META_TYPE(mm);
       const double dx = pk.x - pm.x, dy = pk.y - pm.y, dz = pk.z - pm.z;
       const double rsq = dx * dx + dy * dy + dz * dz;
-      if (rsq < (onetype ? cut11 : P.cutsq[tk * na1 + tm])) rho += prox_fn_t(ucg_tanh(prox_arg(sqrt(rsq), rth, w, rw, wok)));
+      double cutv = cut11;
+      if (!onetype) cutv = s_cutsq[tk * na1 + tm];  // (uniform branch)
+      if (rsq < cutv) rho += prox_fn_t(ucg_tanh(prox_arg(sqrt(rsq), rth, w, rw, wok)));
       ent_n = ent_nn;
       pm = pm_n;
       mm = mm_n;
@@ -370,8 +391,11 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass3(const PairDev P, c
   __shared__ double4 s_pos[PAIR_BLOCK];
   __shared__ int s_meta[PAIR_BLOCK];
   __shared__ double2 s_cv[PAIR_BLOCK];
+  __shared__ double s_cutsq[NA1MAX * NA1MAX];
+  __shared__ double4 s_tp[NA1MAX];
   const int chunk = xcd_chunk(blockIdx.x, gridDim.x);
   const int k0 = chunk * PAIR_BLOCK;
+  stage_type_pars(P, s_cutsq, s_tp);
   if (k0 + (int) threadIdx.x < A.nlocal) s_cv[threadIdx.x] = cv[k0 + threadIdx.x];
   stage_own_block(A, k0, s_pos, s_meta);
   OwnBlock O{s_pos, s_meta, k0, (unsigned) max(0, min(PAIR_BLOCK, A.nlocal - k0))};
@@ -407,9 +431,17 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass3(const PairDev P, c
       const int tm = UCG_META_TYPE(mm);
       const double dx = pk.x - pm.x, dy = pk.y - pm.y, dz = pk.z - pm.z;
       const double rsq = dx * dx + dy * dy + dz * dz;
-      const bool in_k = dens_k && rsq < (onetype ? cut11 : P.cutsq[tk * na1 + tm]);
-      const bool dens_m = onetype ? dens_k : (P.dens_flags[tm * 2 + 0] == 1);
-      const bool in_m = dens_m && rsq < (onetype ? cut11 : P.cutsq[tm * na1 + tk]);
+      double cut_km = cut11, cut_mk = cut11;
+      bool dens_m = dens_k;
+      double4 tpm = make_double4(rth_k, w_k, rw_k, 0.0);
+      if (!onetype) {  // (uniform branch)
+        cut_km = s_cutsq[tk * na1 + tm];
+        cut_mk = s_cutsq[tm * na1 + tk];
+        tpm = s_tp[tm];
+        dens_m = ((int) tpm.w & 1) != 0;
+      }
+      const bool in_k = dens_k && rsq < cut_km;
+      const bool in_m = dens_m && rsq < cut_mk;
       if (in_k || in_m) {
         const double distance = sqrt(rsq);
         // the four quotients (cv * w) / distance share the divisor: its reciprocal + two FMA residual
@@ -438,13 +470,12 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass3(const PairDev P, c
         }
         if (in_m) {
           double w;
-          if (tm == tk && in_k) {
-            w = w_own;  // same type: same threshold radius, same arithmetic (prox_arg is the IEEE quotient), same value
+          if (tpm.x == rth_k && in_k) {
+            w = w_own;  // same threshold radius: same arithmetic (prox_arg is the IEEE quotient), same value
           } else {
-            const double rth_m = P.dens_par[tm * 2 + 1];
-            const double w_m = 0.1 * rth_m;
-            const double t = ucg_tanh((distance - rth_m) / w_m);
-            w = P.dens_as_shipped ? prox_fn_t(t) : prox_der_t(t, w_m);
+            const bool wok_m = onetype ? wok_k : ((int) tpm.w & 2) != 0;
+            const double t = ucg_tanh(prox_arg(distance, tpm.x, tpm.y, tpm.z, wok_m));
+            w = P.dens_as_shipped ? prox_fn_t(t) : prox_der_t(t, tpm.y);
           }
           const unsigned ml = (unsigned) (m - k0);
           const double2 cvm = ml < O.nown ? s_cv[ml] : cv[m];
