@@ -83,6 +83,9 @@ int ucg_ctx_set_units(ucg_ctx *ctx, double boltz, double ftm2v, double mvv2e, do
  *   "hot_block"     tables too large for the LDS: with several actual types the three tables of the pairs of the most
  *                   populous type with itself, with one type the far end of the r^2 grid, are staged in LDS all the
  *                   same and read there by the lanes they serve (default 1; set before ucg_pair_init)
+ *   "kind_blocks"   table_ucg_bethe_density on several actual types, tables read through L1 / L2: the lanes that do so read
+ *                   a compact block per (row type, neighbour type) kind instead of the full layout (default 1; set
+ *                   before ucg_pair_init)
  *   "post_in_pair"  per-bead hooks in the gather kernel's epilogue (default 1), "md_no_fuse" = 1 runs every hook as
  *                   its own kernel
  *   "rows_untiled"  = 1 builds neighbour rows with the one-lane-per-bead kernels (the fallback of the tiled builder)

@@ -494,6 +494,41 @@ int ucg_pair_init(ucg_pair *p, int ntypes, double T)
         p->host_tab = tab;
         p->host_pairtab = pairtab;
       }
+      // kind blocks (KindsDev; the density style's pass 2): the tables of every (row type, neighbour type) kind as one
+      // compact FAST block for the lanes that read their tables through L1 / L2
+      p->kinds = false;
+      D.kinds = KindsDev{nullptr, nullptr};
+      if (fast && !D.tab_in_lds && !bitmap && M.n_actual > 1 && ctx->kind_blocks && M.style == STYLE_BETHE_DENSITY) {
+        const int na1 = M.n_actual + 1;
+        std::vector<int2> dir((size_t) na1 * na1, make_int2(0, 0));
+        std::vector<double4> blocks;
+        for (int a = 1; a <= M.n_actual; a++)
+          for (int b = 1; b <= M.n_actual; b++) {
+            const int *pt = &pairtab[((size_t) a * na1 + b) * 4];
+            const bool same = pt[1] == pt[2];
+            const int nt = same ? 3 : 4, stride = 2 * nt + 1;
+            const int ids[4] = {pt[0], pt[1], same ? pt[3] : pt[2], pt[3]};
+            const size_t ent4 = ((size_t) tl * stride + 1) / 2;
+            std::vector<double2> blk(ent4 * 2, make_double2(0, 0));
+            for (int k = 0; k < tl; k++)
+              for (int q = 0; q < nt; q++) {
+                const double4 v = tab[(size_t) ids[q] * tl + k];
+                blk[(size_t) k * stride + 2 * q] = make_double2(v.x, v.y);
+                blk[(size_t) k * stride + 2 * q + 1] = make_double2(v.z, v.w);
+              }
+            dir[(size_t) a * na1 + b] = make_int2((int) blocks.size(), nt);
+            const double4 *b4 = reinterpret_cast<const double4 *>(blk.data());
+            blocks.insert(blocks.end(), b4, b4 + ent4);
+          }
+        p->d_kind_tab.reserve(blocks.size() + 1);
+        p->d_kind_dir.reserve(dir.size());
+        h2d(ctx, p->d_kind_tab.get(), blocks.data(), blocks.size());
+        h2d(ctx, p->d_kind_dir.get(), dir.data(), dir.size());
+        sync(ctx);
+        p->kinds = true;
+        D.kinds.kind_tab = p->d_kind_tab.get();
+        D.kinds.kind_dir = p->d_kind_dir.get();
+      }
       if (fast && !D.tab_in_lds && !bitmap && M.n_actual == 1 && ctx->hot_block) {
         // one actual type, tables too long for the LDS: the knots of the far end of the r^2 grid -- as many as fit next
         // to 1024 staged beads -- are kept there (PairDev::hot_k0); the window starts at an even knot so that it is a
@@ -1745,6 +1780,10 @@ int ucg_ctx_set_option(ucg_ctx *ctx, const char *name, int value)
   }
   if (std::strcmp(name, "hot_block") == 0) {
     ctx->hot_block = value != 0;
+    return UCG_OK;
+  }
+  if (std::strcmp(name, "kind_blocks") == 0) {
+    ctx->kind_blocks = value != 0;
     return UCG_OK;
   }
   if (std::strcmp(name, "stage_own") == 0) {

@@ -177,6 +177,7 @@ struct ucg_ctx {
   double skin = 0.0;           // Neighbor::skin as given to ucg_domain_set (0 when the caller builds the lists)
   long long list_gen = 0;      // changes whenever the rows change (device build or upload): what derived lists key on
   bool list_from_builder = false;  // rows made by the device builder (which sets no special-bond bits)
+  bool kind_blocks = true;         // option "kind_blocks": KindsDev
   // shared RanMars jump table
   ucg::DevBuf<unsigned int> rm_jump;
   int rm_chunks = 0;
@@ -253,6 +254,10 @@ struct ucg_pair {
   ucg::DevBuf<double4> d_tab_hot;
   ucg::DevBuf<int> d_typehist;
   long long hot_checked = -1;  // ctx->nrebuild at the last choice
+  // kind blocks (KindsDev): made once at ucg_pair_init
+  bool kinds = false;
+  ucg::DevBuf<double4> d_kind_tab;
+  ucg::DevBuf<int2> d_kind_dir;
   double host_boltz = 1.0;  // used by host-only pairs (no context)
   explicit ucg_pair(int style) : model(style) {}
 };

@@ -175,6 +175,91 @@ __device__ __forceinline__ void closure_probs(const double aij, const double bij
   p01 = pj1 - p11;
 }
 
+// The quad of one entry from a compact block: knot-major records {t00, t01, [t10,] t11} x two 16-byte slots + one padding
+// slot (a kind block, KindsDev, or the LDS hot block); o10 == 2: the mixed-state tables are one table.  The same values
+// as eval_quad's FAST branch.
+template <int TS>
+__device__ __forceinline__ void eval_quad_kind(const double2 *blk, const int stride, const int o10, const int o11,
+                                               const double4 par, const int tlm1, const double rsq, Quad &q, RangeTrack &rt)
+{
+  const int it = grid_locate_track(par, tlm1, rsq, rt);
+  const Basis B = grid_basis<TS>(par, it, rsq);
+  const double2 *rec = blk + it * stride;
+  knot_eval_fast<TS>(rec, stride, par.w, B, q.f00, q.u00);
+  knot_eval_fast<TS>(rec + 2, stride, par.w, B, q.f01, q.u01);
+  if (o10 == 2) {
+    q.f10 = q.f01;
+    q.u10 = q.u01;
+  } else {
+    knot_eval_fast<TS>(rec + o10, stride, par.w, B, q.f10, q.u10);
+  }
+  knot_eval_fast<TS>(rec + o11, stride, par.w, B, q.f11, q.u11);
+}
+
+// what one in-cutoff entry adds to its row owner (:597-676): scores, the closure, the pair force (x 1/2 when the neighbour is
+// owned) and what the neighbour's own visit of the pair sends back, the energy / virial terms, the entropic accumulators
+struct DensAcc {
+  double fx, fy, fz, s0, s1, G0, G1;
+};
+
+template <bool FAST, bool EV>
+__device__ __forceinline__ void density_pair_terms(const Quad &q, const bool mixed_same, const double kT, const double rkT,
+                                                   const int kTp2, const int sm, const double pk1, const double pm1,
+                                                   const bool m_owned, const bool dens_k, const double dx, const double dy,
+                                                   const double dz, DensAcc &a, double (&ev)[8])
+{
+  // scores: only the row owner's (:597-603)
+  if (FAST) {
+    a.s0 -= div_kT(sm ? q.u01 : q.u00, kT, rkT, kTp2);
+    a.s1 -= div_kT(sm ? q.u11 : q.u10, kT, rkT, kTp2);
+  } else {
+    a.s0 -= (sm ? q.u01 : q.u00) / kT;
+    a.s1 -= (sm ? q.u11 : q.u10) / kT;
+  }
+  double p00, p01, p10, p11;
+  double aij, bij;
+  closure_coupling<FAST>(kT, rkT, kTp2, q.u00, q.u01, q.u10, q.u11, aij, bij);
+  closure_probs(aij, bij, pk1, pm1, p00, p01, p10, p11);
+  double evdwl = p00 * q.u00 + p01 * q.u01 + p10 * q.u10 + p11 * q.u11;
+  double fpair = p00 * q.f00 + p01 * q.f01 + p10 * q.f10 + p11 * q.f11;
+  if (m_owned) {
+    evdwl = evdwl * 0.5;
+    fpair = fpair * 0.5;
+  }
+  a.fx += dx * fpair;
+  a.fy += dy * fpair;
+  a.fz += dz * fpair;
+  if (m_owned) {
+    // what m's own visit of this pair sends to k: roles swapped (its u[a][b] is our u[b][a])
+    // With ONE table for both mixed states (pairs of one actual type: eval_quad copies u10 = u01) its J is our J
+    // bit for bit -- (u11 + u00 - x) - x either way -- and so are b = exp(-J / kT) and a: only a pair of two types
+    // evaluates the exponential a second time.
+    double t00, t01, t10, t11, am = aij, bm = bij;
+    if (!mixed_same) closure_coupling<FAST>(kT, rkT, kTp2, q.u00, q.u10, q.u01, q.u11, am, bm);
+    closure_probs(am, bm, pm1, pk1, t00, t01, t10, t11);
+    double fpj = t00 * q.f00 + t01 * q.f10 + t10 * q.f01 + t11 * q.f11;
+    fpj = fpj * 0.5;
+    const double djx = -dx, djy = -dy, djz = -dz;
+    a.fx -= djx * fpj;
+    a.fy -= djy * fpj;
+    a.fz -= djz * fpj;
+  }
+  if (EV) {
+    const double sc = m_owned ? 1.0 : 0.5;
+    ev[0] += m_owned ? evdwl : 0.5 * evdwl;
+    ev[1] += sc * (dx * dx * fpair);
+    ev[2] += sc * (dy * dy * fpair);
+    ev[3] += sc * (dz * dz * fpair);
+    ev[4] += sc * (dx * dy * fpair);
+    ev[5] += sc * (dx * dz * fpair);
+    ev[6] += sc * (dy * dz * fpair);
+  }
+  if (dens_k) {
+    a.G0 -= (q.u10 - q.u00 + kT * ucg_log_nb(p10 / p00));
+    a.G1 -= (q.u11 - q.u01 + kT * ucg_log_nb(p11 / p01));
+  }
+}
+
 template <int TS, bool EV, bool LDS_TAB, bool FAST>
 __global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass2(const PairDev P, const AtomsDev A, const ListDev Lst,
                                                              const double2 *prior, const double *partial0, double2 *cv,
@@ -185,10 +270,15 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass2(const PairDev P, c
   __shared__ double4 s_par[UCG_MAX_TABLES];
   __shared__ int s_pairtab[(UCG_MAX_ACTUAL + 1) * (UCG_MAX_ACTUAL + 1) * 4];
   __shared__ double s_cutsq[(UCG_MAX_ACTUAL + 1) * (UCG_MAX_ACTUAL + 1)];
+  __shared__ int2 s_kdir[(UCG_MAX_ACTUAL + 1) * (UCG_MAX_ACTUAL + 1)];
+  // tables through L1 / L2: the cold lanes read the compact block of their pair's kind (KindsDev::kind_tab) when there is one
+  const bool kcold = !LDS_TAB && FAST && TS != 3 && P.kinds.kind_tab != nullptr;
 
   const int ntabent = FAST ? (P.tablength * P.fast_stride + 1) / 2 : P.ntab * P.tablength;
   {
     const int na1sq = (P.n_actual + 1) * (P.n_actual + 1);
+    if (kcold)
+      for (int t = threadIdx.x; t < na1sq; t += blockDim.x) s_kdir[t] = P.kinds.kind_dir[t];
     for (int t = threadIdx.x; t < P.ntab; t += blockDim.x) s_par[t] = P.tabpar[t];
     for (int t = threadIdx.x; t < na1sq * 4; t += blockDim.x) s_pairtab[t] = P.pairtab[t];
     for (int t = threadIdx.x; t < na1sq; t += blockDim.x) s_cutsq[t] = P.cutsq[t];
@@ -247,19 +337,19 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass2(const PairDev P, c
     };
     const bool dens_k = P.dens_flags[tk * 2 + 0] == 1;
 
-    double fx = 0.0, fy = 0.0, fz = 0.0, s0 = 0.0, s1 = 0.0, G0 = 0.0, G1 = 0.0;
+    DensAcc acc{0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     if (dens_k) {
       // one-body terms (:302-314); jnum is the whole row, skin included, as shipped
       const double jnum_f = 1. - n;
       const double mu0 = P.mu[tk * 2 + 0], mu1 = P.mu[tk * 2 + 1];
       if (P.dens_flags[tk * 2 + 1]) {
-        G0 -= kT * ucg_log_nb(prk.x) * jnum_f;
-        G1 -= kT * ucg_log_nb(prk.y) * jnum_f;
+        acc.G0 -= kT * ucg_log_nb(prk.x) * jnum_f;
+        acc.G1 -= kT * ucg_log_nb(prk.y) * jnum_f;
       }
-      G0 -= mu0;
-      s0 -= mu0 / kT;
-      G1 -= mu1;
-      s1 -= mu1 / kT;
+      acc.G0 -= mu0;
+      acc.s0 -= mu0 / kT;
+      acc.G1 -= mu1;
+      acc.s1 -= mu1 / kT;
     }
 
     // the shared grid's parameters (FAST) and, for one actual type, the cutoff as scalars instead of LDS reads per pair
@@ -299,72 +389,30 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass2(const PairDev P, c
         Quad q;
         if (LDS_TAB) eval_quad<TS, FAST>(s_tab, s_par, pt, P.tablength, P.tlm1, P.fast_stride, rsq, factor_lj, q, err, rtrack,
                                          nullptr, false, -1, FAST ? &parF : nullptr);
-        else eval_quad<TS, FAST>(FAST ? P.tab_fast : P.tab, s_par, pt, P.tablength, P.tlm1, P.fast_stride, rsq, factor_lj, q, err, rtrack,
+        else if (kcold) {
+          // per lane: the LDS hot block (stride 7, {t00, t01 = t10, t11}) or the kind's block in global memory
+          const bool hot = hot_ent && tk == P.hot_type && tm == P.hot_type;
+          const int2 kd = s_kdir[tk * na1 + tm];
+          const int stride = hot ? 7 : 2 * kd.y + 1;
+          const double2 *base = hot ? reinterpret_cast<const double2 *>(s_tab)
+                                    : reinterpret_cast<const double2 *>(P.kinds.kind_tab) + 2 * (size_t) kd.x;
+          const bool three = hot || kd.y == 3;
+          eval_quad_kind<TS>(base, stride, three ? 2 : 4, three ? 4 : 6, parF, P.tlm1, rsq, q, rtrack);
+        } else eval_quad<TS, FAST>(FAST ? P.tab_fast : P.tab, s_par, pt, P.tablength, P.tlm1, P.fast_stride, rsq, factor_lj, q, err, rtrack,
                                  hot_ent ? reinterpret_cast<const double2 *>(s_tab) : nullptr, tk == P.hot_type && tm == P.hot_type, P.hot_k0);
-        // scores: only the row owner's (:597-603)
-        if (FAST) {
-          s0 -= div_kT(sm ? q.u01 : q.u00, kT, rkT, kTp2);
-          s1 -= div_kT(sm ? q.u11 : q.u10, kT, rkT, kTp2);
-        } else {
-          s0 -= (sm ? q.u01 : q.u00) / kT;
-          s1 -= (sm ? q.u11 : q.u10) / kT;
-        }
-        const double pm1 = pm.w;
-        double p00, p01, p10, p11;
-        double aij, bij;
-        closure_coupling<FAST>(kT, rkT, kTp2, q.u00, q.u01, q.u10, q.u11, aij, bij);
-        closure_probs(aij, bij, prk.y, pm1, p00, p01, p10, p11);
-        double evdwl = p00 * q.u00 + p01 * q.u01 + p10 * q.u10 + p11 * q.u11;
-        double fpair = p00 * q.f00 + p01 * q.f01 + p10 * q.f10 + p11 * q.f11;
-        const bool m_owned = m < nlocal;
-        if (m_owned) {
-          evdwl = evdwl * 0.5;
-          fpair = fpair * 0.5;
-        }
-        fx += dx * fpair;
-        fy += dy * fpair;
-        fz += dz * fpair;
-        if (m_owned) {
-          // what m's own visit of this pair sends to k: roles swapped (its u[a][b] is our u[b][a])
-          // With ONE table for both mixed states (pairs of one actual type: eval_quad copies u10 = u01) its J is our J
-          // bit for bit -- (u11 + u00 - x) - x either way -- and so are b = exp(-J / kT) and a: only a pair of two types
-          // evaluates the exponential a second time.
-          double t00, t01, t10, t11, am = aij, bm = bij;
-          if (pt[1] != pt[2]) closure_coupling<FAST>(kT, rkT, kTp2, q.u00, q.u10, q.u01, q.u11, am, bm);
-          closure_probs(am, bm, pm1, prk.y, t00, t01, t10, t11);
-          double fpj = t00 * q.f00 + t01 * q.f10 + t10 * q.f01 + t11 * q.f11;
-          fpj = fpj * 0.5;
-          const double djx = pm.x - pk.x, djy = pm.y - pk.y, djz = pm.z - pk.z;
-          fx -= djx * fpj;
-          fy -= djy * fpj;
-          fz -= djz * fpj;
-        }
-        if (EV) {
-          const double sc = m_owned ? 1.0 : 0.5;
-          ev[0] += m_owned ? evdwl : 0.5 * evdwl;
-          ev[1] += sc * (dx * dx * fpair);
-          ev[2] += sc * (dy * dy * fpair);
-          ev[3] += sc * (dz * dz * fpair);
-          ev[4] += sc * (dx * dy * fpair);
-          ev[5] += sc * (dx * dz * fpair);
-          ev[6] += sc * (dy * dz * fpair);
-        }
-        if (dens_k) {
-          G0 -= (q.u10 - q.u00 + kT * ucg_log_nb(p10 / p00));
-          G1 -= (q.u11 - q.u01 + kT * ucg_log_nb(p11 / p01));
-        }
+        density_pair_terms<FAST, EV>(q, pt[1] == pt[2], kT, rkT, kTp2, sm, prk.y, pm.w, m < nlocal, dens_k, dx, dy, dz, acc, ev);
       }
       ent = ent_n;
       ent_n = ent_nn;
       pm = pm_n;
       mm = mm_n;
     }
-    A.frc4[k] = make_double4(fx, fy, fz, 0.0);
-    A.scores[k] = make_double2(s0, s1);
+    A.frc4[k] = make_double4(acc.fx, acc.fy, acc.fz, 0.0);
+    A.scores[k] = make_double2(acc.s0, acc.s1);
     A.num_ucgstates[k] = 2;
     // posterior (:678-689), index fixed to the bead's type (App. B #8)
     {
-      const double e0 = ucg_exp_nb(s0), e1 = ucg_exp_nb(s1);
+      const double e0 = ucg_exp_nb(acc.s0), e1 = ucg_exp_nb(acc.s1);
       double den = 0.0;
       den += e0;
       den += e1;
@@ -373,8 +421,8 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass2(const PairDev P, c
     double2 c = make_double2(0.0, 0.0);
     if (dens_k) {
       const double pa = partial0[k];
-      c.x = G0 * pa;
-      c.y = G1 * (-pa);
+      c.x = acc.G0 * pa;
+      c.y = acc.G1 * (-pa);
     }
     cv[k] = c;
   }

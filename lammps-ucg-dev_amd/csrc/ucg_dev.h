@@ -21,6 +21,15 @@
 
 namespace ucg {
 
+// Kind blocks (table_ucg_bethe_density's pass 2 on a deck of several actual types whose tables are read through L1 / L2):
+// the tables of every (row type a, neighbour type b) kind as one compact FAST block -- per knot {t00, t01, [t10,] t11} x two
+// 16-byte slots + one padding slot -- so that what a cold lane reads for one pair lies in two or three cache lines instead
+// of being spread over the full layout's 2 * ntab + 1 slots per knot.  Same values either way.
+struct KindsDev {
+  const double4 *kind_tab;  // all blocks; nullptr: none
+  const int2 *kind_dir;     // [(n_actual+1)^2] {offset into kind_tab in double4 units, tables of the kind: 3 or 4}
+};
+
 struct PairDev {
   int style, tabstyle, tablength, tlm1;
   int n_actual;        // actual types are 1..n_actual
@@ -63,6 +72,7 @@ struct PairDev {
   int hot_k0;
   const double4 *tab_hot;
   double special_lj[4];
+  KindsDev kinds;
 };
 
 struct AtomsDev {

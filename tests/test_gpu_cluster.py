@@ -50,12 +50,13 @@ def test_several_actual_types_forces_bitwise(fresh_ctx, pkg, orc, style, n_actua
     assert np.max(np.abs(sim0.arrays()["f"] - G["f"])) < 1e-10
 
 
-@pytest.mark.parametrize("hot_block", [1, 0])
+@pytest.mark.parametrize("hot_block,kind_blocks", [(1, 1), (0, 1), (1, 0), (0, 0)])
 @pytest.mark.parametrize("tablength", [256, 1024])
-def test_several_actual_types_density_style_bitwise(fresh_ctx, pkg, orc, tablength, hot_block):
+def test_several_actual_types_density_style_bitwise(fresh_ctx, pkg, orc, tablength, hot_block, kind_blocks):
     """table_ucg_bethe_density on two actual types (BASELINE config 5's deck): 256 knots fit the LDS; with 1024 knots
-    the ten tables are read through L2 and -- option hot_block, the default -- the block of the most populous type is
-    staged in LDS next to that path.  Bit for bit the oracle's canonical order either way."""
+    the ten tables are read through L2 -- from a compact block per (row type, neighbour type) kind (option kind_blocks,
+    the default) or from the full layout -- and (option hot_block, the default) the block of the most populous type is
+    staged in LDS next to that path.  Bit for bit the oracle's canonical order every way."""
     deck = util.make_multi_deck(2, "spline", tablength, density=(11.3, 1.5), extra11=0.05, n_file=2000)
     beads = util.multi_type_beads(pkg, 9, 2, seed=23)
     op = util.oracle_pair_multi("table_ucg_bethe_density", deck)
@@ -63,6 +64,7 @@ def test_several_actual_types_density_style_bitwise(fresh_ctx, pkg, orc, tableng
     sim.rebuild()
     ctx = fresh_ctx
     ctx.set_option("hot_block", hot_block)
+    ctx.set_option("kind_blocks", kind_blocks)
     util.upload_from_oracle(ctx, sim, beads)
     gp = util.gpu_pair_multi(ctx, "table_ucg_bethe_density", deck)
     eng, vir = gp.compute(1, 1)
