@@ -107,6 +107,10 @@ int ucg_selftest_div(ucg_ctx *ctx, double b, long long seed, int n, long long *m
  * identity (csrc/ucg_math.h: ucg_div_core): n random numerators (exponents -112 ... 2, and zeros) over denominators in
  * [1.25, 2.75] and [5.25, 6.75]; counts the quotients that differ from a / b (must be 0) */
 int ucg_selftest_div_core(ucg_ctx *ctx, long long seed, int n, long long *mismatches);
+/* ... and for the bare square-root iteration of the Bethe closure (csrc/ucg_math.h: ucg_sqrt_core), used for arguments in
+ * [2^-700, 2^700): n random arguments of that range, one in eight a perfect square or its neighbour in the last place;
+ * counts the roots that differ from sqrt(x) (must be 0) */
+int ucg_selftest_sqrt_core(ucg_ctx *ctx, long long seed, int n, long long *mismatches);
 
 /* --------------------------------------------------------------- pair styles
  * replaces PairTable_UCGLD / PairTable_UCG_Bethe / PairTable_UCG_Bethe_Density

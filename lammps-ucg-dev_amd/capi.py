@@ -60,7 +60,7 @@ SYMBOLS = [
     "ucg_profile_enable", "ucg_profile_read",
     "ucg_comm_attach", "ucg_comm_rccl_unique_id", "ucg_comm_attach_rccl", "ucg_comm_detach", "ucg_comm_info",
     "ucg_comm_allreduce_f64", "ucg_pair_density_aux_download", "ucg_pair_density_aux_upload",
-    "ucg_device_count", "ucg_selftest_div_core", "ucg_comm_attach_host", "ucg_comm_transport", "ucg_fix_langevin_reset_target", "ucg_fix_langevin_reset_dt",
+    "ucg_device_count", "ucg_selftest_div_core", "ucg_selftest_sqrt_core", "ucg_comm_attach_host", "ucg_comm_transport", "ucg_fix_langevin_reset_target", "ucg_fix_langevin_reset_dt",
     "ucg_fix_langevin_set_bias", "ucg_md_run_until", "ucg_md_set_window", "ucg_atoms_download_mask",
     "ucg_ghosts_upload_images", "ucg_host_bind", "ucg_host_modified", "ucg_host_sync", "ucg_host_status", "ucg_verlet_hooks_run",
 ]
@@ -230,6 +230,7 @@ def lib():
     L.ucg_verlet_hooks_run.argtypes = [vp, vp, C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_ll_p]
     L.ucg_device_count.argtypes = []
     L.ucg_selftest_div_core.argtypes = [vp, C.c_longlong, C.c_int, c_ll_p]
+    L.ucg_selftest_sqrt_core.argtypes = [vp, C.c_longlong, C.c_int, c_ll_p]
     L.ucg_comm_attach_host.argtypes = [vp, C.POINTER(CommOps)]
     L.ucg_comm_transport.argtypes = [vp, c_int_p]
     L.ucg_fix_langevin_reset_target.argtypes = [vp, C.c_double]
@@ -304,6 +305,11 @@ class Context:
     def selftest_div_core(self, seed, n):
         bad = C.c_longlong(0)
         self.chk(self.L.ucg_selftest_div_core(self.h, int(seed), int(n), C.byref(bad)))
+        return bad.value
+
+    def selftest_sqrt_core(self, seed, n):
+        bad = C.c_longlong(0)
+        self.chk(self.L.ucg_selftest_sqrt_core(self.h, int(seed), int(n), C.byref(bad)))
         return bad.value
 
     def selftest_stream(self, nbytes, wide, repeats=1):

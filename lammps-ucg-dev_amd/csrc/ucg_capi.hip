@@ -1716,6 +1716,22 @@ int ucg_selftest_div_core(ucg_ctx *ctx, long long seed, int n, long long *mismat
   });
 }
 
+int ucg_selftest_sqrt_core(ucg_ctx *ctx, long long seed, int n, long long *mismatches)
+{
+  if (!ctx || !mismatches || n < 0) return UCG_ERR_INVALID;
+  return guarded(ctx, [&]() -> int {
+    DevBuf<unsigned long long> d;
+    d.reserve(2);
+    UCG_HIP(hipMemsetAsync(d.get(), 0, sizeof(unsigned long long), ctx->stream));
+    UCG_HIP(launch_selftest_sqrt_core((unsigned long long) seed, n, d.get(), ctx->stream));
+    unsigned long long h = 0;
+    d2h(ctx, &h, d.get(), 1);
+    sync(ctx);
+    *mismatches = (long long) h;
+    return UCG_OK;
+  });
+}
+
 int ucg_selftest_stream(ucg_ctx *ctx, long long nbytes, int wide, int repeats)
 {
   if (!ctx || nbytes < 16 || repeats < 1) return UCG_ERR_INVALID;

@@ -35,6 +35,7 @@ hipError_t launch_pair_vrow(const PairDev &P, const AtomsDev &A, const ListDev &
 
 hipError_t launch_selftest_div(double b, unsigned long long seed, int n, unsigned long long *d_mismatches, hipStream_t st);
 hipError_t launch_selftest_div_core(unsigned long long seed, int n, unsigned long long *d_mismatches, hipStream_t st);
+hipError_t launch_selftest_sqrt_core(unsigned long long seed, int n, unsigned long long *d_mismatches, hipStream_t st);
 
 // ---- ucg_density.hip
 hipError_t launch_density(const PairDev &P, const AtomsDev &A, const ListDev &L, const int *ghost_src, bool ev,

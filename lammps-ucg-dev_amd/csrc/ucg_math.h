@@ -201,6 +201,29 @@ UCG_HD double ucg_div_core(double a, double b)
 UCG_HD double ucg_div_core(double a, double b) { return a / b; }
 #endif
 
+/* sqrt(x) for x the caller knows to be a normal number >= 2^-767 (finite): on gfx950 `sqrt(x)` is v_rsq_f64 + the coupled
+ * Goldschmidt / Newton iteration below, wrapped in an operand scaling (compare, select, two v_ldexp_f64) for x < 2^-767 and a
+ * class test with two selects for 0 / inf / NaN; for x in the range above the wrapping is the identity, so the bare core
+ * returns the same bits -- the correctly rounded root -- with eleven instructions less.  On the host it IS sqrt(x).
+ * ucg_selftest_sqrt_core compares the two on the device. */
+#if defined(__HIP_DEVICE_COMPILE__)
+UCG_HD double ucg_sqrt_core(double x)
+{
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y;
+  double h = y * 0.5;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  double d = __builtin_fma(-g, g, x);
+  h = __builtin_fma(h, r, h);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, x);
+  return __builtin_fma(d, h, g);
+}
+#else
+UCG_HD double ucg_sqrt_core(double x) { return sqrt(x); }
+#endif
+
 /* exp(x) and expm1(x) of the SAME argument (the Bethe closure needs both, UCG/pair_table_ucg_bethe.cpp:550-551), with
  * one shared argument reduction and almost no control flow -- on a GPU the two functions' many early exits and
  * k-dependent formulas make a wavefront run every path one of its 64 lanes takes.  Every result is bit for bit that of

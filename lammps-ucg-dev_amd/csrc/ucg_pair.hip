@@ -87,6 +87,31 @@ __global__ void k_selftest_div_core(const unsigned long long seed, const int n, 
   if (__builtin_bit_cast(unsigned long long, q1) != __builtin_bit_cast(unsigned long long, q2)) atomicAdd(mismatches, 1ull);
 }
 
+// exactness check of ucg_sqrt_core (ucg_math.h) against sqrt on the range it is used on: random significands, exponents
+// -700 ... 699 (and the perfect squares and their neighbours in the last place, where the rounding is decided by one bit)
+__global__ void k_selftest_sqrt_core(const unsigned long long seed, const int n, unsigned long long *mismatches)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long) (i + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  const unsigned long long mant = z & 0xFFFFFFFFFFFFFull;
+  const unsigned long long ex = 1023ull - 700ull + ((z >> 52) % 1400ull);
+  double x = __builtin_bit_cast(double, (ex << 52) | mant);
+  if ((i & 7) == 7) {
+    // a square of a 26-bit significand (exactly representable), or its neighbour one unit in the last place up / down
+    const double m = (double) ((z >> 8) & 0x3FFFFFFull) + 1.0;
+    const double sq = m * m;
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, sq) + (unsigned long long) ((long long) ((z >> 40) % 3ull) - 1ll);
+    x = __builtin_bit_cast(double, b);
+  }
+  const double q1 = sqrt(x);
+  const double q2 = ucg_sqrt_core(x);
+  if (__builtin_bit_cast(unsigned long long, q1) != __builtin_bit_cast(unsigned long long, q2)) atomicAdd(mismatches, 1ull);
+}
+
 template <int STYLE, int TS, int SLOTS>
 hipError_t launch_style_ts(const PairDev &P, const AtomsDev &A, const ListDev &L, bool ev, double *evpart,
                            int *errflag, hipStream_t st, int nblocks)
@@ -206,6 +231,12 @@ hipError_t launch_block_classify(const AtomsDev &A, const ListDev &L, int slots,
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k_block_classify, dim3((A.nlocal + 255) / 256), dim3(256), 0, st, A.nlocal, PAIR_BLOCK / slots, L.pitch,
                      L.numneigh, L.neigh, flags);
+  return hipGetLastError();
+}
+
+hipError_t launch_selftest_sqrt_core(unsigned long long seed, int n, unsigned long long *d_mismatches, hipStream_t st)
+{
+  hipLaunchKernelGGL(k_selftest_sqrt_core, dim3((n + 255) / 256), dim3(256), 0, st, seed, n, d_mismatches);
   return hipGetLastError();
 }
 

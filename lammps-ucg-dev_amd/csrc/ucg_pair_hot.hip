@@ -20,7 +20,7 @@ hipError_t launch_hot_ts(const PairDev &P, const AtomsDev &A, const ListDev &L, 
     auto kern = k_pair_gather<STYLE, TS, EVF, true, true, SLOTS>;                                       \
     const bool p2 = P.kT_pow2 != 0;                                                                     \
     if constexpr (STYLE == 1) {                                                                         \
-      if (P.onetype_same10)                                                                             \
+      if (P.onetype_same10 && !P.first_possible) /* (the variants without the first-call rules) */      \
         kern = P.pseudo_flag ? (p2 ? k_pair_gather<STYLE, TS, EVF, true, true, SLOTS, true, 1, 1>       \
                                    : k_pair_gather<STYLE, TS, EVF, true, true, SLOTS, true, 1>)         \
                              : (p2 ? k_pair_gather<STYLE, TS, EVF, true, true, SLOTS, true, 0, 1>       \

@@ -157,7 +157,9 @@ __global__ __launch_bounds__(PAIR_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4
     bool k_first_chempot = false;
     // first-call rules (:179-205, :227-253) only while the host says a marker may still be around (uniform): afterwards
     // the per-pair test and the selects behind it are skipped, and a marker met anyway is reported (error bit 16)
-    const bool firstp = STYLE == 1 && P.first_possible != 0;
+    // (the tuned Bethe variants -- ONETYPE with the score mode fixed -- are launched only while the flag is down: compiled out)
+    constexpr bool STEADY = STYLE == 1 && ONETYPE && SCE >= 0;
+    const bool firstp = STYLE == 1 && !STEADY && P.first_possible != 0;
     int upm_sign_or = 0;
     if (STYLE == 1) {
       const double upk = A.ucgp[k];
@@ -344,7 +346,11 @@ __global__ __launch_bounds__(PAIR_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4
           if (P.method_flag == 1) {
             // the closure's two quotient forms (:566-575) share the square root and ONE division: numerator and
             // denominator are selected, not the branch (same operations on the selected operands: same bits)
-            const double sD = sqrt(Dij);
+            // the root: the bare iteration where the hardware form's operand scaling and special cases are the identity
+            // (ucg_sqrt_core) -- chosen per wavefront, so that a wavefront runs one of the two sequences
+            double sD;
+            if (__builtin_amdgcn_ballot_w64(!(Dij >= 0x1p-700 && Dij < 0x1p+700)) != 0ull) sD = sqrt(Dij);
+            else sD = ucg_sqrt_core(Dij);
             const bool neg = Qij < 0.0;
             const double num = neg ? (Qij - sD) : (2. * bij * pi1 * pj1);
             const double den = neg ? (2. * aij) : (Qij + sD);

@@ -230,6 +230,15 @@ def test_bare_division_core_equals_the_ieee_division_on_its_operand_ranges(gpu_c
         assert gpu_ctx.selftest_div_core(seed, 4_000_000) == 0
 
 
+def test_sqrt_core_matches_the_hardware_square_root(gpu_ctx):
+    """ucg_sqrt_core (csrc/ucg_math.h): the rsq-seeded iteration of the hardware square root without its operand scaling and
+    special-case selects, used by the Bethe closure for arguments in [2^-700, 2^700) where those are the identity: 8 M
+    random arguments of that range, one in eight a perfect square or its neighbour in the last place, every root bit-equal
+    to sqrt(x)"""
+    for seed in (3, 123456789):
+        assert gpu_ctx.selftest_sqrt_core(seed, 4_000_000) == 0
+
+
 @pytest.mark.parametrize("style", ["table_ucgld", "table_ucg_bethe"])
 @pytest.mark.parametrize("tabstyle,tablength,T", [("spline", 1024, 0.7), ("linear", 2048, 1.3), ("lookup", 3000, 1.0), ("spline", 512, 0.25),
                                                   ("bitmap", 10, 0.7)])
