@@ -142,6 +142,8 @@ def lib():
     L.orc_sim_molecule.restype = c_int_p
     L.orc_sim_cluster_switch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_char_p, C.c_char_p]
     L.orc_sim_cluster_switch.restype = C.c_char_p
+    L.orc_world_cluster_switch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_char_p, C.c_char_p]
+    L.orc_world_cluster_switch.restype = C.c_char_p
     L.orc_sim_cs.argtypes = [C.c_void_p]
     L.orc_sim_cs.restype = C.c_void_p
     L.orc_cs_maxmol.argtypes = [C.c_void_p]
@@ -541,6 +543,22 @@ class World:
             return s.arrays(ghosts=ghosts)
         finally:
             s.h = None  # borrowed: the world owns the rank simulations
+
+    def cluster_switch(self, mol_seed, mol_offset, cutoff, seed, switch_freq, rate_file, contact_file):
+        """fix cluster_switch on every rank (before setup): survey reduced over the ranks, one RanPark stream per rank"""
+        err = self.L.orc_world_cluster_switch(self.h, int(mol_seed), int(mol_offset), float(cutoff), int(seed),
+                                              int(switch_freq), rate_file.encode(), contact_file.encode())
+        if err:
+            raise ValueError(err.decode())
+
+    def rank_cs(self, r):
+        """(arrays, stats) of rank r's fix cluster_switch, as Sim.cs_arrays / Sim.cs_stats"""
+        s = Sim.__new__(Sim)
+        s.L, s.h, s.lang, s.pair = self.L, self.L.orc_world_rank(self.h, r), None, None
+        try:
+            return s.cs_arrays(), s.cs_stats()
+        finally:
+            s.h = None
 
     def rank_info(self, r):
         s = Sim.__new__(Sim)

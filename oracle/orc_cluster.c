@@ -216,30 +216,38 @@ static int partner(const orc_cluster_switch *cs, int m)
 
 #define IMIN(a, b) ((a) < (b) ? (a) : (b))
 
-/* check_cluster (:551-719): minimum-label propagation over contacts, sequential sweeps */
-int orc_cs_check_cluster(orc_cluster_switch *cs, const orc_atoms *a, const int *molecule, const orc_list *list)
+/* check_cluster (:551-719) in three phases, so that a decomposed run (orc_world) can reduce the labels over the ranks
+   between sweeps the way the reference does (MPI_Allreduce MAX of the starting labels :587, MIN between sweeps :683):
+     orc_cs_presence     the molecules with an in-group atom among these owned atoms (what :573-580 label)
+     orc_cs_labels_init  the starting labels from the molecules present ANYWHERE (:573-599)
+     orc_cs_sweep_local  sequential sweeps over these rows until one changes nothing; returns "changed at all"
+     orc_cs_finalize     restrict / state flags of the seed's cluster (:675-690) */
+void orc_cs_presence(const orc_cluster_switch *cs, const orc_atoms *a, const int *molecule, int *present)
+{
+  for (int i = 0; i < a->nlocal; i++)
+    if ((a->mask[i] & cs->groupbit) && molecule[i] >= 0 && molecule[i] <= cs->maxmol) present[molecule[i]] = 1;
+}
+
+void orc_cs_labels_init(orc_cluster_switch *cs, const int *present, int *lab)
 {
   const int maxmol = cs->maxmol;
-  int *lab = (int *) malloc(sizeof(int) * ((size_t) maxmol + 1));
   for (int i = 0; i <= maxmol; i++) lab[i] = -1;
   lab[cs->mol_seed] = cs->mol_seed;
   lab[cs->mol_seed - cs->mol_offset] = cs->mol_seed;
-  for (int ii = 0; ii < list->inum; ii++) {
-    const int i = list->ilist[ii];
-    if (a->mask[i] & cs->groupbit) lab[molecule[i]] = molecule[i];
-  }
-  for (int ii = 0; ii < list->inum; ii++) {
-    const int i = list->ilist[ii];
-    if (a->mask[i] & cs->groupbit) {
-      const int molID = molecule[i];
-      if (switchable(cs, molID)) {
-        const int p = molID - cs->mol_offset;
-        if (p >= 0 && p <= maxmol) lab[p] = molID;
-      }
+  for (int m = 0; m <= maxmol; m++)
+    if (present[m]) lab[m] = m;
+  for (int m = 0; m <= maxmol; m++)
+    if (present[m] && switchable(cs, m)) {
+      const int p = m - cs->mol_offset;
+      if (p >= 0 && p <= maxmol) lab[p] = m;
     }
-  }
-  const int nct = cs->nContactTypes, napc = cs->nAtomsPerContact;
   cs->sweeps = 0;
+}
+
+int orc_cs_sweep_local(orc_cluster_switch *cs, const orc_atoms *a, const int *molecule, const orc_list *list, int *lab)
+{
+  const int nct = cs->nContactTypes, napc = cs->nAtomsPerContact;
+  int any = 0;
   for (;;) {
     int done = 1;
     cs->sweeps++;
@@ -273,10 +281,15 @@ int orc_cs_check_cluster(orc_cluster_switch *cs, const orc_atoms *a, const int *
       }
     }
     if (done) break;
+    any = 1;
   }
-  memcpy(cs->mol_cluster, lab, sizeof(int) * ((size_t) maxmol + 1));
-  free(lab);
+  return any;
+}
 
+void orc_cs_finalize(orc_cluster_switch *cs, const int *lab)
+{
+  const int maxmol = cs->maxmol;
+  memcpy(cs->mol_cluster, lab, sizeof(int) * ((size_t) maxmol + 1));
   /* :675-690 */
   const int clusterID = cs->mol_cluster[cs->mol_seed];
   cs->nCluster = 0.0;
@@ -292,6 +305,23 @@ int orc_cs_check_cluster(orc_cluster_switch *cs, const orc_atoms *a, const int *
       if (cs->mol_cluster[i] == clusterID) cs->nCluster += 1.0;
     }
   }
+}
+
+/* single rank: every reduction is the identity */
+int orc_cs_check_cluster(orc_cluster_switch *cs, const orc_atoms *a, const int *molecule, const orc_list *list)
+{
+  const int maxmol = cs->maxmol;
+  int *lab = (int *) malloc(sizeof(int) * ((size_t) maxmol + 1));
+  int *present = (int *) calloc((size_t) maxmol + 1, sizeof(int));
+  for (int ii = 0; ii < list->inum; ii++) {
+    const int i = list->ilist[ii];
+    if ((a->mask[i] & cs->groupbit) && molecule[i] >= 0 && molecule[i] <= maxmol) present[molecule[i]] = 1;
+  }
+  orc_cs_labels_init(cs, present, lab);
+  orc_cs_sweep_local(cs, a, molecule, list, lab);
+  orc_cs_finalize(cs, lab);
+  free(present);
+  free(lab);
   return 0;
 }
 
@@ -320,8 +350,11 @@ static int confirm_molecule(orc_cluster_switch *cs, const orc_atoms *a, const in
   return 0;
 }
 
-/* attempt_switch (:721-802), switch_flag (:860-885), gather_statistics (:899-935) */
-int orc_cs_attempt_switch(orc_cluster_switch *cs, orc_atoms *a, const int *molecule)
+/* attempt_switch (:721-802), switch_flag (:860-885), gather_statistics (:899-935), in two phases: attempt_local decides the
+   molecules THESE owned atoms make this rank the decision maker of (confirm_molecule's majority rule over its atoms, one
+   RanPark draw each, ascending molecule id) and leaves the decisions in mol_accept; a decomposed run takes the maximum over
+   the ranks (:793) before attempt_apply flips the types of the owned atoms and the molecules' states */
+void orc_cs_attempt_local(orc_cluster_switch *cs, const orc_atoms *a, const int *molecule)
 {
   const int maxmol = cs->maxmol;
   char *present = (char *) calloc((size_t) maxmol + 1, 1);
@@ -342,7 +375,11 @@ int orc_cs_attempt_switch(orc_cluster_switch *cs, orc_atoms *a, const int *molec
   }
   free(ord);
   free(present);
+}
 
+int orc_cs_attempt_apply(orc_cluster_switch *cs, orc_atoms *a)
+{
+  const int maxmol = cs->maxmol;
   /* gather_statistics, before the states flip */
   for (int i = 0; i <= maxmol; i++) {
     if (cs->mol_restrict[i] != 1) continue;
@@ -373,6 +410,37 @@ int orc_cs_attempt_switch(orc_cluster_switch *cs, orc_atoms *a, const int *molec
     else if (cs->mol_state[i] == 1) cs->mol_state[i] = 0;
   }
   return 0;
+}
+
+int orc_cs_attempt_switch(orc_cluster_switch *cs, orc_atoms *a, const int *molecule)
+{
+  orc_cs_attempt_local(cs, a, molecule);
+  return orc_cs_attempt_apply(cs, a);
+}
+
+/* a second object with the same parameters, survey and molecule arrays and its own random streams in the same state: what
+   every rank of a decomposed run holds after the constructor's reductions (:114-116, :158-159; RanPark(lmp, seed) on every
+   rank alike, :56-57) */
+orc_cluster_switch *orc_cs_clone(const orc_cluster_switch *cs)
+{
+  orc_cluster_switch *c = (orc_cluster_switch *) malloc(sizeof(orc_cluster_switch));
+  memcpy(c, cs, sizeof(orc_cluster_switch));
+  const size_t nm = (size_t) cs->maxmol + 1;
+#define ORC_DUP(field, count)                                        \
+  do {                                                               \
+    c->field = (int *) malloc(sizeof(int) * (size_t) ((count) > 0 ? (count) : 1)); \
+    memcpy(c->field, cs->field, sizeof(int) * (size_t) (count));     \
+  } while (0)
+  ORC_DUP(typesON, cs->nSwitchTypes);
+  ORC_DUP(typesOFF, cs->nSwitchTypes);
+  ORC_DUP(contactMap, cs->nContactTypes * cs->nAtomsPerContact * 2);
+  ORC_DUP(mol_restrict, nm);
+  ORC_DUP(mol_state, nm);
+  ORC_DUP(mol_accept, nm);
+  ORC_DUP(mol_cluster, nm);
+  ORC_DUP(mol_atoms, nm * (size_t) cs->nSwitchPerMol);
+#undef ORC_DUP
+  return c;
 }
 
 /* compute_vector (:887-897): attempts, successes, attempts ON/OFF, successes ON/OFF, cluster size */

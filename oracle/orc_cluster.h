@@ -33,6 +33,15 @@ const char *orc_cs_error(const orc_cluster_switch *cs);
 /* molecule[] covers owned + ghost atoms; list is a full list */
 int orc_cs_check_cluster(orc_cluster_switch *cs, const orc_atoms *a, const int *molecule, const orc_list *list);
 int orc_cs_attempt_switch(orc_cluster_switch *cs, orc_atoms *a, const int *molecule);
+/* the phases of the two, for decomposed runs (orc_world reduces over the ranks in between, as the reference's MPI_Allreduce
+ * calls do): presence / labels_init / sweep_local / finalize, attempt_local / attempt_apply; and a per-rank copy */
+void orc_cs_presence(const orc_cluster_switch *cs, const orc_atoms *a, const int *molecule, int *present);
+void orc_cs_labels_init(orc_cluster_switch *cs, const int *present, int *lab);
+int orc_cs_sweep_local(orc_cluster_switch *cs, const orc_atoms *a, const int *molecule, const orc_list *list, int *lab);
+void orc_cs_finalize(orc_cluster_switch *cs, const int *lab);
+void orc_cs_attempt_local(orc_cluster_switch *cs, const orc_atoms *a, const int *molecule);
+int orc_cs_attempt_apply(orc_cluster_switch *cs, orc_atoms *a);
+orc_cluster_switch *orc_cs_clone(const orc_cluster_switch *cs);
 void orc_cs_stats(const orc_cluster_switch *cs, double *out7);
 int orc_cs_maxmol(const orc_cluster_switch *cs);
 /* which: 0 mol_cluster, 1 mol_state, 2 mol_restrict, 3 mol_accept; maxmol+1 entries */

@@ -757,6 +757,7 @@ static void world_forward(orc_world *w)
       a->ucgstate[n + g] = o->ucgstate[src];
       a->ucgl[n + g] = o->ucgl[src];
       a->ucgp[n + g] = o->ucgp[src];
+      a->type[n + g] = o->type[src]; /* (fix cluster_switch's forward_comm: the ghosts' new types) */
     }
   }
 }
@@ -976,6 +977,104 @@ int orc_world_setup(orc_world *w, long long nsteps_planned)
   return rc;
 }
 
+/* fix cluster_switch on a decomposed run.  The constructor's survey is reduced over the ranks (UCG/fix_cluster_switch.cpp:
+   114-116 maxmol MAX and the two counts SUM, :158-159 mol_restrict / mol_state MAX), so it is made here from all beads at
+   once -- the same numbers whatever the split, for molecules that are wholly ON or OFF -- and every rank gets a copy with
+   its own RanPark streams, seeded alike (:56-57). */
+const char *orc_world_cluster_switch(orc_world *w, int mol_seed, int mol_offset, double cutoff, int seed, int switchFreq,
+                                     const char *rateFile, const char *contactFile)
+{
+  int total = 0;
+  for (int me = 0; me < w->nranks; me++) total += w->r[me]->a.nlocal;
+  orc_atoms u;
+  memset(&u, 0, sizeof u);
+  u.nlocal = total;
+  u.tag = (int *) malloc(sizeof(int) * (size_t) (total + 1));
+  u.type = (int *) malloc(sizeof(int) * (size_t) (total + 1));
+  u.mask = (int *) malloc(sizeof(int) * (size_t) (total + 1));
+  int *mol = (int *) malloc(sizeof(int) * (size_t) (total + 1));
+  int k = 0;
+  for (int me = 0; me < w->nranks; me++) {
+    const orc_sim *s = w->r[me];
+    for (int i = 0; i < s->a.nlocal; i++, k++) {
+      u.tag[k] = s->a.tag[i];
+      u.type[k] = s->a.type[i];
+      u.mask[k] = s->a.mask[i];
+      mol[k] = s->molecule[i];
+    }
+  }
+  orc_sim *s0 = w->r[0];
+  orc_cluster_switch *cs = orc_cs_create(&u, mol, s0->ntypes, s0->groupbit, mol_seed, mol_offset, cutoff, seed, switchFreq,
+                                         rateFile, contactFile, s0->ntimestep);
+  free(u.tag);
+  free(u.type);
+  free(u.mask);
+  free(mol);
+  for (int me = 0; me < w->nranks; me++) {
+    orc_cs_destroy(w->r[me]->cs);
+    w->r[me]->cs = NULL;
+  }
+  if (orc_cs_error(cs)) {
+    w->r[0]->cs = cs; /* keeps the message alive */
+    return orc_cs_error(cs);
+  }
+  w->r[0]->cs = cs;
+  for (int me = 1; me < w->nranks; me++) w->r[me]->cs = orc_cs_clone(cs);
+  return NULL;
+}
+
+/* check_cluster + attempt_switch on fresh lists (:452-469), the ranks in lockstep with the reference's reductions in between:
+   labels MIN between the ranks' sweeps until no rank changes any (:664-683), mol_accept MAX (:793); then the ghosts take
+   their owners' new types (comm->forward_comm(this)) */
+static int world_cluster_step(orc_world *w)
+{
+  orc_cluster_switch *c0 = w->r[0]->cs;
+  const int nm = c0->maxmol + 1;
+  int *present = (int *) calloc((size_t) nm, sizeof(int));
+  for (int me = 0; me < w->nranks; me++) orc_cs_presence(w->r[me]->cs, &w->r[me]->a, w->r[me]->molecule, present);
+  int **lab = (int **) malloc(sizeof(int *) * (size_t) w->nranks);
+  for (int me = 0; me < w->nranks; me++) {
+    lab[me] = (int *) malloc(sizeof(int) * (size_t) nm);
+    orc_cs_labels_init(w->r[me]->cs, present, lab[me]);
+  }
+  for (;;) {
+    int any = 0;
+    for (int me = 0; me < w->nranks; me++) {
+      orc_sim *s = w->r[me];
+      if (orc_cs_sweep_local(s->cs, &s->a, s->molecule, &s->full, lab[me])) any = 1;
+    }
+    for (int i = 0; i < nm; i++) {
+      int m = lab[0][i];
+      for (int me = 1; me < w->nranks; me++)
+        if (lab[me][i] < m) m = lab[me][i];
+      for (int me = 0; me < w->nranks; me++) lab[me][i] = m;
+    }
+    if (!any) break;
+  }
+  int rc = 0;
+  for (int me = 0; me < w->nranks; me++) {
+    orc_sim *s = w->r[me];
+    orc_cs_finalize(s->cs, lab[me]);
+    orc_cs_attempt_local(s->cs, &s->a, s->molecule);
+    free(lab[me]);
+  }
+  free(lab);
+  free(present);
+  for (int i = 0; i < nm; i++) {
+    int m = -1;
+    for (int me = 0; me < w->nranks; me++)
+      if (w->r[me]->cs->mol_accept[i] > m) m = w->r[me]->cs->mol_accept[i];
+    for (int me = 0; me < w->nranks; me++) w->r[me]->cs->mol_accept[i] = m;
+  }
+  for (int me = 0; me < w->nranks; me++) {
+    orc_sim *s = w->r[me];
+    if (orc_cs_attempt_apply(s->cs, &s->a)) rc = 1;
+    s->cs->next_reneighbor = s->ntimestep + s->cs->switchFreq;
+  }
+  world_forward(w);
+  return rc;
+}
+
 int orc_world_run(orc_world *w, long long nsteps, int thermo_every)
 {
   int rc_any = 0;
@@ -990,8 +1089,12 @@ int orc_world_run(orc_world *w, long long nsteps, int thermo_every)
       else if (s->have_nve >= 2) orc_fix_nve_wall_initial(&s->a, s->dt, s->ftm2v, s->groupbit);
       if (decide(s)) flag = 1; /* Neighbor::decide(): MPI_Allreduce of the ranks' flags */
     }
-    if (flag) world_rebuild(w);
-    else world_forward(w);
+    if (flag) {
+      world_rebuild(w);
+      orc_sim *s0 = w->r[0];
+      if (s0->cs && s0->cs->next_reneighbor == s0->ntimestep && s0->cs->switchFreq != 0 && world_cluster_step(w)) return 1;
+    } else
+      world_forward(w);
     const int rc = world_forces(w, ev);
     if (rc) rc_any = rc;
     for (int me = 0; me < w->nranks; me++) {

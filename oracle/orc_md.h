@@ -88,7 +88,8 @@ int orc_sim_compute_forces(orc_sim *s, int eflag, int vflag);
  *   the random streams are per rank: RanMars(seed + me) drawn in the rank's local bead order
  *   (UCG/fix_ucgld_langevin.cpp:85, 280; UCG/fix_ucgstate.cpp:62, 117).
  * All three pair styles in canonical order (the density style's passes run in lockstep over the ranks, its ghosts' priors
- * and CV forces coming from their owner ranks); fix cluster_switch's reductions are not covered here. */
+ * and CV forces coming from their owner ranks); fix cluster_switch with the reference's reductions between the ranks' label
+ * sweeps and decisions, one RanPark stream per rank (orc_world_cluster_switch). */
 typedef struct orc_world orc_world;
 orc_world *orc_world_create(const int *grid3, int natoms, const double *boxlo, const double *boxhi, double cutforce,
                             double skin, int ntypes);
@@ -103,6 +104,10 @@ void orc_world_set_run_params(orc_world *w, double dt, int every, int delay, int
 void orc_world_attach(orc_world *w, orc_pair *pair, int have_langevin, double t_start, double t_stop, double t_period,
                       int lang_seed, int have_nve, double wall_barrier, int have_ucgstate, int ld_flag, int mc_flag,
                       int mc_seed, double mc_rate);
+/* fix cluster_switch on every rank (survey reduced over the ranks, RanPark streams per rank, seeded alike); call it before
+ * orc_world_setup.  Returns NULL or the error message */
+const char *orc_world_cluster_switch(orc_world *w, int mol_seed, int mol_offset, double cutoff, int seed, int switchFreq,
+                                     const char *rateFile, const char *contactFile);
 int orc_world_setup(orc_world *w, long long nsteps_planned);
 int orc_world_run(orc_world *w, long long nsteps, int thermo_every);
 /* totals over the ranks of the last energy evaluation: eng_vdwl, virial[6] */

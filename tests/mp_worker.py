@@ -200,18 +200,22 @@ def main():
         sim.cluster_switch(mol_seed, 0, 1.15, 4711, 5, rates, contacts)
         e0, v0 = sim.setup(30, ntypes=mb.ntypes)
         A0 = ctx.atoms_download()
-        changed = ctx.cs_sweep(1)
-        while True:
-            ctx.cs_set_array(5, tr.allreduce_array(ctx.cs_array(5), "min"))
-            if not tr.allreduce_max(changed):
-                break
-            changed = ctx.cs_sweep(0)
-        ctx.cs_finalize()
-        labels = ctx.cs_array(0)
+        labels = None
+        if os.environ.get("UCG_TEST_CS_LABELS_AT_SETUP", "1") == "1":
+            # check_cluster by hand on the setup's configuration (it also sets the seed cluster's restrict / state flags, as
+            # every check_cluster does; the comparison of whole trajectories with orc_world runs without it)
+            changed = ctx.cs_sweep(1)
+            while True:
+                ctx.cs_set_array(5, tr.allreduce_array(ctx.cs_array(5), "min"))
+                if not tr.allreduce_max(changed):
+                    break
+                changed = ctx.cs_sweep(0)
+            ctx.cs_finalize()
+            labels = ctx.cs_array(0)
         sim.run(30)
         pair.check_errors()
         A = ctx.atoms_download()
-        result = dict(tag0=A0["tag"], f0=A0["f"], p0=A0["ucgp"], st0=A0["ucgstate"], e0=e0,
+        result = dict(tag0=A0["tag"], f0=A0["f"], p0=A0["ucgp"], st0=A0["ucgstate"], e0=e0, cs_state=ctx.cs_array(1),
                       labels=labels, tag=A["tag"], type=A["type"], st=A["ucgstate"], x=A["x"], mol=ctx.download_molecule(),
                       vec=ctx.fix_cluster_switch_vector(), mol_seed=mol_seed, nrebuild=sim.nrebuild, nghost=A["nghost"])
         pair.close()

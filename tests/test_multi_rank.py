@@ -416,6 +416,39 @@ def test_world2_config5_density_with_cluster_switch_vs_oracle(pkg, orc):
 
 
 @pytest.mark.gpu
+def test_world2_config5_with_cluster_switch_equals_the_decomposed_oracle_bit_for_bit(pkg, orc, monkeypatch):
+    """the same run against orc_world, which states what a decomposed run of fix cluster_switch does (labels reduced between
+    the ranks' sweeps, each rank deciding the molecules it holds from its own RanPark stream in ascending molecule id, the
+    decisions reduced, the ghosts taking the new types): forces and posteriors at setup, then after 30 steps with switching
+    every 5 -- six rounds of decisions feeding back into the dynamics -- types, states, positions and the fix's statistics of
+    every rank, bit for bit"""
+    monkeypatch.setenv("UCG_TEST_CS_LABELS_AT_SETUP", "0")
+    res = _launch("gpu_config5")
+    deck = util.make_multi_deck(2, "spline", 1024, density=(11.3, 1.5), extra11=0.05)
+    mb = util.multi_type_beads(pkg, 10, 2, seed=5, molecule_size=2)
+    rates, contacts = pkg.synth.write_cluster_switch_files(deck.workdir, 0.35, [1], [2], [(1, 1)])
+    op = util.oracle_pair_multi("table_ucg_bethe_density", deck)
+    w = orc.World(mb, pkg.multi.choose_procgrid(2))
+    w.set_run_params(dt=0.002, every=5, delay=0, check=1)
+    w.attach(op, langevin=None, nve=True, ucgstate=("mc", 9127, 0.3))
+    w.cluster_switch(res[0]["mol_seed"], 0, 1.15, 4711, 5, rates, contacts)
+    assert w.setup(30) == 0
+    for r in range(2):
+        O, G = w.rank_arrays(r), res[r]
+        assert np.array_equal(G["tag0"], O["tag"])
+        assert util.bits_equal(G["f0"], O["f"]) and util.bits_equal(G["p0"], O["ucgp"])
+    assert w.run(30, 0) == 0
+    for r in range(2):
+        O, G = w.rank_arrays(r), res[r]
+        assert np.array_equal(G["tag"], O["tag"]) and np.array_equal(G["type"], O["type"]) and np.array_equal(G["st"], O["ucgstate"])
+        assert util.bits_equal(G["x"], O["x"])
+        ca, cst = w.rank_cs(r)
+        assert np.array_equal(G["vec"], cst) and np.array_equal(G["cs_state"], ca["mol_state"])
+        assert G["nrebuild"] == w.rank_info(r)["nrebuild"]
+    assert res[0]["vec"][1] > 0 and (np.concatenate([r["type"] for r in res]) != mb.type[np.concatenate([r["tag"] for r in res]) - 1]).sum() > 0
+
+
+@pytest.mark.gpu
 def test_bench_starts_its_own_ranks_and_prints_one_json_line():
     """`python bench.py --gpus 2 ...` exactly as the driver calls it (no torchrun, no rendezvous environment): the parent
     starts the ranks before touching the GPU, relays rank 0's single JSON line, and fails when a rank fails.  On this

@@ -547,3 +547,62 @@ def test_state_trajectories_do_not_depend_on_the_libm_in_use(orc, pkg, style, ex
     for k in ("x", "v", "ucgl", "ucgp"):
         assert np.abs(out[0][k] - out[1][k]).max() <= 1e-9, k
     assert not util.bits_equal(out[0]["ucgp"], out[1]["ucgp"])  # the two libraries do differ in the last place
+
+
+def test_world_cluster_switch_one_rank_equals_the_single_rank_run_and_two_ranks_agree_on_the_labels(orc, pkg):
+    """fix cluster_switch in orc_world (the reference's reductions between the ranks' label sweeps and decisions, one RanPark
+    stream per rank): on ONE rank it is the single-rank run bit for bit -- types, states, positions, statistics after
+    several switching steps; on two ranks the cluster labels (which do not depend on the decomposition) are the single-rank
+    ones at every switching step, molecules stay wholly ON or OFF, and the decisions -- drawn from per-rank streams in the
+    rank's molecule order -- differ from the single-rank ones"""
+    deck = util.make_multi_deck(2, "spline", 128)
+    beads = util.multi_type_beads(pkg, 8, 2, seed=17, molecule_size=2)
+    rates, contacts = pkg.synth.write_cluster_switch_files(deck.workdir, 0.4, [1], [2], [(1, 1)])
+    mol_seed = int(beads.molecule[np.flatnonzero(beads.type == 1)[0]])
+    steps, freq = 24, 4
+
+    def single():
+        op = util.oracle_pair_multi("table_ucg_bethe", deck)
+        s = util.oracle_sim(beads, op, mode=1, dt=0.004, nve=True, ucgstate="plain", every=2)
+        s.cluster_switch(mol_seed, 0, 1.2, 99, freq, rates, contacts)
+        assert s.setup(steps) == 0
+        return s
+
+    def world(grid):
+        op = util.oracle_pair_multi("table_ucg_bethe", deck)
+        w = orc.World(beads, grid)
+        w.set_run_params(dt=0.004, every=2, delay=0, check=1)
+        w.attach(op, langevin=None, nve=True, ucgstate="plain")
+        w.cluster_switch(mol_seed, 0, 1.2, 99, freq, rates, contacts)
+        assert w.setup(steps) == 0
+        return w
+
+    s, w1 = single(), world([1, 1, 1])
+    assert s.run(steps, 0) == 0 and w1.run(steps, 0) == 0
+    O, W = s.arrays(), w1.rank_arrays(0)
+    assert np.array_equal(O["tag"], W["tag"]) and np.array_equal(O["type"], W["type"])
+    for k in ("x", "v", "ucgl", "f", "ucgp"):
+        assert util.bits_equal(O[k], W[k]), k
+    ca, cst = w1.rank_cs(0)
+    for k, v in s.cs_arrays().items():
+        assert np.array_equal(v, ca[k]), k
+    assert np.array_equal(s.cs_stats(), cst) and cst[1] > 0
+
+    # two ranks, switching step by switching step (positions diverge from the single-rank run after the first decisions)
+    s, w2 = single(), world([2, 1, 1])
+    assert s.run(freq, 0) == 0 and w2.run(freq, 0) == 0  # the first switching step: same positions, same contacts
+    lab = s.cs_arrays()["mol_cluster"]
+    for r in range(2):
+        assert np.array_equal(w2.rank_cs(r)[0]["mol_cluster"], lab)
+    assert np.array_equal(w2.rank_cs(0)[1], w2.rank_cs(1)[1])  # the statistics are global
+    assert w2.run(steps - freq, 0) == 0
+    tag = np.concatenate([w2.rank_arrays(r)["tag"] for r in range(2)])
+    typ = np.concatenate([w2.rank_arrays(r)["type"] for r in range(2)])
+    assert sorted(tag.tolist()) == list(range(1, beads.n + 1))
+    t = np.empty(beads.n, dtype=np.int64)
+    t[tag - 1] = typ
+    assert np.array_equal(t[0::2], t[1::2])  # molecules of two beads: wholly ON or OFF
+    assert (t != beads.type).sum() > 0
+    ts = np.empty(beads.n, dtype=np.int64)
+    ts[O["tag"] - 1] = O["type"]
+    assert (t != ts).sum() > 0  # per-rank streams: other decisions than the single-rank run's
