@@ -50,7 +50,7 @@ struct Domain {
   DevBuf<char> cub_tmp;
   DevBuf<int> scratch;                 // discovery-order rows before the class partition
   DevBuf<unsigned long long> rowstat;  // [0] max row length, [1] total entries
-  int row_capacity = 0, skin_capacity = 0;
+  int row_capacity = 0;
   // second scratch set of the one-launch permutation of all per-bead arrays (k_permute_all)
   DevBuf<double4> tmp4b;
   DevBuf<int> tmpi2, tmpi3, tmpi4, tmpi5;
@@ -452,10 +452,15 @@ __global__ __launch_bounds__(NB) void k_rows_partition(int nlocal, const int *ro
 // bins.  Beads are sorted by (Morton code of bin, tag), so a brick's beads are one contiguous
 // range; every candidate they can see lies in the 8x8x8 bins around the brick.  Those candidates
 // (position, index, tag: 32 B) are staged in LDS once, bin by bin (owned, then ghosts), and each
-// lane then walks its bead's stencil in the specified (dz, dy, dx) order over LDS -- twice: pass A
-// counts the four distance classes, pass B writes the entries straight to their class-partitioned
-// slots.  Same rows, bit for bit, as k_rows_discover + k_rows_partition (kept as the fallback for
-// stencils wider than 2 bins and for bricks whose candidates exceed the staging capacity).
+// lane then walks its bead's stencil in the specified (dz, dy, dx) order over LDS, appending the
+// kept entries -- tagged with their distance class -- to the bead's column of a scratch buffer
+// through one running pointer, and finally copies the column into the row class by class (eight
+// loads in flight).  Round 4: the walk used to send class 0 straight to the row and the skin
+// classes to a side buffer, with two counters, two capacities and a 64-bit slot address per kept
+// entry; one pointer and a byte-packed class count cost half the instructions in the block every
+// candidate runs through (1200 -> ~1010 us per re-neighbouring at 1 M beads).  Same rows, bit for
+// bit, as k_rows_discover + k_rows_partition (kept as the fallback for stencils wider than 2 bins
+// and for bricks whose candidates exceed the staging capacity).
 constexpr int TILE_B = 192;      // lanes per brick (mean ~145 beads at rho* = 0.8)
 constexpr int TILE_BX = 4;       // brick = 4 x 4 x 4 bins = the low 6 bits of the Morton code (8 x 4 x 4 with
                                  // 320 lanes measured slower: one workgroup per CU instead of three)
@@ -473,18 +478,22 @@ struct __attribute__((aligned(16))) TileCand {
 // One bead's walk over the staged candidates.  For a fixed (dz, dy) the stencil's bins are
 // consecutive in x, and so are their staged candidates: 25 contiguous LDS ranges per bead instead
 // of 125 bins.  Rows of bins (and their outermost bins in x) that lie farther than cutneigh from
-// the bead are skipped; candidates are fetched four at a time and committed in order: class 0
-// (inside the force cutoff) straight to the front of the bead's row, the skin classes -- tagged
-// in bits 30-31 -- to a side buffer from which the caller appends them class by class.
-__device__ __forceinline__ void tile_walk(const DomainDev &D, const double3 &binsize, const int k, const double4 &pk,
-                                          const int tk, const int bx, const int by, const int bz, const int r0x,
-                                          const int r0y, const int r0z, const int *s_start, const TileCand *s_cand,
-                                          int &c0, int &ns, int *neigh, int *skin, const int pitch,
-                                          const int cap, const int capskin)
+// the bead are skipped; candidates are fetched four at a time and the kept ones -- tagged with their
+// build-time distance class in bits 30-31 -- are appended in discovery order to the bead's column of
+// a scratch buffer through ONE running pointer (an entry costs a store and a pointer step; the
+// class-partitioned row is made from the column afterwards, k_rows_tile).  Returns the number of
+// kept entries, which may exceed `cap`: the entries beyond it are counted, not stored.
+__device__ __forceinline__ int tile_walk(const DomainDev &D, const double3 &binsize, const int k, const double4 &pk,
+                                         const int tk, const int bx, const int by, const int bz, const int r0x,
+                                         const int r0y, const int r0z, const int *s_start, const TileCand *s_cand,
+                                         int *scratch, const int pitch, const int cap, unsigned &classcount)
 {
+  unsigned cc = 0;  // entries per class, one byte each (a row that long does not fit anyway)
   const double prune = D.cutneighsq * (1.0 + 1.0e-9) + 1.0e-12;
-  c0 = 0;
-  ns = 0;
+  const size_t step = (size_t) pitch * sizeof(int);
+  char *const base = reinterpret_cast<char *>(scratch + k);
+  char *const pend = base + (size_t) cap * step;
+  char *p = base;
   const int xlo_bin = max(bx - D.sten[0], 0), xhi_bin = min(bx + D.sten[0], D.nbin[0] - 1);
   for (int dz = -D.sten[2]; dz <= D.sten[2]; dz++) {
     const int cz = bz + dz;
@@ -524,28 +533,26 @@ __device__ __forceinline__ void tile_walk(const DomainDev &D, const double3 &bin
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-          // branch-free bookkeeping (plain integer adds and selects: keeps the counters in registers); the
-          // skin classes are only tagged here and counted when the side buffer is read back
           const bool ok = (j + u < j1) && (pm[u].idx != k) && (rsq[u] < D.cutneighsq);
-          const int in0 = rsq[u] < D.cls_sq[0], in1 = rsq[u] < D.cls_sq[1], in2 = rsq[u] < D.cls_sq[2];
-          const int cls = 3 - in0 - in1 - in2;
-          const int orient = (tk <= pm[u].tag) ? 1 : 0;
-          const int ent = pm[u].idx | (orient << UCG_ORIENT_BIT);
-          // one store: class 0 to the row, the skin classes (tagged) to the side buffer
-          int *dst = in0 ? neigh + ((size_t) c0 * pitch + k) : skin + ((size_t) ns * pitch + k);
-          const bool room = in0 ? (c0 < cap) : (ns < capskin);
-          if (ok && room) *dst = in0 ? ent : (ent | (cls << 30));
-          c0 += (ok && in0) ? 1 : 0;
-          ns += (ok && !in0) ? 1 : 0;
+          if (ok) {
+            const int in0 = rsq[u] < D.cls_sq[0], in1 = rsq[u] < D.cls_sq[1], in2 = rsq[u] < D.cls_sq[2];
+            const int cls = 3 - in0 - in1 - in2;
+            const int orient = (tk <= pm[u].tag) ? 1 : 0;
+            if (p < pend) *reinterpret_cast<int *>(p) = pm[u].idx | (orient << UCG_ORIENT_BIT) | (cls << 30);
+            p += step;
+            cc += 1u << (cls << 3);
+          }
         }
       }
     }
   }
+  classcount = cc;
+  return (int) ((size_t) (p - base) / step);
 }
 
 __global__ __launch_bounds__(TILE_B) void k_rows_tile(const DomainDev D, const double4 *pos4, const int *tag,
                                                       const int *bin_of, const int4 *cells, int *rowcount, int *neigh,
-                                                      int *skin, int pitch, int cap, int capskin, const double3 binsize,
+                                                      int *scratch, int pitch, int cap, const double3 binsize,
                                                       const int3 nbrick, int4 *blockstat, int *fallback)
 {
   __shared__ TileCand s_cand[TILE_CAP];
@@ -633,30 +640,41 @@ __global__ __launch_bounds__(TILE_B) void k_rows_tile(const DomainDev D, const d
     const int tk = tag[k];
     const int b = bin_of[k];
     const int bx = b % D.nbin[0], by = (b / D.nbin[0]) % D.nbin[1], bz = b / (D.nbin[0] * D.nbin[1]);
-    int c0, ns;
-    tile_walk(D, binsize, k, pk, tk, bx, by, bz, r0x, r0y, r0z, s_start, s_cand, c0, ns, neigh, skin, pitch, cap, capskin);
-    const int cnt = c0 + ns;
-    if (cnt <= cap && ns <= capskin) {
-      // append the skin classes behind class 0, each in discovery order (the lane reads back its own writes):
-      // count the classes, then place the entries
-      int c1 = 0, c2 = 0;
-      for (int e = 0; e < ns; e++) {
-        const int cls = (skin[(size_t) e * pitch + k] >> 30) & 3;
-        c1 += cls == 1;
-        c2 += cls == 2;
+    unsigned cc;
+    const int cnt = tile_walk(D, binsize, k, pk, tk, bx, by, bz, r0x, r0y, r0z, s_start, s_cand, scratch, pitch, cap, cc);
+    if (cnt <= cap) {
+      // the row: the column's entries class by class, each class in discovery order (the lane reads back its own
+      // writes), eight loads in flight
+      const int *col = scratch + k;
+      int c0 = (int) (cc & 255u), c1 = (int) ((cc >> 8) & 255u), c2 = (int) ((cc >> 16) & 255u);
+      if (cnt >= 256) {  // the byte counters of the walk have wrapped: count the column
+        c0 = c1 = c2 = 0;
+        for (int e = 0; e < cnt; e++) {
+          const int cls = (col[(size_t) e * pitch] >> 30) & 3;
+          c0 += cls == 0;
+          c1 += cls == 1;
+          c2 += cls == 2;
+        }
       }
-      int p1 = c0, p2 = c0 + c1, p3 = c0 + c1 + c2;
-      for (int e = 0; e < ns; e++) {
-        const int ent = skin[(size_t) e * pitch + k];
-        const int cls = (ent >> 30) & 3;
-        const int slot = cls == 1 ? p1 : (cls == 2 ? p2 : p3);
-        p1 += cls == 1;
-        p2 += cls == 2;
-        p3 += cls == 3;
-        neigh[(size_t) slot * pitch + k] = ent & 0x3FFFFFFF;
+      int p0 = 0, p1 = c0, p2 = c0 + c1, p3 = c0 + c1 + c2;
+      for (int e = 0; e < cnt; e += 8) {
+        int ent[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) ent[u] = col[(size_t) min(e + u, cnt - 1) * pitch];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          if (e + u < cnt) {
+            const int cls = (ent[u] >> 30) & 3;
+            const int slot = cls == 0 ? p0 : (cls == 1 ? p1 : (cls == 2 ? p2 : p3));
+            p0 += cls == 0;
+            p1 += cls == 1;
+            p2 += cls == 2;
+            p3 += cls == 3;
+            neigh[(size_t) slot * pitch + k] = ent[u] & 0x3FFFFFFF;
+          }
+        }
       }
     }
-    mxs = max(mxs, ns);
     rowcount[k] = cnt;
     mx = max(mx, cnt);
     tot += (unsigned long long) cnt;
@@ -995,16 +1013,15 @@ void build_bins_and_rows(ucg_ctx *ctx)
   if (tiled) {
     const int3 nbrick = make_int3((D.nbin[0] + TILE_BX - 1) / TILE_BX, (D.nbin[1] + 3) / 4, (D.nbin[2] + 3) / 4);
     const long long nblocks = (long long) nbrick.x * nbrick.y * nbrick.z;
-    int capskin = D.skin_capacity > 0 ? D.skin_capacity : 48;
     for (int attempt = 0; attempt < 4; attempt++) {
       ctx->neigh.reserve((size_t) pitch * (size_t) cap);
-      D.scratch.reserve((size_t) pitch * (size_t) capskin);
+      D.scratch.reserve((size_t) pitch * (size_t) cap);
       UCG_HIP(hipMemsetAsync(D.rowstat.get(), 0, 8 * sizeof(unsigned long long), st));
       D.blockstat.reserve((size_t) nblocks + 1);
       UCG_HIP(hipMemsetAsync(D.blockstat.get(), 0, (size_t) nblocks * sizeof(int4), st));
       hipLaunchKernelGGL(k_rows_tile, dim3((unsigned) nblocks), dim3(TILE_B), 0, st, dd, ctx->pos4.get(), ctx->tag.get(),
                          D.bin_of.get(), D.cells.get(), ctx->numneigh.get(), ctx->neigh.get(), D.scratch.get(), pitch, cap,
-                         capskin, bs, nbrick, D.blockstat.get(), (int *) (D.rowstat.get() + 2));
+                         bs, nbrick, D.blockstat.get(), (int *) (D.rowstat.get() + 2));
       hipLaunchKernelGGL(k_rowstat_fold, dim3(1), dim3(1024), 0, st, (int) nblocks, D.blockstat.get(),
                          D.rowstat.get());
       unsigned long long stat[6];
@@ -1016,12 +1033,8 @@ void build_bins_and_rows(ucg_ctx *ctx)
       }
       maxrow = (int) (stat[0] & 0xFFFFFFFFull);
       total = (long long) stat[1];
-      const int maxskin = (int) (stat[3] & 0xFFFFFFFFull);
-      const bool fits = maxrow <= cap && maxskin <= capskin;
-      D.skin_capacity = maxskin + 8;
-      if (fits) break;
-      if (maxrow > cap) cap = maxrow + 16;
-      if (maxskin > capskin) capskin = maxskin + 8;
+      if (maxrow <= cap) break;
+      cap = maxrow + 16;
       if (attempt == 3) throw InputError{"neighbour rows keep overflowing their buffers"};
     }
   }

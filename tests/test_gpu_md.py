@@ -57,6 +57,40 @@ def test_device_rebuild_matches_spec(gpu_ctx, pkg, orc, ncell, untiled):
     assert nl == beads.n
 
 
+def test_tiled_row_builder_with_rows_longer_than_its_byte_counters(gpu_ctx, pkg, orc):
+    """a dense clump inside a dilute melt: rows of more than 255 entries (the tiled builder counts a row's distance classes in
+    byte fields while it walks the candidates and recounts such a row from its column), candidates still within the staging
+    capacity of a brick: the rows are the specification's, entry by entry, and the tiled builder did build them"""
+    deck = util.make_deck("spline", 1024)
+    beads = pkg.synth.make_beads(12, seed=4)
+    rng = np.random.default_rng(99)
+    centre = 0.5 * (beads.boxlo + beads.boxhi)
+    m = 330
+    d = rng.normal(size=(m, 3))
+    d *= (1.2 * rng.random(m) ** (1.0 / 3.0) / np.linalg.norm(d, axis=1))[:, None]
+    beads.x[:m] = centre + d  # 330 beads inside a ball of radius 1.2: all within the list cutoff of one another
+    op = util.oracle_pair("table_ucgld", deck)
+    sim = util.oracle_sim(beads, op, mode=1)
+    sim.rebuild()
+    _setup_gpu(gpu_ctx, beads, 0.002, 1)
+    gpu_ctx.neigh_rebuild()
+    info = gpu_ctx.md_info()
+    gl = gpu_ctx.neigh_download()
+    ol = sim.full_list()
+    assert int(ol[1].max()) >= 300 and info["maxrow"] == int(ol[1].max())
+    for a, b in zip(gl, ol):
+        assert np.array_equal(a, b)
+    # the same rows from the one-lane-per-bead builder
+    gpu_ctx.set_option("rows_untiled", 1)
+    try:
+        gpu_ctx.upload_beads(beads)
+        gpu_ctx.neigh_rebuild()
+    finally:
+        gpu_ctx.set_option("rows_untiled", 0)
+    for a, b in zip(gpu_ctx.neigh_download(), ol):
+        assert np.array_equal(a, b)
+
+
 CASES = [
     # style, extra keywords, langevin, ucgstate, dt, steps, every, integrator
     ("table_ucgld", (), (1.0, 1.0, 1.0, 48279), "ld", 0.004, 120, 1, True),
