@@ -252,6 +252,9 @@ void VerletUCGGPU::download_atoms(bool with_energy)
 
 void VerletUCGGPU::device_setup()
 {
+  // Verlet::setup(): ev_set() tells compute pe / compute pressure that energy and virial are tallied on this step
+  // (update->eflag_global / vflag_global; without it thermo stops with "Energy was not tallied on needed timestep")
+  ev_set(update->ntimestep);
   upload_atoms();
   attach_communicator();
   if (fix_cs) fix_cs->create_on_device(ctx);
@@ -291,6 +294,7 @@ void VerletUCGGPU::run(int n)
     const bigint gap = output->next - update->ntimestep;
     const int chunk = (gap > 0 && gap < (bigint) left) ? (int) gap : left;
     const bool out = (update->ntimestep + chunk == output->next);
+    if (out) ev_set(update->ntimestep + chunk);    // the step whose energy / virial the output's computes will ask for
     check(ucg_md_run_until(ctx, chunk, out ? 1 : 0));
     update->ntimestep += chunk;
     left -= chunk;

@@ -197,6 +197,8 @@ class Integrate : protected Pointers {
 
  protected:
   int eflag, vflag;
+  void ev_setup();
+  void ev_set(bigint);
 };
 class Respa : public Integrate {
  public:
