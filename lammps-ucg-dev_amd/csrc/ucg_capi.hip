@@ -498,6 +498,7 @@ int ucg_pair_init(ucg_pair *p, int ntypes, double T)
       // compact FAST block for the lanes that read their tables through L1 / L2
       p->kinds = false;
       D.kinds = KindsDev{nullptr, nullptr};
+      D.tcache = nullptr;
       if (fast && !D.tab_in_lds && !bitmap && M.n_actual > 1 && ctx->kind_blocks && M.style == STYLE_BETHE_DENSITY) {
         const int na1 = M.n_actual + 1;
         std::vector<int2> dir((size_t) na1 * na1, make_int2(0, 0));
@@ -792,6 +793,11 @@ static int pair_compute_impl(ucg_pair *p, int eflag, int vflag, double *eng_vdwl
       p->d_cv.reserve(nall + 1);
       p->d_partial.reserve((size_t) ctx->nlocal + 1);
       p->d_evpart.reserve((size_t) density_evpart_doubles(ctx->nlocal));
+      p->dev.tcache = nullptr;
+      if (ctx->density_tcache && ctx->list_maxrow > 0) {
+        p->d_tcache.reserve((size_t) ctx->list_pitch * (size_t) ctx->list_maxrow);
+        p->dev.tcache = p->d_tcache.get();
+      }
       UCG_HIP(launch_density(p->dev, ctx->atoms_dev(), ctx->list_dev(), ctx->ghost_src.get(), ev, p->d_prior.get(),
                              p->d_partial.get(), p->d_cv.get(), p->d_evpart.get(), p->d_evout.get(), p->d_err.get(),
                              ctx->stream));
@@ -851,6 +857,11 @@ int ucg_pair_density_phase(ucg_pair *p, int phase, int eflag, int vflag, double 
     if (ctx->list_inum != ctx->nlocal) return fail(ctx, UCG_ERR_INVALID, "no neighbour list for the current beads");
     const bool ev = (eflag || vflag);
     if (phase == 1) {
+      p->dev.tcache = nullptr;
+      if (ctx->density_tcache && ctx->list_maxrow > 0) {
+        p->d_tcache.reserve((size_t) ctx->list_pitch * (size_t) ctx->list_maxrow);
+        p->dev.tcache = p->d_tcache.get();
+      }
       const size_t nall = (size_t) ctx->nlocal + ctx->nghost;
       p->d_prior.reserve(nall + 1);
       p->d_cv.reserve(nall + 1);
@@ -1800,6 +1811,10 @@ int ucg_ctx_set_option(ucg_ctx *ctx, const char *name, int value)
   }
   if (std::strcmp(name, "kind_blocks") == 0) {
     ctx->kind_blocks = value != 0;
+    return UCG_OK;
+  }
+  if (std::strcmp(name, "density_tcache") == 0) {
+    ctx->density_tcache = value != 0;
     return UCG_OK;
   }
   if (std::strcmp(name, "stage_own") == 0) {

@@ -178,6 +178,7 @@ struct ucg_ctx {
   long long list_gen = 0;      // changes whenever the rows change (device build or upload): what derived lists key on
   bool list_from_builder = false;  // rows made by the device builder (which sets no special-bond bits)
   bool kind_blocks = true;         // option "kind_blocks": KindsDev
+  bool density_tcache = true;      // option "density_tcache": PairDev::tcache
   // shared RanMars jump table
   ucg::DevBuf<unsigned int> rm_jump;
   int rm_chunks = 0;
@@ -236,6 +237,7 @@ struct ucg_pair {
   // table_ucg_bethe_density
   ucg::DevBuf<double2> d_prior, d_cv;
   ucg::DevBuf<double> d_partial, d_denspar;
+  ucg::DevBuf<double> d_tcache;  // PairDev::tcache: one double per list entry
   ucg::DevBuf<int> d_densflags;
   std::vector<int> tabmap;  // host table id -> device table id (or -1)
   std::string err;

@@ -108,6 +108,7 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass1(const PairDev P, c
     const int n = Lst.numneigh[k];
     const int *rp = Lst.neigh + k;
     const size_t pitch = (size_t) Lst.pitch;
+    double *const tc = P.tcache ? P.tcache + k : nullptr;
     double rho = 0.0;
     // one-deep software pipeline: the next entry's bead is in flight while this one is evaluated
     int ent = n > 0 ? rp[0] : 0, ent_n = n > 1 ? rp[pitch] : ent;
@@ -126,7 +127,11 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass1(const PairDev P, c
       const double rsq = dx * dx + dy * dy + dz * dz;
       double cutv = cut11;
       if (!onetype) cutv = s_cutsq[tk * na1 + tm];  // (uniform branch)
-      if (rsq < cutv) rho += prox_fn_t(ucg_tanh(prox_arg(sqrt(rsq), rth, w, rw, wok)));
+      if (rsq < cutv) {
+        const double t = ucg_tanh(prox_arg(sqrt(rsq), rth, w, rw, wok));
+        rho += prox_fn_t(t);
+        if (tc) tc[(size_t) e * pitch] = t;  // pass 3 needs tanh of the same argument for this entry
+      }
       ent_n = ent_nn;
       pm = pm_n;
       mm = mm_n;
@@ -468,6 +473,10 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass3(const PairDev P, c
     double4 pm;
     int mm;
     gather_bead(A, O, ent & 0x1FFFFFFF, pm, mm);
+    // pass 1's tanh of this bead's in-cutoff entries (valid where pass 1 evaluated the entry: dens_k and inside the cutoff --
+    // the conditions of `in_k` below, on the same positions), fetched one entry ahead like the beads
+    const double *tc = (P.tcache && dens_k) ? P.tcache + k : nullptr;
+    double tc_cur = (tc && n > 0) ? tc[0] : 0.0;
     rp += pitch;
     for (int e = 0; e < n; e++) {
       rp += pitch;
@@ -475,6 +484,7 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass3(const PairDev P, c
       double4 pm_n;
       int mm_n;
       gather_bead(A, O, ent_n & 0x1FFFFFFF, pm_n, mm_n);
+      const double tc_n = (tc && e + 1 < n) ? tc[(size_t) (e + 1) * pitch] : 0.0;
       const int m = ent & 0x1FFFFFFF;
       const int tm = UCG_META_TYPE(mm);
       const double dx = pk.x - pm.x, dy = pk.y - pm.y, dz = pk.z - pm.z;
@@ -498,7 +508,7 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass3(const PairDev P, c
         const bool dok = recip_ok(distance);
         double w_own = 0.0;
         if (in_k) {
-          const double t = ucg_tanh(prox_arg(distance, rth_k, w_k, rw_k, wok_k));
+          const double t = tc ? tc_cur : ucg_tanh(prox_arg(distance, rth_k, w_k, rw_k, wok_k));
           w_own = P.dens_as_shipped ? prox_fn_t(t) : prox_der_t(t, w_k);
           for (int s = 0; s < 2; s++) {
             const double num = (s ? cvk.y : cvk.x) * w_own;
@@ -541,6 +551,7 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass3(const PairDev P, c
       ent_n = ent_nn;
       pm = pm_n;
       mm = mm_n;
+      tc_cur = tc_n;
     }
     A.frc4[k] = f;
   }

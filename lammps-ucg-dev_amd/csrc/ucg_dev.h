@@ -73,6 +73,9 @@ struct PairDev {
   const double4 *tab_hot;
   double special_lj[4];
   KindsDev kinds;
+  // table_ucg_bethe_density: tanh of the proximity argument of every in-cutoff entry, written by pass 1 at the entry's place
+  // (e * pitch + k) and read back by pass 3, which needs the same value for the same pair (nullptr: pass 3 evaluates it again)
+  double *tcache;
 };
 
 struct AtomsDev {

@@ -346,6 +346,11 @@ def test_pair_bethe_density_parity(fresh_ctx, pkg, orc, tabstyle, tablength, ent
     assert np.allclose(vir, ev["virial"], rtol=1e-10, atol=1e-8)
     # momentum is conserved (every CV back-force has its reaction, also across periodic images)
     assert np.abs(G["f"].sum(axis=0)).max() < 1e-8 * np.abs(G["f"]).max() * beads.n ** 0.5
+    # pass 3 evaluating its tanh itself instead of reading pass 1's (option density_tcache 0): the same bits
+    ctx.set_option("density_tcache", 0)
+    gp.compute(0, 0)
+    assert util.bits_equal(ctx.atoms_download()["f"], O["f"])
+    ctx.set_option("density_tcache", 1)
     # the reference's loop shape (sequential sweep, scatter to j): same numbers, other association
     sim0 = util.oracle_sim(beads, op, mode=0)
     sim0.rebuild()
