@@ -83,9 +83,9 @@ int ucg_ctx_set_units(ucg_ctx *ctx, double boltz, double ftm2v, double mvv2e, do
  *   "hot_block"     tables too large for the LDS: with several actual types the three tables of the pairs of the most
  *                   populous type with itself, with one type the far end of the r^2 grid, are staged in LDS all the
  *                   same and read there by the lanes they serve (default 1; set before ucg_pair_init)
- *   "kind_blocks"   table_ucg_bethe_density on several actual types, tables read through L1 / L2: the lanes that do so read
- *                   a compact block per (row type, neighbour type) kind instead of the full layout (default 1; set
- *                   before ucg_pair_init)
+ *   "kind_blocks"   several actual types, tables read through L1 / L2 (all three styles): the lanes that do so read a
+ *                   compact block per (row type, neighbour type) kind instead of the full layout (default 1; set before
+ *                   ucg_pair_init)
  *   "density_tcache" table_ucg_bethe_density: pass 1 leaves tanh of the proximity argument of every in-cutoff entry in a buffer
  *                   of one double per list entry and pass 3 reads it back instead of evaluating it again (default 1; the
  *                   same bits either way)

@@ -494,12 +494,12 @@ int ucg_pair_init(ucg_pair *p, int ntypes, double T)
         p->host_tab = tab;
         p->host_pairtab = pairtab;
       }
-      // kind blocks (KindsDev; the density style's pass 2): the tables of every (row type, neighbour type) kind as one
+      // kind blocks (KindsDev): the tables of every (row type, neighbour type) kind as one
       // compact FAST block for the lanes that read their tables through L1 / L2
       p->kinds = false;
       D.kinds = KindsDev{nullptr, nullptr};
       D.tcache = nullptr;
-      if (fast && !D.tab_in_lds && !bitmap && M.n_actual > 1 && ctx->kind_blocks && M.style == STYLE_BETHE_DENSITY) {
+      if (fast && !D.tab_in_lds && !bitmap && M.n_actual > 1 && ctx->kind_blocks) {
         const int na1 = M.n_actual + 1;
         std::vector<int2> dir((size_t) na1 * na1, make_int2(0, 0));
         std::vector<double4> blocks;

@@ -180,27 +180,6 @@ __device__ __forceinline__ void closure_probs(const double aij, const double bij
   p01 = pj1 - p11;
 }
 
-// The quad of one entry from a compact block: knot-major records {t00, t01, [t10,] t11} x two 16-byte slots + one padding
-// slot (a kind block, KindsDev, or the LDS hot block); o10 == 2: the mixed-state tables are one table.  The same values
-// as eval_quad's FAST branch.
-template <int TS>
-__device__ __forceinline__ void eval_quad_kind(const double2 *blk, const int stride, const int o10, const int o11,
-                                               const double4 par, const int tlm1, const double rsq, Quad &q, RangeTrack &rt)
-{
-  const int it = grid_locate_track(par, tlm1, rsq, rt);
-  const Basis B = grid_basis<TS>(par, it, rsq);
-  const double2 *rec = blk + it * stride;
-  knot_eval_fast<TS>(rec, stride, par.w, B, q.f00, q.u00);
-  knot_eval_fast<TS>(rec + 2, stride, par.w, B, q.f01, q.u01);
-  if (o10 == 2) {
-    q.f10 = q.f01;
-    q.u10 = q.u01;
-  } else {
-    knot_eval_fast<TS>(rec + o10, stride, par.w, B, q.f10, q.u10);
-  }
-  knot_eval_fast<TS>(rec + o11, stride, par.w, B, q.f11, q.u11);
-}
-
 // what one in-cutoff entry adds to its row owner (:597-676): scores, the closure, the pair force (x 1/2 when the neighbour is
 // owned) and what the neighbour's own visit of the pair sends back, the energy / virial terms, the entropic accumulators
 struct DensAcc {

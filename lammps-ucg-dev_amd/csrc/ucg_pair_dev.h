@@ -284,6 +284,27 @@ __device__ __forceinline__ void eval_quad(TabPtr tab, const double4 *s_par, cons
   }
 }
 
+// The quad of one entry from a compact block: knot-major records {t00, t01, [t10,] t11} x two 16-byte slots + one padding
+// slot (a kind block, KindsDev, or the LDS hot block); o10 == 2: the mixed-state tables are one table.  The same values
+// as eval_quad's FAST branch.
+template <int TS>
+__device__ __forceinline__ void eval_quad_kind(const double2 *blk, const int stride, const int o10, const int o11,
+                                               const double4 par, const int tlm1, const double rsq, Quad &q, RangeTrack &rt)
+{
+  const int it = grid_locate_track(par, tlm1, rsq, rt);
+  const Basis B = grid_basis<TS>(par, it, rsq);
+  const double2 *rec = blk + it * stride;
+  knot_eval_fast<TS>(rec, stride, par.w, B, q.f00, q.u00);
+  knot_eval_fast<TS>(rec + 2, stride, par.w, B, q.f01, q.u01);
+  if (o10 == 2) {
+    q.f10 = q.f01;
+    q.u10 = q.u01;
+  } else {
+    knot_eval_fast<TS>(rec + o10, stride, par.w, B, q.f10, q.u10);
+  }
+  knot_eval_fast<TS>(rec + o11, stride, par.w, B, q.f11, q.u11);
+}
+
 // bias_force of fix nve/ucgld/wall/hard (UCG/fix_nve_ucgld_wall_hard.cpp:216-221), as in csrc/ucg_fix.hip
 __device__ __forceinline__ double post_wall_bias(const double lmd, const double H)
 {

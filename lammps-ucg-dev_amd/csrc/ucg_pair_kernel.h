@@ -85,6 +85,7 @@ __global__ __launch_bounds__(PAIR_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4
   const bool stage_own = P.stage_own != 0;
   // tables through L1 / L2 with one actual type's block in LDS all the same (PairDev::hot_type)
   const int hot_ent = (!LDS_TAB && FAST && TS != 3) ? P.hot_ent : 0;
+  const bool kcold = !LDS_TAB && FAST && TS != 3 && P.kinds.kind_tab != nullptr;
   double4 *s_ownpos = s_tab + (LDS_TAB ? ntabent : hot_ent);
   int *s_ownmeta = reinterpret_cast<int *>(s_ownpos + PAIR_BLOCK / SLOTS);
   // table_ucg_bethe: ucgp of the workgroup's own beads as well (8 bytes per bead behind the meta words)
@@ -103,7 +104,12 @@ __global__ __launch_bounds__(PAIR_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4
   {
     const int na1sq = (P.n_actual + 1) * (P.n_actual + 1);
     for (int t = threadIdx.x; t < P.ntab; t += blockDim.x) s_par[t] = P.tabpar[t];
-    for (int t = threadIdx.x; t < na1sq * 4; t += blockDim.x) s_pairtab[t] = P.pairtab[t];
+    // (tables through L1 / L2 on several actual types: the cold lanes read the compact block of their pair's kind, KindsDev,
+    // and need its directory instead of the table ids -- in the same LDS words)
+    if (kcold)
+      for (int t = threadIdx.x; t < na1sq; t += blockDim.x) reinterpret_cast<int2 *>(s_pairtab)[t] = P.kinds.kind_dir[t];
+    else
+      for (int t = threadIdx.x; t < na1sq * 4; t += blockDim.x) s_pairtab[t] = P.pairtab[t];
     for (int t = threadIdx.x; t < na1sq; t += blockDim.x) s_cutsq[t] = P.cutsq[t];
     if (LDS_TAB)
       for (int t = threadIdx.x; t < ntabent; t += blockDim.x) s_tab[t] = (FAST ? P.tab_fast : P.tab)[t];
@@ -262,6 +268,8 @@ __global__ __launch_bounds__(PAIR_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4
         int pt[4];
         if (onetype) {
           pt[0] = pt11_0; pt[1] = pt11_1; pt[2] = pt11_2; pt[3] = pt11_3;
+        } else if (kcold) {
+          pt[0] = pt[1] = pt[2] = pt[3] = 0;  // (the kind's directory stands where the table ids were)
         } else {
           const int *ps = s_pairtab + (tk * na1 + tm) * 4;
           pt[0] = ps[0]; pt[1] = ps[1]; pt[2] = ps[2]; pt[3] = ps[3];
@@ -269,7 +277,16 @@ __global__ __launch_bounds__(PAIR_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4
         Quad q;
         if (LDS_TAB) eval_quad<TS, FAST, ONETYPE>(s_tab, s_par, pt, P.tablength, P.tlm1, P.fast_stride, rsq, factor_lj, q, err, rtrack,
                                                   nullptr, false, -1, FAST ? &parF : nullptr);
-        else eval_quad<TS, FAST>(FAST ? P.tab_fast : P.tab, s_par, pt, P.tablength, P.tlm1, P.fast_stride, rsq, factor_lj, q, err, rtrack,
+        else if (kcold) {
+          // per lane: the LDS hot block (stride 7, {t00, t01 = t10, t11}) or the kind's block in global memory
+          const bool hot = hot_ent && tk == P.hot_type && tm == P.hot_type;
+          const int2 kd = reinterpret_cast<const int2 *>(s_pairtab)[tk * na1 + tm];
+          const int stride = hot ? 7 : 2 * kd.y + 1;
+          const double2 *base = hot ? reinterpret_cast<const double2 *>(s_tab)
+                                    : reinterpret_cast<const double2 *>(P.kinds.kind_tab) + 2 * (size_t) kd.x;
+          const bool three = hot || kd.y == 3;
+          eval_quad_kind<TS>(base, stride, three ? 2 : 4, three ? 4 : 6, parF, P.tlm1, rsq, q, rtrack);
+        } else eval_quad<TS, FAST>(FAST ? P.tab_fast : P.tab, s_par, pt, P.tablength, P.tlm1, P.fast_stride, rsq, factor_lj, q, err, rtrack,
                                  hot_ent ? reinterpret_cast<const double2 *>(s_tab) : nullptr, tk == P.hot_type && tm == P.hot_type, P.hot_k0);
 
         double evdwl = 0.0, fpair;

@@ -16,11 +16,13 @@ def _setup_gpu(ctx, beads, dt, every):
 
 
 @pytest.mark.parametrize("style", ["table_ucgld", "table_ucg_bethe"])
-@pytest.mark.parametrize("n_actual,tablength,hot_block", [(2, 256, 1), (3, 128, 1), (2, 1024, 1), (2, 1024, 0), (3, 1024, 1)])
-def test_several_actual_types_forces_bitwise(fresh_ctx, pkg, orc, style, n_actual, tablength, hot_block):
+@pytest.mark.parametrize("n_actual,tablength,hot_block,kind_blocks",
+                         [(2, 256, 1, 1), (3, 128, 1, 1), (2, 1024, 1, 1), (2, 1024, 0, 1), (3, 1024, 1, 1), (2, 1024, 1, 0), (3, 1024, 0, 0)])
+def test_several_actual_types_forces_bitwise(fresh_ctx, pkg, orc, style, n_actual, tablength, hot_block, kind_blocks):
     """tables per actual pair, cutoffs and mu per type: the general (not one-type) path of the pair kernels;
     2 x 1024-knot decks do not fit LDS and read their tables through L2, with (option hot_block, the default) the block
-    of the most populous type in LDS next to that path"""
+    of the most populous type in LDS next to that path and (option kind_blocks, the default) the cold lanes reading a compact
+    block per (row type, neighbour type) kind instead of the full layout"""
     deck = util.make_multi_deck(n_actual, "spline", tablength)
     beads = util.multi_type_beads(pkg, 9, n_actual, seed=17)
     beads.ucgp = np.clip(np.random.default_rng(3).uniform(size=beads.n), 1e-6, 1 - 1e-6)
@@ -32,6 +34,7 @@ def test_several_actual_types_forces_bitwise(fresh_ctx, pkg, orc, style, n_actua
     assert len(np.unique(O["type"])) == n_actual
     ctx = fresh_ctx
     ctx.set_option("hot_block", hot_block)
+    ctx.set_option("kind_blocks", kind_blocks)
     _setup_gpu(ctx, beads, 0.002, 1)
     ctx.neigh_rebuild()
     gp = util.gpu_pair_multi(ctx, style, deck)
