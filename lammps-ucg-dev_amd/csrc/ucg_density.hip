@@ -244,7 +244,9 @@ __device__ __forceinline__ void density_pair_terms(const Quad &q, const bool mix
   }
 }
 
-template <int TS, bool EV, bool LDS_TAB, bool FAST>
+// KTP2: 1 = kT is a power of two (known on the host): u / kT is the exact product u * (1 / kT) and the general quotient's
+// branch goes at compile time; -1 = P.kT_pow2 decides at run time
+template <int TS, bool EV, bool LDS_TAB, bool FAST, int KTP2 = -1>
 __global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass2(const PairDev P, const AtomsDev A, const ListDev Lst,
                                                              const double2 *prior, const double *partial0, double2 *cv,
                                                              double *evpart, int *errflag)
@@ -295,7 +297,7 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass2(const PairDev P, c
   const int nlocal = A.nlocal;
   const int na1 = P.n_actual + 1;
   const double kT = P.kT, rkT = P.rkT;
-  const int kTp2 = P.kT_pow2;
+  const int kTp2 = KTP2 >= 0 ? KTP2 : P.kT_pow2;
   double ev[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int err = 0;
   RangeTrack rtrack = range_track_init();
@@ -574,6 +576,9 @@ hipError_t launch_pass2(const PairDev &Pin, const AtomsDev &A, const ListDev &L,
 #define UCG_LAUNCH(EVF, LDSF, FASTF)                                                                     \
   do {                                                                                                   \
     auto kern = k_density_pass2<TS, EVF, LDSF, FASTF>;                                                   \
+    if constexpr (FASTF) {                                                                               \
+      if (P.kT_pow2) kern = k_density_pass2<TS, EVF, LDSF, FASTF, 1>;                                    \
+    }                                                                                                    \
     if (ldsbytes > 48 * 1024) {                                                                          \
       hipError_t e = hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                          (int) ldsbytes);                                                \
