@@ -173,7 +173,12 @@ __device__ __forceinline__ void closure_probs(const double aij, const double bij
                                               double &p01, double &p10, double &p11)
 {
   const double Qij = (pi1 + pj1) * aij + 1.;
-  const double Dij = sqrt(Qij * Qij - 4. * aij * bij * pi1 * pj1);
+  // (the discriminant is used as shipped, unguarded: a negative one gives NaN through the hardware form; in [2^-700, 2^700)
+  // the bare rsq iteration returns the same bits -- ucg_sqrt_core, chosen per wavefront as in the Bethe kernel)
+  const double disc = Qij * Qij - 4. * aij * bij * pi1 * pj1;
+  double Dij;
+  if (__builtin_amdgcn_ballot_w64(!(disc >= 0x1p-700 && disc < 0x1p+700)) != 0ull) Dij = sqrt(disc);
+  else Dij = ucg_sqrt_core(disc);
   p11 = (Qij - Dij) / 2. / aij;
   p00 = 1. + p11 - pi1 - pj1;
   p10 = pi1 - p11;
