@@ -99,6 +99,9 @@ ListDev ucg_ctx::list_dev() const
   L.numneigh = numneigh.get();
   L.blockflag = nullptr;
   L.blockwant = 0;
+  // (measured on the gather kernel: 400 -> 392 us at 1 M beads, 292 MB of entries; 101 -> 105 us at 262 144 beads, 76 MB, which
+  // the 256 MB last-level cache otherwise keeps from step to step)
+  L.stream_rows = (list_entries * (long long) sizeof(int) > 192ll * 1024 * 1024) ? 1 : 0;
   L.post = PostDev{};
   return L;
 }

@@ -111,14 +111,14 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass1(const PairDev P, c
     double *const tc = P.tcache ? P.tcache + k : nullptr;
     double rho = 0.0;
     // one-deep software pipeline: the next entry's bead is in flight while this one is evaluated
-    int ent = n > 0 ? rp[0] : 0, ent_n = n > 1 ? rp[pitch] : ent;
+    int ent = n > 0 ? row_load(rp, Lst.stream_rows) : 0, ent_n = n > 1 ? row_load(rp + pitch, Lst.stream_rows) : ent;
     double4 pm;
     int mm;
     gather_bead(A, O, ent & 0x1FFFFFFF, pm, mm);
     rp += pitch;
     for (int e = 0; e < n; e++) {
       rp += pitch;
-      const int ent_nn = (e + 2 < n) ? rp[0] : ent_n;
+      const int ent_nn = (e + 2 < n) ? row_load(rp, Lst.stream_rows) : ent_n;
       double4 pm_n;
       int mm_n;
       gather_bead(A, O, ent_n & 0x1FFFFFFF, pm_n, mm_n);
@@ -352,14 +352,14 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass2(const PairDev P, c
       parF = make_double4(uniform_f64(pg.x), uniform_f64(pg.y), uniform_f64(pg.z), uniform_f64(pg.w));
     }
     // one-deep software pipeline: the next entry's bead is in flight while this one is evaluated
-    int ent = n > 0 ? rp[0] : 0, ent_n = n > 1 ? rp[pitch] : ent;
+    int ent = n > 0 ? row_load(rp, Lst.stream_rows) : 0, ent_n = n > 1 ? row_load(rp + pitch, Lst.stream_rows) : ent;
     double4 pm;
     int mm;
     gather(ent, pm, mm);
     rp += pitch;
     for (int e = 0; e < n; e++) {
       rp += pitch;
-      const int ent_nn = (e + 2 < n) ? rp[0] : ent_n;
+      const int ent_nn = (e + 2 < n) ? row_load(rp, Lst.stream_rows) : ent_n;
       double4 pm_n;
       int mm_n;
       gather(ent_n, pm_n, mm_n);
@@ -455,22 +455,24 @@ __global__ __launch_bounds__(PAIR_BLOCK) void k_density_pass3(const PairDev P, c
     const int n = Lst.numneigh[k];
     const int *rp = Lst.neigh + k;
     const size_t pitch = (size_t) Lst.pitch;
-    int ent = n > 0 ? rp[0] : 0, ent_n = n > 1 ? rp[pitch] : ent;
+    int ent = n > 0 ? row_load(rp, Lst.stream_rows) : 0, ent_n = n > 1 ? row_load(rp + pitch, Lst.stream_rows) : ent;
     double4 pm;
     int mm;
     gather_bead(A, O, ent & 0x1FFFFFFF, pm, mm);
     // pass 1's tanh of this bead's in-cutoff entries (valid where pass 1 evaluated the entry: dens_k and inside the cutoff --
     // the conditions of `in_k` below, on the same positions), fetched one entry ahead like the beads
     const double *tc = (P.tcache && dens_k) ? P.tcache + k : nullptr;
-    double tc_cur = (tc && n > 0) ? tc[0] : 0.0;
+    const int strm = Lst.stream_rows;
+    double tc_cur = (tc && n > 0) ? (strm ? __builtin_nontemporal_load(tc) : tc[0]) : 0.0;
     rp += pitch;
     for (int e = 0; e < n; e++) {
       rp += pitch;
-      const int ent_nn = (e + 2 < n) ? rp[0] : ent_n;
+      const int ent_nn = (e + 2 < n) ? row_load(rp, Lst.stream_rows) : ent_n;
       double4 pm_n;
       int mm_n;
       gather_bead(A, O, ent_n & 0x1FFFFFFF, pm_n, mm_n);
-      const double tc_n = (tc && e + 1 < n) ? tc[(size_t) (e + 1) * pitch] : 0.0;
+      const double *tcp = tc + (size_t) (e + 1) * pitch;
+      const double tc_n = (tc && e + 1 < n) ? (strm ? __builtin_nontemporal_load(tcp) : *tcp) : 0.0;
       const int m = ent & 0x1FFFFFFF;
       const int tm = UCG_META_TYPE(mm);
       const double dx = pk.x - pm.x, dy = pk.y - pm.y, dz = pk.z - pm.z;

@@ -120,6 +120,9 @@ struct ListDev {
   // workgroups that touch no ghost): run only workgroups with blockflag[chunk] == blockwant
   const int *blockflag;
   int blockwant;
+  // 1: the rows are larger than the last-level cache (ucg_ctx::list_dev: more than 192 MB of entries) and are read with
+  // non-temporal loads, so that they do not displace the beads the gathers re-read; smaller lists stay cached from step to step
+  int stream_rows;
   PostDev post;
 };
 

@@ -305,6 +305,12 @@ __device__ __forceinline__ void eval_quad_kind(const double2 *blk, const int str
   knot_eval_fast<TS>(rec + o11, stride, par.w, B, q.f11, q.u11);
 }
 
+// one word of a neighbour row: a plain load, or a non-temporal one when the rows are streamed (ListDev::stream_rows; uniform)
+__device__ __forceinline__ int row_load(const int *p, const int stream)
+{
+  return stream ? __builtin_nontemporal_load(p) : *p;
+}
+
 // bias_force of fix nve/ucgld/wall/hard (UCG/fix_nve_ucgld_wall_hard.cpp:216-221), as in csrc/ucg_fix.hip
 __device__ __forceinline__ double post_wall_bias(const double lmd, const double H)
 {

@@ -60,7 +60,11 @@ __device__ __forceinline__ void gather_bead_split(const AtomsDev &A, const doubl
 // full-SCE code and the per-row reciprocals it keeps in registers are compiled out; 1 = full SCE (`pseudo no`)
 // KTP2: 1 = kT is a power of two (known on the host): u / kT is the exact product u * (1 / kT) and the general quotient's
 // code (a uniform branch and a range test per division) is compiled out; -1 = P.kT_pow2 decides at run time
-template <int STYLE, int TS, bool EV, bool LDS_TAB, bool FAST, int SLOTS, bool ONETYPE = false, int SCE = -1, int KTP2 = -1>
+// STREAM: the rows are read with non-temporal loads (lists larger than the last-level cache, ListDev::stream_rows: read once
+// per launch, they would displace the beads the gathers re-read; 400 -> 392 us at 1 M beads).  A compile-time choice: the same
+// choice behind a uniform run-time flag costs the gain.
+template <int STYLE, int TS, bool EV, bool LDS_TAB, bool FAST, int SLOTS, bool ONETYPE = false, int SCE = -1, int KTP2 = -1,
+          bool STREAM = false>
 __global__ __launch_bounds__(PAIR_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_pair_gather(const PairDev P, const AtomsDev A,
                                                            const ListDev Lst, double *evpart,
                                                            int *errflag)
@@ -227,8 +231,8 @@ __global__ __launch_bounds__(PAIR_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4
 
     // two-stage software pipeline: while entry e is evaluated, the gather of entry e+SLOTS is in
     // flight and the list word of entry e+2*SLOTS is being fetched (no exposed index-load latency)
-    int ent = (slot < n) ? rp[0] : 0;
-    int ent_n = (slot + SLOTS < n) ? rp[rstep] : ent;
+    int ent = (slot < n) ? (STREAM ? __builtin_nontemporal_load(rp) : rp[0]) : 0;
+    int ent_n = (slot + SLOTS < n) ? (STREAM ? __builtin_nontemporal_load(rp + rstep) : rp[rstep]) : ent;
     double4 pm;
     int mm;
     gather_bead_split(A, s_ownpos, s_ownmeta, k0, nown, ent & 0x1FFFFFFF, pm, mm);
@@ -244,7 +248,7 @@ __global__ __launch_bounds__(PAIR_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4
     rp += rstep;
     for (int e = slot; e < n; e += SLOTS) {
       rp += rstep;
-      const int ent_nn = (e + 2 * SLOTS < n) ? rp[0] : ent_n;
+      const int ent_nn = (e + 2 * SLOTS < n) ? (STREAM ? __builtin_nontemporal_load(rp) : rp[0]) : ent_n;
       double4 pm_n;
       int mm_n;
       gather_bead_split(A, s_ownpos, s_ownmeta, k0, nown, ent_n & 0x1FFFFFFF, pm_n, mm_n);
