@@ -89,6 +89,9 @@ int ucg_ctx_set_units(ucg_ctx *ctx, double boltz, double ftm2v, double mvv2e, do
  *   "density_tcache" table_ucg_bethe_density: pass 1 leaves tanh of the proximity argument of every in-cutoff entry in a buffer
  *                   of one double per list entry and pass 3 reads it back instead of evaluating it again (default 1; the
  *                   same bits either way)
+ *   "stream_rows"   -1 (default): neighbour rows of more than 192 MB -- more than the last-level cache keeps from step to step --
+ *                   are read with non-temporal loads, so that they do not displace the beads the gathers re-read; 0 / 1:
+ *                   never / always (the same bits either way)
  *   "post_in_pair"  per-bead hooks in the gather kernel's epilogue (default 1), "md_no_fuse" = 1 runs every hook as
  *                   its own kernel
  *   "rows_untiled"  = 1 builds neighbour rows with the one-lane-per-bead kernels (the fallback of the tiled builder)

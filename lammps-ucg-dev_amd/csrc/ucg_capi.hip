@@ -101,7 +101,7 @@ ListDev ucg_ctx::list_dev() const
   L.blockwant = 0;
   // (measured on the gather kernel: 400 -> 392 us at 1 M beads, 292 MB of entries; 101 -> 105 us at 262 144 beads, 76 MB, which
   // the 256 MB last-level cache otherwise keeps from step to step)
-  L.stream_rows = (list_entries * (long long) sizeof(int) > 192ll * 1024 * 1024) ? 1 : 0;
+  L.stream_rows = stream_rows >= 0 ? stream_rows : ((list_entries * (long long) sizeof(int) > 192ll * 1024 * 1024) ? 1 : 0);
   L.post = PostDev{};
   return L;
 }
@@ -1818,6 +1818,10 @@ int ucg_ctx_set_option(ucg_ctx *ctx, const char *name, int value)
   }
   if (std::strcmp(name, "density_tcache") == 0) {
     ctx->density_tcache = value != 0;
+    return UCG_OK;
+  }
+  if (std::strcmp(name, "stream_rows") == 0) {
+    ctx->stream_rows = value < 0 ? -1 : (value != 0 ? 1 : 0);
     return UCG_OK;
   }
   if (std::strcmp(name, "stage_own") == 0) {

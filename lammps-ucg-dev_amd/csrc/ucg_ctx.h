@@ -179,6 +179,7 @@ struct ucg_ctx {
   bool list_from_builder = false;  // rows made by the device builder (which sets no special-bond bits)
   bool kind_blocks = true;         // option "kind_blocks": KindsDev
   bool density_tcache = true;      // option "density_tcache": PairDev::tcache
+  int stream_rows = -1;            // option "stream_rows": ListDev::stream_rows (-1: by the list's size)
   // shared RanMars jump table
   ucg::DevBuf<unsigned int> rm_jump;
   int rm_chunks = 0;

@@ -30,14 +30,17 @@ hipError_t launch_hot_ts(const PairDev &P, const AtomsDev &A, const ListDev &L, 
                 : k_pair_gather<STYLE, TS, EVF, true, true, SLOTS, true>;                               \
     }                                                                                                   \
     if constexpr (SLOTS == 1 && !EVF) {                                                                 \
-      /* lists larger than the last-level cache: the variants that stream their rows (the fully tuned kernels only) */ \
-      if (L.stream_rows && p2 && P.onetype_same10) {                                                    \
+      /* lists larger than the last-level cache: the variants that stream their rows (the tuned one-type kernels) */ \
+      if (L.stream_rows && P.onetype_same10) {                                                          \
         if constexpr (STYLE == 1) {                                                                     \
           if (!P.first_possible)                                                                        \
-            kern = P.pseudo_flag ? k_pair_gather<STYLE, TS, EVF, true, true, SLOTS, true, 1, 1, true>   \
-                                 : k_pair_gather<STYLE, TS, EVF, true, true, SLOTS, true, 0, 1, true>;  \
+            kern = P.pseudo_flag ? (p2 ? k_pair_gather<STYLE, TS, EVF, true, true, SLOTS, true, 1, 1, true>   \
+                                       : k_pair_gather<STYLE, TS, EVF, true, true, SLOTS, true, 1, -1, true>) \
+                                 : (p2 ? k_pair_gather<STYLE, TS, EVF, true, true, SLOTS, true, 0, 1, true>   \
+                                       : k_pair_gather<STYLE, TS, EVF, true, true, SLOTS, true, 0, -1, true>); \
         } else {                                                                                        \
-          kern = k_pair_gather<STYLE, TS, EVF, true, true, SLOTS, true, -1, 1, true>;                   \
+          kern = p2 ? k_pair_gather<STYLE, TS, EVF, true, true, SLOTS, true, -1, 1, true>               \
+                    : k_pair_gather<STYLE, TS, EVF, true, true, SLOTS, true, -1, -1, true>;             \
         }                                                                                               \
       }                                                                                                 \
     }                                                                                                   \
