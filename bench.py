@@ -291,7 +291,7 @@ def apply_env_options(ctx):
     if os.environ.get("UCG_FMA_CONTRACT"):  # NOT the bit-exact path: see DESIGN.md 4.1; never the default
         ctx.set_option("fma_contract", int(os.environ["UCG_FMA_CONTRACT"]))
     for env, opt in (("UCG_POST_IN_PAIR", "post_in_pair"), ("UCG_STAGE_OWN", "stage_own"), ("UCG_PAIR_VROW", "pair_vrow"),
-                     ("UCG_HOT_BLOCK", "hot_block"), ("UCG_KIND_BLOCKS", "kind_blocks"), ("UCG_GENERIC_KERNELS", "generic_kernels"),
+                     ("UCG_HOT_BLOCK", "hot_block"), ("UCG_KIND_BLOCKS", "kind_blocks"), ("UCG_STREAM_ROWS", "stream_rows"), ("UCG_GENERIC_KERNELS", "generic_kernels"),
                      ("UCG_ROWS_SORT_R2", "rows_sort_r2")):  # (the last one: an experiment, not the specification's row order)
         if os.environ.get(env):
             ctx.set_option(opt, int(os.environ[env]))
