@@ -29,7 +29,7 @@ hipError_t launch_hot_ts(const PairDev &P, const AtomsDev &A, const ListDev &L, 
       kern = p2 ? k_pair_gather<STYLE, TS, EVF, true, true, SLOTS, true, -1, 1>                         \
                 : k_pair_gather<STYLE, TS, EVF, true, true, SLOTS, true>;                               \
     }                                                                                                   \
-    if constexpr (SLOTS == 1 && !EVF) {                                                                 \
+    if constexpr (!EVF) {                                                                               \
       /* lists larger than the last-level cache: the variants that stream their rows (the tuned one-type kernels) */ \
       if (L.stream_rows && P.onetype_same10) {                                                          \
         if constexpr (STYLE == 1) {                                                                     \

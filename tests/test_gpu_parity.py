@@ -392,6 +392,13 @@ def test_gather_slots_define_the_canonical_order(fresh_ctx, pkg, orc, slots, sty
     for k in ("f", "ucgforce", "scores"):
         assert util.bits_equal(G[k], O[k]), k
     assert abs(eng - sim.ev()["eng_vdwl"]) <= 1e-12 * abs(eng)
+    # ... and with the rows read by non-temporal loads (the tuned kernels of one and two lanes per bead have such variants)
+    ctx.set_option("stream_rows", 1)
+    gp.compute(0, 0)
+    gp.check_errors()
+    S = ctx.atoms_download()
+    ctx.set_option("stream_rows", -1)
+    assert util.bits_equal(S["f"], O["f"]) and util.bits_equal(S["scores"], O["scores"])
 
 
 @pytest.mark.parametrize("style", ["table_ucgld", "table_ucg_bethe"])
