@@ -11,6 +11,10 @@
 //   (halo)                       ghosts take their owner's CV forces
 //   k_density_pass3   :698-733   back-force of the density CV over the neighbours
 //
+// Pass 1 leaves tanh of every in-cutoff entry's proximity argument in PairDev::tcache (one double per list entry); pass 3,
+// which needs the same value for the same pair, reads it back.  Decks of several actual types whose tables do not fit the
+// LDS: pass 2's cold lanes read a compact table block per (row type, neighbour type) kind (KindsDev).
+//
 // The reference scatters to owned neighbours (f[j] -= ...); here a bead also evaluates what
 // each neighbour's own visit of the pair would send it (the closure with the roles swapped,
 // the neighbour's CV force), so nothing is scattered and the sums are formed in row order.
